@@ -1,0 +1,781 @@
+// gl_model.hpp -- GreenLight greenhouse + tomato-crop ODE, written from scratch for CDNA4.
+//
+// What it computes (reference behaviour, NOT reference code):
+//   dx/dt = ODE(x; u, d, p) of gl_gym/environments/models/ode.hpp:6-124, whose 239 auxiliaries
+//   are defined in gl_gym/environments/models/aux_states.hpp:96-1271.
+//
+// How it is organised (MI355X-first, nothing like the reference's flat a[0..238] list):
+//   tier 1  ModelConst<T>  -- everything that depends on the SHARED parameter block only.  Built on the
+//                             host in fp64 once per handle, passed by value in the kernarg segment, so the
+//                             compiler reads it with scalar loads and it lives in SGPRs (no VGPR cost).
+//   tier 2  StepCoef<T>    -- everything that depends on (u, d) of THIS env-step (cover optics, FIR view
+//                             factors, ventilation constants, lamp/boiler inputs...).  Per lane, VGPRs,
+//                             computed once per env-step and amortised over 4*n_sub RHS evaluations.
+//   tier 3  rhs()          -- the state-dependent remainder, one lane per environment.
+//
+// fp32-specific measures (hard part 2), all algebraically identical to the reference:
+//   * harvest switch as a logistic instead of (tanh z + 1)/2      (aux_states.hpp:75-79)
+//   * electron-transport root in its cancellation-free form        (aux_states.hpp:1076-1077)
+//   * screen air flux from (tTop - tAir) instead of rhoAir - rhoTop  (aux_states.hpp:801-809)
+//   * Arrhenius exponent from (tCan - 25 C) instead of 1/T differences (aux_states.hpp:1066)
+//   * lamp energy balance with the LAI-dependent short-wave terms cancelled analytically (ode.hpp:83-86)
+//
+// The header also compiles with a plain host compiler (GL_HD empty): tests/ builds a host-only
+// library from it to unit-test this exact arithmetic against the oracle on machines without a GPU.
+// The product (C-ABI in glgym_capi.hip) never uses that host build.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+namespace glm {
+
+constexpr int NX = 28, NU = 6, ND = 10, NP = 208;
+constexpr int NCROP = 34;            // p[128..161] -- the block parametric_crop_uncertainty perturbs (noise.py:16)
+constexpr int CROP0 = 128;
+
+// ---------------------------------------------------------------------------------------------------
+// math: fast hardware transcendentals in fp32 on the device, libm otherwise
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct Math;
+
+template <> struct Math<double> {
+    static GL_HD double exp(double v) { return ::exp(v); }
+    static GL_HD double log(double v) { return ::log(v); }
+    static GL_HD double rcp(double v) { return 1.0 / v; }
+    static GL_HD double sqrt(double v) { return ::sqrt(v); }
+    static GL_HD double powa(double av, double e) { return ::pow(av, e); }   // av >= 0
+    static GL_HD double abs(double v) { return ::fabs(v); }
+    static GL_HD double min(double a, double b) { return ::fmin(a, b); }
+    static GL_HD double max(double a, double b) { return ::fmax(a, b); }
+};
+
+template <> struct Math<float> {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static GL_HD float exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+    static GL_HD float rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+    static GL_HD float sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+    static GL_HD float powa(float av, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(av)); }
+#else
+    static GL_HD float exp(float v) { return ::expf(v); }
+    static GL_HD float rcp(float v) { return 1.0f / v; }
+    static GL_HD float sqrt(float v) { return ::sqrtf(v); }
+    static GL_HD float powa(float av, float e) { return ::powf(av, e); }
+#endif
+    static GL_HD float log(float v) { return ::logf(v); }
+    static GL_HD float abs(float v) { return ::fabsf(v); }
+    static GL_HD float min(float a, float b) { return ::fminf(a, b); }
+    static GL_HD float max(float a, float b) { return ::fmaxf(a, b); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// tier 1b: crop constants.  Uniform (part of ModelConst) unless per-env crop-parameter noise is on,
+// in which case each lane derives its own copy from its 34 perturbed parameters.
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct CropConst {
+    T sla;                      // p142
+    T j25LeafMax;               // p129
+    T cGamma, cGamma20;         // p130, 20*p130
+    T etaCo2Stom;               // p131
+    T kJ1;                      // p132 / (1e-3*R*T25)
+    T t25C;                     // p133 - 273.15
+    T jDen25;                   // 1 + exp((S*T25 - H)/(1e-3*R*T25))
+    T kS, kH;                   // p134/(1e-3 R), p135/(1e-3 R)
+    T inv2Theta, fourTheta;     // 1/(2 p136), 4 p136
+    T alpha;                    // p137
+    T mCh2o, co2PerCh2o;        // p138, p139/p138
+    T parSunUmol;               // p140
+    T cLeafMax, cFruitMax;      // p144, p145
+    T cFruitG, cLeafG, cStemG;  // p146..148
+    T maintBase;                // 1 - exp(-p149*p143)
+    T q10k;                     // 0.1*ln(p150)
+    T cFruitM, cLeafM, cStemM;  // p151..153
+    T rgFruit, rgLeaf, rgStem;  // p154..156
+    T cBufMax, cBufMin;         // p157, p158
+    T tCan24Max, tCan24Min, tCanMax, tCanMin;   // p159..162
+};
+
+// pc[i] = p[128 + i], i < 34; gasR = p39 and tCanMin = p162 come from the shared block
+template <class T, class S> GL_HD void make_crop_const(const S* pc, S gasR, S tCanMin, CropConst<T>& c)
+{
+    auto P = [&](int i) -> S { return pc[i - CROP0]; };
+    const S r3 = S(1e-3) * gasR;
+    c.sla = T(P(142));
+    c.j25LeafMax = T(P(129));
+    c.cGamma = T(P(130));
+    c.cGamma20 = T(S(20) * P(130));
+    c.etaCo2Stom = T(P(131));
+    c.kJ1 = T(P(132) / (r3 * P(133)));
+    c.t25C = T(P(133) - S(273.15));
+    c.jDen25 = T(S(1) + Math<S>::exp((P(134) * P(133) - P(135)) / (r3 * P(133))));
+    c.kS = T(P(134) / r3);
+    c.kH = T(P(135) / r3);
+    c.inv2Theta = T(S(1) / (S(2) * P(136)));
+    c.fourTheta = T(S(4) * P(136));
+    c.alpha = T(P(137));
+    c.mCh2o = T(P(138));
+    c.co2PerCh2o = T(P(139) / P(138));
+    c.parSunUmol = T(P(140));
+    c.cLeafMax = T(P(144));
+    c.cFruitMax = T(P(145));
+    c.cFruitG = T(P(146));
+    c.cLeafG = T(P(147));
+    c.cStemG = T(P(148));
+    c.maintBase = T(S(1) - Math<S>::exp(-P(149) * P(143)));
+    c.q10k = T(S(0.1) * Math<S>::log(P(150)));
+    c.cFruitM = T(P(151));
+    c.cLeafM = T(P(152));
+    c.cStemM = T(P(153));
+    c.rgFruit = T(P(154));
+    c.rgLeaf = T(P(155));
+    c.rgStem = T(P(156));
+    c.cBufMax = T(P(157));
+    c.cBufMin = T(P(158));
+    c.tCan24Max = T(P(159));
+    c.tCan24Min = T(P(160));
+    c.tCanMax = T(P(161));
+    c.tCanMin = T(tCanMin);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tier 1: constants of the shared parameter block
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct ModelConst {
+    // --- cover optics inputs (aux_states.hpp:111-220)
+    T tauRfPar, rhoRfPar, tauRfNir, rhoRfNir;                // p69 p66 p68 p65
+    T thOneMinusTauPar, thRhoPar, thOneMinusTauNir, thRhoNir, thOneMinusTauFir;   // 1-p80 p77 1-p79 p76 1-p81
+    T blOneMinusTauPar, blRhoPar, blOneMinusTauNir, blRhoNir, blOneMinusTauFir;   // 1-p90 p88 1-p89 p87 1-p91
+    T tauLampPar, rhoLampPar, tauLampNir, rhoLampNir;        // p176 p179 p177 p180
+    // --- short wave
+    T etaGlobAir, etaGlobPar, etaGlobNir;                    // p44 p6 p5
+    T thetaLampMax, etaLampPar, etaLampNir, zetaLampPar;     // p172 p174 p175 p187
+    T lampNetFrac;                                           // 1 - p174 - p175 - p186
+    T nk1Par, nk2Par, nkNir, nkFir;                          // -p32 -p33 -p34 -p35
+    T oneMinusRhoCanPar, rhoFlrPar, oneMinusRhoFlrPar;       // 1-p10 p98 1-p98
+    T rhoCanNir, oneMinusRhoCanNir, rhoFlrNir, oneMinusRhoFlrNir;   // p11 1-p11 p97 1-p97
+    // --- FIR: sigma folded into the Kelvin^4 scale, remaining factors per exchange pair.
+    T sigma;
+    // p-only coefficients (suffix: a = times aCan, g = times canopy gap exp(-kFir*lai))
+    T fCanFlr_a, fPipeFlr, fPipeCan_a, fCovESky, fLampFlr_g, fLampPipe_g, fLampCan_a, fGroPipeCan;
+    // bases that precompute() multiplies by screen positions
+    T bCanCovIn, bCanSky, bCanThScr, bPipeCovIn, bPipeSky, bPipeThScr, bFlrCovIn, bFlrSky, bFlrThScr;
+    T bThScrCovIn, bThScrSky, bLampThScr, bLampCovIn, bLampSky, bFlrBlScr, bPipeBlScr, bCanBlScr;
+    T bBlScrThScr, bBlScrCovIn, bBlScrSky, bLampBlScr;
+    // --- interlights (all zero with the default parameters; evaluated only when active)
+    int intLampActive;
+    T nkIntFirUp, nkIntFirDown;                              // -p203*(1-p189), -p203*p189
+    T iFlr, iPipe, iCan, iLamp, bIBlScr, bIThScr, bICovIn, bISky, cIntLampAir;
+    // --- ventilation (aux_states.hpp:698-779)
+    T aRoofOverFlr2;          // p55*p59/(2*p46)
+    T gHVent;                 // p26*p56
+    T cWind;                  // p61
+    T cLeakage, minWind, cLeakTop, etaInsScr;                // p60 p205 p204 p57
+    int roofOnly;             // etaRoof(=1) >= p8
+    T cDOverFlr, aRoof;       // p59/p46, p55  (used only when !roofOnly)
+    // --- air (aux_states.hpp:782-820)
+    T kPpm;                   // R_/(P*M_CO2): co2ppm = kPpm * (tAir+C2K) * co2Air
+    T kRho;                   // p36*p126/p39
+    T gHalf;                  // 0.5*p26
+    T kThScr, kBlScr;         // p84 p94
+    T rhoCp;                  // p111*p23
+    // --- convection (aux_states.hpp:824-935)
+    T hCanAir2;               // 2*p0
+    T cTopCov;                // p50*p47/p46
+    T covOut0, covOut1, covOutExp;                           // p47/p46*p51, p47/p46*p52, p53
+    T cPipeAir, cGroPipeAir;  // |1.99*pi*p105*p107|, |1.99*pi*p167*p166|
+    T cFlrSo1, cSo12, cSo23, cSo34, cSo45, cSo5Out, cCovCond, cLampAir;
+    // --- inverse capacities (ode.hpp:14-100)
+    T iCapCo2Air, iCapCo2Top, iCapAir, iCapTop, iCapCov, iCapThScr, iCapFlr, iCapPipe;
+    T iCapSo1, iCapSo2, iCapSo3, iCapSo4, iCapSo5, iCapLamp, iCapIntLamp, iCapGroPipe, iCapBlScr;
+    T capLeaf;                // p16
+    T kCapVpAir, kCapVpTop;   // p39/(p38*p48), p39/(p38*(p49-p48))
+    // --- transpiration (aux_states.hpp:940-981)
+    T rCanSp, sRsSlope;       // p40 p43
+    T cEvap3Day, cEvap3Night, cEvap4Day, cEvap4Night;        // p19 p20 p21 p22
+    T cEvap1, cEvap2, rSMin, rB, etaMgPpm;                   // p17 p18 p42 p41 p7
+    T kVec;                   // 2*p111*p23/(p1*p14)
+    T latent;                 // p1
+    // --- actuators
+    T boilPerFlr, co2PerFlr;  // p108/p46, p109/p46
+    T tEndSumInv;             // 1/p163
+    CropConst<T> crop;
+};
+
+template <class T> inline void make_model_const(const double* p, ModelConst<T>& m)
+{
+    const double PI = 3.14159265358979323846;
+    const double sigma = p[2];
+    const double aCovFir = 1.0 - p[70] - p[67];      // aux_states.hpp:201-220 (epsCovFir = aCovFir)
+    const double tauCovFir = p[70];
+    const double pipeCover = 0.49 * PI * p[107] * p[105];
+    const double pipeShade = 1.0 - pipeCover;
+    auto S = [](double v) { return T(v); };
+
+    m.tauRfPar = S(p[69]); m.rhoRfPar = S(p[66]); m.tauRfNir = S(p[68]); m.rhoRfNir = S(p[65]);
+    m.thOneMinusTauPar = S(1.0 - p[80]); m.thRhoPar = S(p[77]);
+    m.thOneMinusTauNir = S(1.0 - p[79]); m.thRhoNir = S(p[76]); m.thOneMinusTauFir = S(1.0 - p[81]);
+    m.blOneMinusTauPar = S(1.0 - p[90]); m.blRhoPar = S(p[88]);
+    m.blOneMinusTauNir = S(1.0 - p[89]); m.blRhoNir = S(p[87]); m.blOneMinusTauFir = S(1.0 - p[91]);
+    m.tauLampPar = S(p[176]); m.rhoLampPar = S(p[179]); m.tauLampNir = S(p[177]); m.rhoLampNir = S(p[180]);
+
+    m.etaGlobAir = S(p[44]); m.etaGlobPar = S(p[6]); m.etaGlobNir = S(p[5]);
+    m.thetaLampMax = S(p[172]); m.etaLampPar = S(p[174]); m.etaLampNir = S(p[175]); m.zetaLampPar = S(p[187]);
+    m.lampNetFrac = S(1.0 - p[174] - p[175] - p[186]);
+    m.nk1Par = S(-p[32]); m.nk2Par = S(-p[33]); m.nkNir = S(-p[34]); m.nkFir = S(-p[35]);
+    m.oneMinusRhoCanPar = S(1.0 - p[10]); m.rhoFlrPar = S(p[98]); m.oneMinusRhoFlrPar = S(1.0 - p[98]);
+    m.rhoCanNir = S(p[11]); m.oneMinusRhoCanNir = S(1.0 - p[11]);
+    m.rhoFlrNir = S(p[97]); m.oneMinusRhoFlrNir = S(1.0 - p[97]);
+
+    m.sigma = S(sigma);
+    const double aPipe = p[124], ePipe = p[104], eCan = p[3], eSky = p[4], eFlr = p[95], eTh = p[74], eBl = p[85];
+    const double aLamp = p[181], eLampT = p[182], eLampB = p[183], tauLampFir = p[178], tauIntFir = p[199];
+    m.fCanFlr_a = S(eCan * eFlr * p[125]);
+    m.fPipeFlr = S(aPipe * ePipe * eFlr * 0.49);
+    m.fPipeCan_a = S(aPipe * ePipe * eCan * 0.49);
+    m.fCovESky = S(aCovFir * eSky);
+    m.fLampFlr_g = S(aLamp * eLampB * eFlr * tauIntFir * pipeShade);
+    m.fLampPipe_g = S(aLamp * eLampB * ePipe * tauIntFir * pipeCover);
+    m.fLampCan_a = S(aLamp * eLampB * eCan);
+    m.fGroPipeCan = S(p[169] * p[165] * eCan);
+    m.bCanCovIn = S(eCan * aCovFir * tauLampFir);
+    m.bCanSky = S(eCan * eSky * tauLampFir * tauCovFir);
+    m.bCanThScr = S(eCan * eTh * tauLampFir);
+    m.bPipeCovIn = S(aPipe * ePipe * aCovFir * tauIntFir * tauLampFir * 0.49);
+    m.bPipeSky = S(aPipe * ePipe * eSky * tauIntFir * tauLampFir * tauCovFir * 0.49);
+    m.bPipeThScr = S(aPipe * ePipe * eTh * tauIntFir * tauLampFir * 0.49);
+    m.bFlrCovIn = S(eFlr * aCovFir * tauIntFir * tauLampFir * pipeShade);
+    m.bFlrSky = S(eFlr * eSky * tauIntFir * tauLampFir * tauCovFir * pipeShade);
+    m.bFlrThScr = S(eFlr * eTh * tauIntFir * tauLampFir * pipeShade);
+    m.bThScrCovIn = S(eTh * aCovFir);
+    m.bThScrSky = S(eTh * eSky * tauCovFir);
+    m.bLampThScr = S(aLamp * eLampT * eTh);
+    m.bLampCovIn = S(aLamp * eLampT * aCovFir);
+    m.bLampSky = S(aLamp * eLampT * eSky * tauCovFir);
+    m.bFlrBlScr = S(eFlr * eBl * tauIntFir * tauLampFir * pipeShade);
+    m.bPipeBlScr = S(aPipe * ePipe * eBl * tauIntFir * tauLampFir * 0.49);
+    m.bCanBlScr = S(eCan * eBl * tauLampFir);
+    m.bBlScrThScr = S(eBl * eTh);
+    m.bBlScrCovIn = S(eBl * aCovFir);
+    m.bBlScrSky = S(eBl * eSky * tauCovFir);
+    m.bLampBlScr = S(aLamp * eLampT * eBl);
+
+    const double aInt = p[194], eInt = p[195];
+    m.intLampActive = (aInt * eInt != 0.0 || p[198] != 0.0) ? 1 : 0;
+    m.nkIntFirUp = S(-p[203] * (1.0 - p[189]));
+    m.nkIntFirDown = S(-p[203] * p[189]);
+    m.iFlr = S(aInt * eInt * eFlr * pipeShade);
+    m.iPipe = S(aInt * eInt * ePipe * pipeCover);
+    m.iCan = S(aInt * eInt * eCan);
+    m.iLamp = S(aInt * eInt * eLampB * aLamp);
+    m.bIBlScr = S(aInt * eInt * eBl * tauLampFir);
+    m.bIThScr = S(aInt * eInt * eTh * tauLampFir);
+    m.bICovIn = S(aInt * eInt * aCovFir * tauLampFir);
+    m.bISky = S(aInt * eInt * eSky * tauCovFir * tauLampFir);
+    m.cIntLampAir = S(std::fabs(p[198]));
+
+    m.aRoofOverFlr2 = S(p[55] * p[59] / (2.0 * p[46]));
+    m.gHVent = S(p[26] * p[56]);
+    m.cWind = S(p[61]);
+    m.cLeakage = S(p[60]); m.minWind = S(p[205]); m.cLeakTop = S(p[204]); m.etaInsScr = S(p[57]);
+    m.roofOnly = (1.0 >= p[8]) ? 1 : 0;
+    m.cDOverFlr = S(p[59] / p[46]); m.aRoof = S(p[55]);
+
+    m.kPpm = S(8.3144598 / (101325.0 * 44.01e-3));
+    m.kRho = S(p[36] * p[126] / p[39]);
+    m.gHalf = S(0.5 * p[26]);
+    m.kThScr = S(p[84]); m.kBlScr = S(p[94]);
+    m.rhoCp = S(p[111] * p[23]);
+
+    m.hCanAir2 = S(std::fabs(2.0 * p[0]));
+    m.cTopCov = S(p[50] * p[47] / p[46]);
+    m.covOut0 = S(p[47] / p[46] * p[51]); m.covOut1 = S(p[47] / p[46] * p[52]); m.covOutExp = S(p[53]);
+    m.cPipeAir = S(std::fabs(1.99 * PI * p[105] * p[107]));
+    m.cGroPipeAir = S(std::fabs(1.99 * PI * p[167] * p[166]));
+    m.cFlrSo1 = S(std::fabs(2.0 / (p[101] / p[99] + p[27] / p[103])));
+    m.cSo12 = S(std::fabs(2.0 * p[103] / (p[27] + p[28])));
+    m.cSo23 = S(std::fabs(2.0 * p[103] / (p[28] + p[29])));
+    m.cSo34 = S(std::fabs(2.0 * p[103] / (p[29] + p[30])));
+    m.cSo45 = S(std::fabs(2.0 * p[103] / (p[30] + p[31])));
+    m.cSo5Out = S(std::fabs(2.0 * p[103] / (p[31] + p[37])));
+    m.cCovCond = S(std::fabs(1.0 / (p[73] / p[71])));
+    m.cLampAir = S(std::fabs(p[185]));
+
+    const double capCov = std::cos(p[45] * PI / 180.0) * p[73] * p[64] * p[72];   // aux_states.hpp:227
+    m.iCapCo2Air = S(1.0 / p[122]); m.iCapCo2Top = S(1.0 / p[123]);
+    m.iCapAir = S(1.0 / p[112]); m.iCapTop = S(1.0 / p[120]); m.iCapCov = S(1.0 / (0.1 * capCov));
+    m.iCapThScr = S(1.0 / p[119]); m.iCapFlr = S(1.0 / p[113]); m.iCapPipe = S(1.0 / p[110]);
+    m.iCapSo1 = S(1.0 / p[114]); m.iCapSo2 = S(1.0 / p[115]); m.iCapSo3 = S(1.0 / p[116]);
+    m.iCapSo4 = S(1.0 / p[117]); m.iCapSo5 = S(1.0 / p[118]);
+    m.iCapLamp = S(1.0 / p[184]); m.iCapIntLamp = S(1.0 / p[191]); m.iCapGroPipe = S(1.0 / p[171]);
+    m.iCapBlScr = S(1.0 / p[121]);
+    m.capLeaf = S(p[16]);
+    m.kCapVpAir = S(p[39] / (p[38] * p[48]));
+    m.kCapVpTop = S(p[39] / (p[38] * (p[49] - p[48])));
+
+    m.rCanSp = S(p[40]); m.sRsSlope = S(p[43]);
+    m.cEvap3Day = S(p[19]); m.cEvap3Night = S(p[20]); m.cEvap4Day = S(p[21]); m.cEvap4Night = S(p[22]);
+    m.cEvap1 = S(p[17]); m.cEvap2 = S(p[18]); m.rSMin = S(p[42]); m.rB = S(p[41]); m.etaMgPpm = S(p[7]);
+    m.kVec = S(2.0 * p[111] * p[23] / (p[1] * p[14]));
+    m.latent = S(p[1]);
+    m.boilPerFlr = S(p[108] / p[46]); m.co2PerFlr = S(p[109] / p[46]);
+    m.tEndSumInv = S(1.0 / p[163]);
+    make_crop_const<T, double>(p + CROP0, p[39], p[162], m.crop);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tier 2: per env-step coefficients (functions of u, d)
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct StepCoef {
+    // short wave
+    T sunPar, lampPar;          // PAR above the canopy from sun / lamps              (a39, a40)
+    T sunNirK, lampNir;         // (1-etaGlobAir)*etaGlobNir*iGlob ; etaLampNir*qLamp
+    T rhoCovNir, tauHatCovNir;  // a23, 1-a23
+    T sunAirPar, sunAirNirK;    // etaGlobAir*iGlob*tauCovPar*etaGlobPar ; etaGlobAir*iGlob*etaGlobNir
+    T sunCovE;                  // a80
+    T parUmolK;                 // zetaLampPar*lampPar + parSunUmol*sunPar   (x G = parCan, a191)
+    T lampAirK;                 // (etaLampPar+etaLampNir)*qLamp
+    T lampNet;                  // qLamp*(1 - etaLampPar - etaLampNir - etaLampCool)
+    // stomata (depend on rCan = a45 only)
+    T cEvap3, cEvap4, rSK;      // a169, a170, p42*a171
+    // FIR (sigma lives in the K^4 values)
+    T qSky;                     // sigma*(tSky+C2K)^4
+    T cCanCovIn, cCanSky, cCanThScr, cCanBlScr;                        // x aCan
+    T cPipeCovIn, cPipeSky, cPipeThScr, cPipeBlScr;                    // x gap
+    T cFlrCovIn, cFlrSky, cFlrThScr, cFlrBlScr;                        // x gap
+    T cThScrCovIn, cThScrSky, cLampThScr, cLampCovIn, cLampSky;
+    T cBlScrThScr, cBlScrCovIn, cBlScrSky, cLampBlScr;
+    T cIBlScr, cIThScr, cICovIn, cISky;                                // interlights (x E_up)
+    // ventilation / outside
+    T ventK;                    // etaInsScr * u3*aRoof*cD/(2 aFlr)
+    T windTerm;                 // cW*wind^2
+    T leakTop;                  // cLeakTop*fLeakage
+    T fVentSide;                // a137
+    T ventElse;                 // !roofOnly: etaInsScr*(1-scrMax)*a133 ; scrMax kept in ventK
+    T tOut, tOutK2;             // d1 ; d1 + 2*C2K
+    T vpOutOverT;               // d2/(d1 + c2k_f32)
+    T co2Out;                   // d3
+    T hAirOutK;                 // rhoCp*fVentSide
+    T covOutK;                  // |p47/p46*(p51+p52*wind^p53)|
+    T tSoOut;                   // d6
+    // screens
+    T uTh, uBl, oneMinusUTh, oneMinusUBl, kTh, kBl, hTh, hBl;   // u2 u5 1-u2 1-u5 u2*p84 u5*p94 1.7u2 1.7u5
+    // actuators
+    T hBoilPipe, mcExtAir;
+};
+
+// C-to-K offsets: the reference uses 273.15 everywhere except airMv(), whose offset is a C `float`
+template <class T> struct Kelvin {
+    static GL_HD T c2k() { return T(273.15); }
+    static GL_HD T c2kF32() { return T((double)273.15f); }
+};
+
+template <class T>
+GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const CropConst<T>& cr, StepCoef<T>& s)
+{
+    using M = Math<T>;
+    const T one = T(1);
+    const T uBoil = u[0], uCo2 = u[1], uTh = u[2], uVent = u[3], uLamp = u[4], uBl = u[5];
+    const T iGlob = d[0], tOut = d[1], vpOut = d[2], co2Out = d[3], wind = d[4], tSky = d[5], tSoOut = d[6];
+
+    // -- cover optics: roof + thermal screen + blackout screen + lamp layer (aux_states.hpp:111-216)
+    auto layer = [&](T tau1, T rho1Up, T rho1Dn, T tau2, T rho2Up, T rho2Dn, T& tau, T& rUp, T& rDn) {
+        const T r = M::rcp(one - rho1Dn * rho2Up);
+        tau = tau1 * tau2 * r;
+        rUp = rho1Up + tau1 * tau1 * rho2Up * r;
+        rDn = rho2Dn + tau2 * tau2 * rho1Dn * r;
+    };
+    T tauPar, rUpPar, rDnPar, tauNir, rUpNir, rDnNir, t2, ru2, rd2;
+    {
+        const T tauTh = one - uTh * m.thOneMinusTauPar, rhoTh = uTh * m.thRhoPar;
+        layer(m.tauRfPar, m.rhoRfPar, m.rhoRfPar, tauTh, rhoTh, rhoTh, tauPar, rUpPar, rDnPar);
+        const T tauBl = one - uBl * m.blOneMinusTauPar, rhoBl = uBl * m.blRhoPar;
+        layer(tauPar, rUpPar, rDnPar, tauBl, rhoBl, rhoBl, t2, ru2, rd2);
+        layer(t2, ru2, rd2, m.tauLampPar, m.rhoLampPar, m.rhoLampPar, tauPar, rUpPar, rDnPar);
+    }
+    {
+        const T tauTh = one - uTh * m.thOneMinusTauNir, rhoTh = uTh * m.thRhoNir;
+        layer(m.tauRfNir, m.rhoRfNir, m.rhoRfNir, tauTh, rhoTh, rhoTh, tauNir, rUpNir, rDnNir);
+        const T tauBl = one - uBl * m.blOneMinusTauNir, rhoBl = uBl * m.blRhoNir;
+        layer(tauNir, rUpNir, rDnNir, tauBl, rhoBl, rhoBl, t2, ru2, rd2);
+        layer(t2, ru2, rd2, m.tauLampNir, m.rhoLampNir, m.rhoLampNir, tauNir, rUpNir, rDnNir);
+    }
+    const T tauCovPar = tauPar, rhoCovPar = rUpPar, tauCovNir = tauNir, rhoCovNir = rUpNir;
+    const T aCovPar = one - tauCovPar - rhoCovPar, aCovNir = one - tauCovNir - rhoCovNir;
+
+    // -- short wave (aux_states.hpp:256-470)
+    const T qLamp = m.thetaLampMax * uLamp;
+    const T oneMinusAir = one - m.etaGlobAir;
+    s.sunPar = oneMinusAir * tauCovPar * m.etaGlobPar * iGlob;
+    s.lampPar = m.etaLampPar * qLamp;
+    s.sunNirK = oneMinusAir * m.etaGlobNir * iGlob;
+    s.lampNir = m.etaLampNir * qLamp;
+    s.rhoCovNir = rhoCovNir;
+    s.tauHatCovNir = one - rhoCovNir;
+    s.sunAirPar = m.etaGlobAir * iGlob * tauCovPar * m.etaGlobPar;
+    s.sunAirNirK = m.etaGlobAir * iGlob * m.etaGlobNir;
+    s.sunCovE = (aCovPar * m.etaGlobPar + aCovNir * m.etaGlobNir) * iGlob;
+    s.parUmolK = m.zetaLampPar * s.lampPar + cr.parSunUmol * s.sunPar;
+    s.lampAirK = (m.etaLampPar + m.etaLampNir) * qLamp;
+    s.lampNet = qLamp * m.lampNetFrac;
+
+    // -- stomatal response to radiation above the canopy (aux_states.hpp:940-954); rCan has no LAI term
+    const T rCan = oneMinusAir * iGlob * (m.etaGlobPar * tauCovPar + m.etaGlobNir * tauCovNir) + s.lampAirK;
+    const T sRs = M::rcp(one + M::exp(m.sRsSlope * (rCan - m.rCanSp)));
+    s.cEvap3 = m.cEvap3Night * (one - sRs) + m.cEvap3Day * sRs;
+    s.cEvap4 = m.cEvap4Night * (one - sRs) + m.cEvap4Day * sRs;
+    s.rSK = m.rSMin * (rCan + m.cEvap1) * M::rcp(rCan + m.cEvap2);
+
+    // -- FIR view factors (aux_states.hpp:476-691)
+    const T tauThF = one - uTh * m.thOneMinusTauFir, tauBlF = one - uBl * m.blOneMinusTauFir;
+    const T thbl = tauThF * tauBlF, uThBl = uTh * tauBlF;
+    const T skyK = tSky + Kelvin<T>::c2k();
+    const T sk2 = skyK * skyK;
+    s.qSky = m.sigma * sk2 * sk2;
+    s.cCanCovIn = m.bCanCovIn * thbl;    s.cCanSky = m.bCanSky * thbl;
+    s.cCanThScr = m.bCanThScr * uThBl;   s.cCanBlScr = m.bCanBlScr * uBl;
+    s.cPipeCovIn = m.bPipeCovIn * thbl;  s.cPipeSky = m.bPipeSky * tauThF;      // :520 has no blackout factor
+    s.cPipeThScr = m.bPipeThScr * uThBl; s.cPipeBlScr = m.bPipeBlScr * uBl;
+    s.cFlrCovIn = m.bFlrCovIn * thbl;    s.cFlrSky = m.bFlrSky * thbl;
+    s.cFlrThScr = m.bFlrThScr * uThBl;   s.cFlrBlScr = m.bFlrBlScr * uBl;
+    s.cThScrCovIn = m.bThScrCovIn * uTh; s.cThScrSky = m.bThScrSky * uTh;
+    s.cLampThScr = m.bLampThScr * uThBl; s.cLampCovIn = m.bLampCovIn * thbl;  s.cLampSky = m.bLampSky * thbl;
+    s.cBlScrThScr = m.bBlScrThScr * uBl * uTh;
+    s.cBlScrCovIn = m.bBlScrCovIn * uBl * tauThF;
+    s.cBlScrSky = m.bBlScrSky * uBl * tauThF;
+    s.cLampBlScr = m.bLampBlScr * uBl;
+    s.cIBlScr = m.bIBlScr * uBl;  s.cIThScr = m.bIThScr * uThBl;  s.cICovIn = m.bICovIn * thbl;  s.cISky = m.bISky * thbl;
+
+    // -- ventilation (aux_states.hpp:698-779); aSideU == 0 in the reference, so fVentSide2 == 0
+    const T fLeak = (wind < m.minWind) ? m.minWind * m.cLeakage : m.cLeakage * wind;
+    s.windTerm = m.cWind * (wind * wind);
+    const T roofK = uVent * m.aRoofOverFlr2;
+    if (m.roofOnly) {
+        s.ventK = m.etaInsScr * roofK;
+        s.ventElse = T(0);
+        s.fVentSide = (one - m.cLeakTop) * fLeak;
+    } else {
+        const T scrMax = M::max(uTh, uBl);
+        const T aRoofU = uVent * m.aRoof;
+        const T both = m.cDOverFlr * M::sqrt(T(1e-8) + aRoofU * aRoofU * s.windTerm);    // a133 with aSideU = 0
+        s.ventK = m.etaInsScr * scrMax * roofK;
+        s.ventElse = m.etaInsScr * (one - scrMax) * both;
+        s.fVentSide = (one - m.cLeakTop) * fLeak;     // etaSide = 0, fVentSide2 = 0
+    }
+    s.leakTop = m.cLeakTop * fLeak;
+    s.tOut = tOut;
+    s.tOutK2 = tOut + T(2) * Kelvin<T>::c2k();
+    s.vpOutOverT = vpOut * M::rcp(tOut + Kelvin<T>::c2kF32());
+    s.co2Out = co2Out;
+    s.hAirOutK = M::abs(m.rhoCp * s.fVentSide);
+    s.covOutK = M::abs(m.covOut0 + m.covOut1 * M::powa(wind, m.covOutExp));
+    s.tSoOut = tSoOut;
+
+    s.uTh = uTh;  s.uBl = uBl;  s.oneMinusUTh = one - uTh;  s.oneMinusUBl = one - uBl;
+    s.kTh = uTh * m.kThScr;  s.kBl = uBl * m.kBlScr;  s.hTh = T(1.7) * uTh;  s.hBl = T(1.7) * uBl;
+    s.hBoilPipe = uBoil * m.boilPerFlr;
+    s.mcExtAir = uCo2 * m.co2PerFlr;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tier 3: the state-dependent right-hand side.  x[28] -> dx[28]
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
+{
+    using M = Math<T>;
+    const T one = T(1), eps = T(1e-10), third = T(1.0 / 3.0);
+    const T c2k = Kelvin<T>::c2k();
+
+    const T co2Air = x[0], co2Top = x[1], tAir = x[2], tTop = x[3], tCan = x[4], tCovIn = x[5], tCovE = x[6];
+    const T tThScr = x[7], tFlr = x[8], tPipe = x[9], vpAir = x[15], vpTop = x[16], tLamp = x[17];
+    const T tGroPipe = x[19], tBlScr = x[20], tCan24 = x[21], cBuf = x[22], cLeaf = x[23], cStem = x[24];
+    const T cFruit = x[25], tCanSum = x[26];
+
+    // ---- canopy geometry (aux_states.hpp:233, 299-484)
+    const T lai = cr.sla * cLeaf;
+    const T e1Par = M::exp(m.nk1Par * lai);
+    const T e2Par = M::exp(m.nk2Par * lai);
+    const T eNir = M::exp(m.nkNir * lai);
+    const T gap = M::exp(m.nkFir * lai);          // FIR transmission of the canopy
+    const T aCan = one - gap;
+
+    // ---- short wave absorbed by canopy / floor / air (aux_states.hpp:299-470)
+    const T gPar = m.oneMinusRhoCanPar * ((one - e1Par) + m.rhoFlrPar * e1Par * (one - e2Par));
+    const T rParSunCan = s.sunPar * gPar;
+    const T rParLampCan = s.lampPar * gPar;
+    const T flrPar = m.oneMinusRhoFlrPar * e1Par;
+    const T rParSunFlr = flrPar * s.sunPar, rParLampFlr = flrPar * s.lampPar;
+
+    const T rhoHatCan = m.rhoCanNir * (one - eNir);
+    const T r1 = M::rcp(one - s.rhoCovNir * rhoHatCan);
+    const T tauCC = s.tauHatCovNir * eNir * r1;
+    const T rhoCCUp = s.rhoCovNir + s.tauHatCovNir * s.tauHatCovNir * rhoHatCan * r1;
+    const T rhoCCDn = rhoHatCan + eNir * eNir * s.rhoCovNir * r1;
+    const T r2 = M::rcp(one - rhoCCDn * m.rhoFlrNir);
+    const T aFlrNir = tauCC * m.oneMinusRhoFlrNir * r2;                     // a64 = a67
+    const T rhoCCF = rhoCCUp + tauCC * tauCC * m.rhoFlrNir * r2;          // a65
+    const T aCanNir = one - aFlrNir - rhoCCF;                             // a66
+    const T rNirSunCan = s.sunNirK * aCanNir;
+    const T rNirSunFlr = s.sunNirK * aFlrNir;
+    const T rNirLampCan = s.lampNir * m.oneMinusRhoCanNir * (one - eNir);
+    const T rNirLampFlr = m.oneMinusRhoFlrNir * eNir * s.lampNir;
+    const T rLampAir = s.lampAirK - rParLampCan - rNirLampCan - rParLampFlr - rNirLampFlr;
+    const T rGlobSunAir = s.sunAirPar + s.sunAirNirK * (aCanNir + aFlrNir);
+
+    // ---- long wave: sigma*T^4 per surface, then pairwise exchange (aux_states.hpp:493-632)
+    auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return m.sigma * k2 * k2; };
+    const T qCan = q4(tCan), qCovIn = q4(tCovIn), qCovE = q4(tCovE), qThScr = q4(tThScr), qFlr = q4(tFlr);
+    const T qPipe = q4(tPipe), qLamp = q4(tLamp), qBlScr = q4(tBlScr), qGro = q4(tGroPipe), qSky = s.qSky;
+
+    const T rCanCovIn = s.cCanCovIn * aCan * (qCan - qCovIn);
+    const T rCanSky = s.cCanSky * aCan * (qCan - qSky);
+    const T rCanThScr = s.cCanThScr * aCan * (qCan - qThScr);
+    const T rCanFlr = m.fCanFlr_a * aCan * (qCan - qFlr);
+    const T rCanBlScr = s.cCanBlScr * aCan * (qCan - qBlScr);
+    const T rPipeCovIn = s.cPipeCovIn * gap * (qPipe - qCovIn);
+    const T rPipeSky = s.cPipeSky * gap * (qPipe - qSky);
+    const T rPipeThScr = s.cPipeThScr * gap * (qPipe - qThScr);
+    const T rPipeBlScr = s.cPipeBlScr * gap * (qPipe - qBlScr);
+    const T rPipeFlr = m.fPipeFlr * (qPipe - qFlr);
+    const T rPipeCan = m.fPipeCan_a * aCan * (qPipe - qCan);
+    const T rFlrCovIn = s.cFlrCovIn * gap * (qFlr - qCovIn);
+    const T rFlrSky = s.cFlrSky * gap * (qFlr - qSky);
+    const T rFlrThScr = s.cFlrThScr * gap * (qFlr - qThScr);
+    const T rFlrBlScr = s.cFlrBlScr * gap * (qFlr - qBlScr);
+    const T rThScrCovIn = s.cThScrCovIn * (qThScr - qCovIn);
+    const T rThScrSky = s.cThScrSky * (qThScr - qSky);
+    const T rCovESky = m.fCovESky * (qCovE - qSky);
+    const T rLampFlr = m.fLampFlr_g * gap * (qLamp - qFlr);
+    const T rLampPipe = m.fLampPipe_g * gap * (qLamp - qPipe);
+    const T rLampCan = m.fLampCan_a * aCan * (qLamp - qCan);
+    const T rLampThScr = s.cLampThScr * (qLamp - qThScr);
+    const T rLampCovIn = s.cLampCovIn * (qLamp - qCovIn);
+    const T rLampSky = s.cLampSky * (qLamp - qSky);
+    const T rLampBlScr = s.cLampBlScr * (qLamp - qBlScr);
+    const T rGroPipeCan = m.fGroPipeCan * (qGro - qCan);
+    const T rBlScrThScr = s.cBlScrThScr * (qBlScr - qThScr);
+    const T rBlScrCovIn = s.cBlScrCovIn * (qBlScr - qCovIn);
+    const T rBlScrSky = s.cBlScrSky * (qBlScr - qSky);
+
+    // interlights: geometry exists in the model but their power input is hard-wired to zero
+    // (aux_states.hpp:261); every term below is exactly 0 with the default parameter block.
+    T iToCan = T(0), iToFlr = T(0), iToPipe = T(0), iToLamp = T(0), iToBlScr = T(0), iToThScr = T(0);
+    T iToCovIn = T(0), iToSky = T(0), hIntLampAir = T(0);
+    if (m.intLampActive) {
+        const T tInt = x[18];
+        const T qInt = q4(tInt);
+        const T eUp = M::exp(m.nkIntFirUp * lai), eDn = M::exp(m.nkIntFirDown * lai);
+        iToFlr = m.iFlr * eDn * (qInt - qFlr);
+        iToPipe = m.iPipe * eDn * (qInt - qPipe);
+        iToCan = m.iCan * ((one - eDn) + (one - eUp)) * (qInt - qCan);
+        iToLamp = m.iLamp * eUp * (qInt - qLamp);
+        iToBlScr = s.cIBlScr * eUp * (qInt - qBlScr);
+        iToThScr = s.cIThScr * eUp * (qInt - qThScr);
+        iToCovIn = s.cICovIn * eUp * (qInt - qCovIn);
+        iToSky = s.cISky * eUp * (qInt - qSky);
+        hIntLampAir = m.cIntLampAir * (tInt - tAir);
+    }
+
+    // ---- air exchange (aux_states.hpp:733-814)
+    const T dTOut = tAir - s.tOut;
+    const T buoy = m.gHVent * dTOut * M::rcp(tAir + s.tOutK2);       // g*h*(dT)/(2*(mean T in K))
+    const T fVentRoof2 = M::sqrt(M::abs(buoy + s.windTerm));           // a132 without its prefactor
+    const T fVentRoof = s.ventK * fVentRoof2 + s.ventElse + s.leakTop;  // a136
+
+    const T tAirK = tAir + c2k, tTopK = tTop + c2k;
+    const T iAirK = M::rcp(tAirK), iTopK = M::rcp(tTopK);
+    const T co2Ppm = m.kPpm * tAirK * co2Air;                           // a138
+    const T rhoMean = T(0.5) * m.kRho * (iAirK + iTopK);                // a141
+    const T dRho = M::abs(m.kRho * (tTop - tAir) * iAirK * iTopK);      // |rhoAir - rhoTop|
+    const T dAT = tAir - tTop;
+    const T pw66 = M::powa(M::abs(dAT + eps), T(0.66));
+    const T iRhoMean = M::rcp(rhoMean);
+    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
+    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
+    const T fScr = M::min(fTh, fBl);                                    // a144
+    const T fScrAbs = M::abs(fScr), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
+
+    // ---- convection / conduction (aux_states.hpp:824-935)
+    const T hCanAir = m.hCanAir2 * lai * (tCan - tAir);
+    const T dFA = tFlr - tAir;
+    const bool warmFlr = dFA > T(0);
+    const T hecFlr = (warmFlr ? T(1.7) : T(1.3)) *
+                     M::powa(M::abs((warmFlr ? dFA : -dFA) + eps), warmFlr ? third : T(0.25));
+    const T hAirFlr = hecFlr * (-dFA);
+    const T dATh = tAir - tThScr, dABl = tAir - tBlScr, dThTop = tThScr - tTop, dBlTop = tBlScr - tTop;
+    const T dTopCov = tTop - tCovIn;
+    const T hecAirTh = s.hTh * M::powa(M::abs(dATh + eps), third);
+    const T hecAirBl = s.hBl * M::powa(M::abs(dABl + eps), third);
+    const T hecTopCov = m.cTopCov * M::powa(M::abs(dTopCov + eps), third);
+    const T hAirThScr = M::abs(hecAirTh) * dATh;
+    const T hAirBlScr = M::abs(hecAirBl) * dABl;
+    const T hAirOut = s.hAirOutK * dTOut;
+    const T hAirTop = m.rhoCp * fScrAbs * dAT;
+    const T hThScrTop = s.hTh * M::powa(M::abs(dThTop + eps), third) * dThTop;
+    const T hBlScrTop = s.hBl * M::powa(M::abs(dBlTop + eps), third) * dBlTop;
+    const T hTopCovIn = M::abs(hecTopCov) * dTopCov;
+    const T hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
+    const T hCovEOut = s.covOutK * (tCovE - s.tOut);
+    const T dPA = tPipe - tAir, dGA = tGroPipe - tAir;
+    const T hPipeAir = m.cPipeAir * M::powa(M::abs(dPA + eps), T(0.32)) * dPA;
+    const T hGroPipeAir = m.cGroPipeAir * M::powa(M::abs(dGA + eps), T(0.32)) * dGA;
+    const T hFlrSo1 = m.cFlrSo1 * (tFlr - x[10]);
+    const T hSo12 = m.cSo12 * (x[10] - x[11]), hSo23 = m.cSo23 * (x[11] - x[12]);
+    const T hSo34 = m.cSo34 * (x[12] - x[13]), hSo45 = m.cSo45 * (x[13] - x[14]);
+    const T hSo5Out = m.cSo5Out * (x[14] - s.tSoOut);
+    const T hCovInCovE = m.cCovCond * (tCovIn - tCovE);
+    const T hLampAir = m.cLampAir * (tLamp - tAir);
+
+    // ---- transpiration (aux_states.hpp:958-981)
+    auto satVp = [&](T t) { return T(610.78) * M::exp(T(17.2694) * t * M::rcp(t + T(238.3))); };
+    const T vpd = satVp(tCan) - vpAir;
+    const T co2Dev = m.etaMgPpm * co2Air - T(200);
+    const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
+    const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
+    const T rS = s.rSK * rfCo2 * rfVp;
+    const T mvCanAir = vpd * m.kVec * lai * M::rcp(m.rB + rS);
+
+    // ---- condensation and vapour carried by air (aux_states.hpp:999-1024)
+    auto cond = [&](T hec, T vp1, T vp2) {
+        const T dv = vp1 - vp2;
+        return hec * T(6.4e-9) * dv * M::rcp(one + M::exp(T(-0.1) * dv));
+    };
+    const T mvAirThScr = cond(hecAirTh, vpAir, satVp(tThScr));
+    const T mvAirBlScr = cond(hecAirBl, vpAir, satVp(tBlScr));
+    const T mvTopCovIn = cond(hecTopCov, vpTop, satVp(tCovIn));
+    T vAirOverT, vTopOverT;
+    if (sizeof(T) == 8) {   // the float-typed Kelvin offset of the reference's airMv() is only visible in fp64
+        vAirOverT = vpAir * M::rcp(tAir + Kelvin<T>::c2kF32());
+        vTopOverT = vpTop * M::rcp(tTop + Kelvin<T>::c2kF32());
+    } else {
+        vAirOverT = vpAir * iAirK;
+        vTopOverT = vpTop * iTopK;
+    }
+    const T kMv = T(0.002165);
+    const T mvAirTop = kMv * fScrAbs * (vAirOverT - vTopOverT);
+    const T mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
+    const T mvAirOut = kMv * fSideAbs * (vAirOverT - s.vpOutOverT);
+
+    // ---- photosynthesis (aux_states.hpp:1041-1097)
+    const T parCan = s.parUmolK * gPar;
+    const T iLai = M::rcp(lai);
+    const T j25 = lai * cr.j25LeafMax;
+    const T gammaStar = iLai * cr.cGamma * tCan + cr.cGamma20 * (one - iLai);
+    const T co2Stom = cr.etaCo2Stom * co2Ppm;
+    const T tCanK = tCan + c2k;
+    const T iCanK = M::rcp(tCanK);
+    const T jPot = j25 * M::exp(cr.kJ1 * (tCan - cr.t25C) * iCanK) * cr.jDen25 *
+                   M::rcp(one + M::exp(cr.kS - cr.kH * iCanK));
+    const T aPar = cr.alpha * parCan;
+    const T jSum = jPot + aPar;
+    const T q = cr.fourTheta * jPot * aPar;
+    const T jRate = cr.inv2Theta * (q - eps) * M::rcp(jSum + M::sqrt(jSum * jSum - q + eps));
+    const T photo = jRate * (co2Stom - gammaStar) * M::rcp(T(4) * (co2Stom + T(2) * gammaStar));
+    const T net = photo * (one - gammaStar * M::rcp(co2Stom));           // P - R
+    const T hAirBuf = M::rcp(one + M::exp(T(5e-4) * (cBuf - cr.cBufMax)));
+    const T mcAirBuf = cr.mCh2o * hAirBuf * net;
+
+    // ---- carbohydrate flows (aux_states.hpp:1103-1194)
+    const T gT24 = T(0.047) * tCan24 + T(0.06);
+    const T hT24 = M::rcp((one + M::exp(T(-1.1587) * (tCan24 - cr.tCan24Min))) *
+                          (one + M::exp(T(1.3904) * (tCan24 - cr.tCan24Max))));
+    const T hTCan = M::rcp((one + M::exp(T(-0.869) * (tCan - cr.tCanMin))) *
+                           (one + M::exp(T(0.5793) * (tCan - cr.tCanMax))));
+    const T devA = tCanSum * m.tEndSumInv, devB = devA - one;
+    const T hTSum = T(0.5) * (devA + M::sqrt(devA * devA + T(1e-4))) - T(0.5) * (devB + M::sqrt(devB * devB + T(1e-4)));
+    const T hBufOrg = M::rcp(one + M::exp(T(-5e-3) * (cBuf - cr.cBufMin)));
+    const T flow = hBufOrg * hT24 * gT24;
+    const T mcBufLeaf = flow * cr.rgLeaf, mcBufStem = flow * cr.rgStem;
+    const T mcBufFruit = flow * hTCan * hTSum * cr.rgFruit;
+    const T mcBufAir = cr.cLeafG * mcBufLeaf + cr.cStemG * mcBufStem + cr.cFruitG * mcBufFruit;
+    const T maint = cr.maintBase * M::exp(cr.q10k * (tCan24 - T(25)));
+    const T mcLeafAir = maint * cLeaf * cr.cLeafM, mcStemAir = maint * cStem * cr.cStemM;
+    const T mcFruitAir = maint * cFruit * cr.cFruitM;
+    const T kHar = T(2.0 * 4.6052 / 1e4);
+    const T mcLeafHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cLeaf - cr.cLeafMax)));
+    const T mcFruitHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cFruit - cr.cFruitMax)));
+    const T mcAirCan = cr.co2PerCh2o * (mcAirBuf - mcBufAir - (mcLeafAir + mcStemAir + mcFruitAir));
+
+    // ---- CO2 carried by air (aux_states.hpp:1201-1209)
+    const T mcAirTop = fScrAbs * (co2Air - co2Top);
+    const T mcTopOut = fRoofAbs * (co2Top - s.co2Out);
+    const T mcAirOut = fSideAbs * (co2Air - s.co2Out);
+
+    // ---- balances (ode.hpp:14-121)
+    const T L = m.latent;
+    dx[0] = m.iCapCo2Air * (s.mcExtAir - mcAirCan - mcAirTop - mcAirOut);
+    dx[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
+    dx[2] = m.iCapAir * (hCanAir + hPipeAir + rGlobSunAir - hAirFlr - hAirThScr - hAirOut - hAirTop - hAirBlScr +
+                         hLampAir + rLampAir + hGroPipeAir + hIntLampAir);
+    dx[3] = m.iCapTop * (hThScrTop + hAirTop - hTopCovIn - hTopOut + hBlScrTop);
+    dx[4] = iLai * M::rcp(m.capLeaf) *
+            (rParSunCan + rNirSunCan + rPipeCan - hCanAir - L * mvCanAir - rCanCovIn - rCanFlr - rCanSky - rCanThScr -
+             rCanBlScr + rParLampCan + rNirLampCan + rLampCan + rGroPipeCan + iToCan);
+    dx[5] = m.iCapCov * (hTopCovIn + L * mvTopCovIn + rCanCovIn + rFlrCovIn + rPipeCovIn + rThScrCovIn - hCovInCovE +
+                         rLampCovIn + rBlScrCovIn + iToCovIn);
+    dx[6] = m.iCapCov * (s.sunCovE + hCovInCovE - hCovEOut - rCovESky);
+    dx[7] = m.iCapThScr * (hAirThScr + L * mvAirThScr + rCanThScr + rFlrThScr + rPipeThScr - hThScrTop - rThScrCovIn -
+                           rThScrSky + rBlScrThScr + rLampThScr + iToThScr);
+    dx[8] = m.iCapFlr * (hAirFlr + rParSunFlr + rNirSunFlr + rCanFlr + rPipeFlr - hFlrSo1 - rFlrCovIn - rFlrSky -
+                         rFlrThScr + rParLampFlr + rNirLampFlr + rLampFlr - rFlrBlScr + iToFlr);
+    dx[9] = m.iCapPipe * (s.hBoilPipe - rPipeSky - rPipeCovIn - rPipeCan - rPipeFlr - rPipeThScr - hPipeAir +
+                          rLampPipe - rPipeBlScr + iToPipe);
+    dx[10] = m.iCapSo1 * (hFlrSo1 - hSo12);
+    dx[11] = m.iCapSo2 * (hSo12 - hSo23);
+    dx[12] = m.iCapSo3 * (hSo23 - hSo34);
+    dx[13] = m.iCapSo4 * (hSo34 - hSo45);
+    dx[14] = m.iCapSo5 * (hSo45 - hSo5Out);
+    dx[15] = m.kCapVpAir * tAirK * (mvCanAir - mvAirThScr - mvAirTop - mvAirOut - mvAirBlScr);
+    dx[16] = m.kCapVpTop * tTopK * (mvAirTop - mvTopCovIn - mvTopOut);
+    dx[17] = m.iCapLamp * (s.lampNet - hLampAir - rLampSky - rLampCovIn - rLampThScr - rLampPipe - rLampBlScr -
+                           rLampFlr - rLampCan + iToLamp);
+    dx[18] = m.iCapIntLamp * (-hIntLampAir - iToSky - iToCovIn - iToThScr - iToPipe - iToBlScr - iToFlr - iToCan - iToLamp);
+    dx[19] = m.iCapGroPipe * (-rGroPipeCan - hGroPipeAir);
+    dx[20] = m.iCapBlScr * (hAirBlScr + L * mvAirBlScr + rCanBlScr + rFlrBlScr + rPipeBlScr - hBlScrTop - rBlScrCovIn -
+                            rBlScrSky - rBlScrThScr + rLampBlScr + iToBlScr);
+    const T perDay = T(1.0 / 86400.0);
+    dx[21] = perDay * (tCan - tCan24);
+    dx[22] = mcAirBuf - mcBufFruit - mcBufLeaf - mcBufStem - mcBufAir;
+    dx[23] = mcBufLeaf - mcLeafAir - mcLeafHar;
+    dx[24] = mcBufStem - mcStemAir;
+    dx[25] = mcBufFruit - mcFruitAir - mcFruitHar;
+    dx[26] = perDay * tCan;
+    dx[27] = perDay;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RK4 over one env-step in delta form: the state stays x0 + del, only del is accumulated, so slow,
+// large states (cFruit ~5e4, tCanSum ~3e3) do not lose their small increments in fp32.
+// Returns del (x(dt) - x0); the caller adds it once.
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
+                     int n_sub, T* del)
+{
+    const T h = dt / T(n_sub), h2 = T(0.5) * h, h6 = h / T(6);
+    T xs[NX], k[NX], acc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) del[i] = T(0);
+    for (int it = 0; it < n_sub; ++it) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[i] = x0[i] + del[i];
+        rhs(xs, s, m, cr, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = x0[i] + (del[i] + h2 * k[i]); }
+        rhs(xs, s, m, cr, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = x0[i] + (del[i] + h2 * k[i]); }
+        rhs(xs, s, m, cr, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = x0[i] + (del[i] + h * k[i]); }
+        rhs(xs, s, m, cr, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) del[i] += h6 * (acc[i] + k[i]);
+    }
+}
+
+}  // namespace glm

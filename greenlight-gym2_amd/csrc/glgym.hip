@@ -1,0 +1,707 @@
+// glgym.hip -- gfx950 kernels + the C ABI declared in include/glgym.h.
+//
+// Kernels (one lane = one environment; a 64-lane wavefront = one workgroup = 64 environments):
+//   step_kernel   fused TomatoEnv.step(): action->control, weather-row gather, tier-2 precompute,
+//                 n_sub x RK4 of the GreenLight ODE (gl_model.hpp), failure check, reward / violation /
+//                 info epilogue, terminal test, wave-level metric reduction.   [VALU/transcendental bound]
+//   obs_kernel    row-major observation assembly incl. the weather-forecast gather.      [HBM-write bound]
+//   reset_kernel  masked init_state().        crop_noise_kernel  Philox4x32-10 parameter noise.
+//   evalf_kernel / rhs_kernel                 row-major double I/O for the reference-compatible evalF and tests.
+// No MFMA anywhere: the path is elementwise + transcendental, not a contraction.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "glgym.h"
+#include "gl_model.hpp"
+
+using namespace glm;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                 \
+            return GLGYM_EHIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------------
+// reward constants (rewards.py:96-124,156-231; TomatoEnv.yml:38-67)
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct RewardConst {
+    T heatK, elecK, co2K;       // cost per unit of u0 / u4 / u1 per env-step
+    T gainK;                    // EUR per mg m-2 of fruit dry matter
+    T minProfit, invRange;      // scale_reward(profit, min, max)
+    T fixedCosts;
+    T lo[3], hi[3], invMaxViol[3];
+    T kPpm;
+};
+
+template <class T> void make_reward_const(const double* p, double dt, const glgym_reward_cfg& c, RewardConst<T>& r,
+                                          double* max_profit, double* min_profit, double* fixed_costs)
+{
+    const double heat = p[108] / p[46] * dt / 3600 * 1e-3 * c.heating_price;
+    const double elec = p[172] * dt / 3600 * 1e-3 * c.elec_price;
+    const double co2 = p[109] / p[46] * dt * 1e-6 * c.co2_price;
+    const double maxP = p[154] * dt * 1e-6 / c.dmfm * c.fruit_price;
+    const double minP = -(heat + elec + co2);
+    const double yearly = c.fixed_greenhouse_cost + c.fixed_co2_cost + c.fixed_lamp_cost * 116 + c.fixed_screen_cost;
+    const double fixed = yearly / 365 / (double)(86400 / (long)dt);       // rewards.py:155 uses floor division
+    r.heatK = T(heat); r.elecK = T(elec); r.co2K = T(co2);
+    r.gainK = T(1e-6 / c.dmfm * c.fruit_price);
+    r.minProfit = T(minP); r.invRange = T(1.0 / (maxP - minP)); r.fixedCosts = T(fixed);
+    r.lo[0] = T(c.co2_min); r.lo[1] = T(c.temp_min); r.lo[2] = T(c.rh_min);
+    r.hi[0] = T(c.co2_max); r.hi[1] = T(c.temp_max); r.hi[2] = T(c.rh_max);
+    r.invMaxViol[0] = T(1.0 / 2500.0); r.invMaxViol[1] = T(1.0 / 15.0); r.invMaxViol[2] = T(1.0 / 15.0);   // :89-93
+    r.kPpm = T(8.3144598 / (101325.0 * 44.01e-3));
+    if (max_profit) *max_profit = maxP;
+    if (min_profit) *min_profit = minP;
+    if (fixed_costs) *fixed_costs = fixed;
+}
+
+template <class T> struct StepArgsT {
+    int B, ld;
+    T* x; T* u;
+    const float* action; const T* control;
+    const T* weather; int weather_rows;
+    const int* w_off; int* timestep;
+    const T* crop_p;
+    int N;
+    T* reward; T* info; unsigned char* done; float* metrics;
+    T dt; int n_sub;
+    T gasR, tCanMin;
+};
+
+template <class T> __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
+{
+    return T(610.78) * Math<T>::exp(T(17.2694) * t / (t + T(238.3)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused env-step
+// ---------------------------------------------------------------------------------------------------
+template <class T, bool PER_ENV_CROP>
+__global__ __launch_bounds__(WAVE) void step_kernel(StepArgsT<T> a, ModelConst<T> m, RewardConst<T> rw)
+{
+    __shared__ float sh_act[WAVE * NU];
+    const int lane = threadIdx.x;
+    const int b0 = blockIdx.x * WAVE;
+    const int b = b0 + lane;
+    const bool live = b < a.B;
+    const int bb = live ? b : a.B - 1;        // out-of-range lanes shadow the last env, stores are masked
+
+    // ---- controls: coalesced tile load of the row-major action block through LDS
+    T u[NU];
+    if (a.action) {
+        const int n_tile = min(WAVE, a.B - b0) * NU;
+        for (int i = lane; i < n_tile; i += WAVE) sh_act[i] = a.action[(size_t)b0 * NU + i];
+        __syncthreads();
+        const int l = live ? lane : (a.B - 1 - b0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const float inc = sh_act[l * NU + j] * 0.1f;                     // f32 product, as tomato_env.py:113
+            const T v = a.u[(size_t)j * a.ld + bb] + T(inc);
+            u[j] = Math<T>::min(Math<T>::max(v, T(0)), T(1));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) u[j] = a.control[(size_t)j * a.ld + bb];
+    }
+
+    // ---- state + the weather row of this step (zero-order hold, tomato_env.py:120)
+    T x0[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0[i] = a.x[(size_t)i * a.ld + bb];
+    const int ts = a.timestep[bb];
+    int row = a.w_off[bb] + ts;
+    row = row < 0 ? 0 : (row >= a.weather_rows ? a.weather_rows - 1 : row);
+    T d[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) d[j] = a.weather[(size_t)row * ND + j];
+
+    // ---- tier 2, then the sub-stepped RK4
+    CropConst<T> crLocal;
+    if (PER_ENV_CROP) {
+        T pc[NCROP];
+#pragma unroll
+        for (int i = 0; i < NCROP; ++i) pc[i] = a.crop_p[(size_t)i * a.ld + bb];
+        make_crop_const<T, T>(pc, a.gasR, a.tCanMin, crLocal);
+    }
+    const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
+    StepCoef<T> s;
+    precompute(u, d, m, cr, s);
+    T del[NX];
+    rk4_delta(x0, s, m, cr, a.dt, a.n_sub, del);
+
+    // ---- failure check (tomato_env.py:119-123: on an integrator error the state is left unchanged)
+    T chk = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) chk += del[i] * T(0);
+    const bool bad = !(chk == T(0));
+    T x1[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x1[i] = bad ? x0[i] : x0[i] + del[i];
+
+    // ---- reward epilogue (rewards.py:156-231); indoor obs conversions (observations.py:70-77)
+    const T co2ppm = rw.kPpm * (x1[2] + T(273.15)) * x1[0];
+    const T rh = Math<T>::min(Math<T>::max(T(100) * x1[15] / sat_vp_exact(x1[2]), T(0)), T(100));
+    const T o3[3] = {co2ppm, x1[2], rh};
+    T viol[3], pen = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        viol[i] = Math<T>::max(rw.lo[i] - o3[i], T(0)) + Math<T>::max(o3[i] - rw.hi[i], T(0));
+        pen += viol[i] * rw.invMaxViol[i];
+    }
+    const T heat = u[0] * rw.heatK, elec = u[4] * rw.elecK, co2c = u[1] * rw.co2K;
+    const T varc = heat + co2c + elec;
+    const T gains = (bad ? T(0) : del[25]) * rw.gainK;
+    const T profit = gains - varc;
+    const T reward = (profit - rw.minProfit) * rw.invRange - pen;        // lamp penalty is identically 0 (:203-212)
+    const bool term = bad || (ts >= a.N);
+
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a.x[(size_t)i * a.ld + b] = x1[i];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
+        a.timestep[b] = ts + 1;
+        a.reward[b] = reward;
+        a.done[b] = term ? 1 : 0;
+        if (a.info) {
+            const T inf[GLGYM_NINFO] = {profit, gains, varc, rw.fixedCosts, co2c, heat, elec, viol[1], viol[0], viol[2], T(0)};
+#pragma unroll
+            for (int i = 0; i < GLGYM_NINFO; ++i) a.info[(size_t)i * a.ld + b] = inf[i];
+        }
+    }
+    if (a.metrics) {     // wave-level reductions, one atomic per wave per metric
+        const float w = live ? 1.f : 0.f;
+        float mv[GLGYM_NMETRIC] = {w * (float)reward, w * (float)profit, (live && term) ? 1.f : 0.f,
+                                   (live && bad) ? 1.f : 0.f, w * (float)viol[0], w * (float)viol[1],
+                                   w * (float)viol[2], w};
+#pragma unroll
+        for (int i = 0; i < GLGYM_NMETRIC; ++i) {
+            const float sum = wave_sum(mv[i]);
+            if (lane == 0) atomicAdd(a.metrics + i, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reference-compatible step map / RHS with row-major double I/O (B small; B = 1 for the drop-in evalF)
+// ---------------------------------------------------------------------------------------------------
+template <class T, bool PER_ENV_CROP>
+__global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
+                                                     const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
+                                                     ModelConst<T> m, double* x_next, int rhs_only)
+{
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B) return;
+    T x0[NX], uu[NU], dd[7];
+    for (int i = 0; i < NX; ++i) x0[i] = T(x[(size_t)b * NX + i]);
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[(size_t)b * NU + i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[(size_t)b * ND + i]);
+    CropConst<T> crLocal;
+    if (PER_ENV_CROP) {
+        T pc[NCROP];
+        for (int i = 0; i < NCROP; ++i) pc[i] = T(crop[(size_t)b * NCROP + i]);
+        make_crop_const<T, T>(pc, gasR, tCanMin, crLocal);
+    }
+    const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
+    StepCoef<T> s;
+    precompute(uu, dd, m, cr, s);
+    if (rhs_only) {
+        T k[NX];
+        rhs(x0, s, m, cr, k);
+        for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)k[i];
+        return;
+    }
+    T del[NX];
+    rk4_delta(x0, s, m, cr, dt, n_sub, del);
+    for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// observations: [B][23 + 5*Np] f32 row-major (observations.py:59-182).  One wavefront per env row so the
+// 1 KB row is written with consecutive lanes on consecutive addresses.
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct ObsArgsT {
+    int B, ld;
+    const T* x; const T* u; const T* weather; int weather_rows;
+    const int* w_off; const int* timestep; const float* start_day;
+    int Np; float* obs; double dt;
+};
+
+template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T> a)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int n_waves = gridDim.x * blockDim.x / WAVE;
+    const int dim = 23 + 5 * a.Np;
+    const double kPpm = 8.3144598 / (101325.0 * 44.01e-3);
+    for (int b = wave; b < a.B; b += n_waves) {
+        const int ts = a.timestep[b];
+        const int k = ts > 0 ? ts - 1 : 0;               // weather row / "timestep" the reference shows (pre-increment)
+        const int base = a.w_off[b] + k;
+        float* out = a.obs + (size_t)b * dim;
+        for (int j = lane; j < dim; j += WAVE) {
+            double v;
+            if (j >= 23) {                               // raw forecast rows, no unit conversion (:175-182)
+                const int i = (j - 23) / 5 + 1, c = (j - 23) % 5;
+                int r = base + i;
+                r = r >= a.weather_rows ? a.weather_rows - 1 : r;
+                v = (double)a.weather[(size_t)r * ND + c];
+            } else if (j < 4) {                          // indoor climate (:70-77)
+                const double tAir = (double)a.x[(size_t)2 * a.ld + b];
+                if (j == 0) v = kPpm * (tAir + 273.15) * (double)a.x[b];
+                else if (j == 1) v = tAir;
+                else if (j == 2) {
+                    const double sv = 610.78 * exp(17.2694 * tAir / (tAir + 238.3));
+                    v = fmin(fmax(100.0 * (double)a.x[(size_t)15 * a.ld + b] / sv, 0.0), 100.0);
+                } else v = (double)a.x[(size_t)9 * a.ld + b];
+            } else if (j < 7) {                          // crop (:90-95)
+                const int idx = j == 4 ? 21 : (j == 5 ? 25 : 26);
+                v = (double)a.x[(size_t)idx * a.ld + b];
+            } else if (j < 13) {                         // controls (:108-112)
+                v = (double)a.u[(size_t)(j - 7) * a.ld + b];
+            } else if (j < 18) {                         // current weather (:129-136)
+                int r = base >= a.weather_rows ? a.weather_rows - 1 : base;
+                const T* w = a.weather + (size_t)r * ND;
+                const double tOut = (double)w[1];
+                const int c = j - 13;
+                if (c == 2) {
+                    const double sv = 610.78 * exp(17.2694 * tOut / (tOut + 238.3));
+                    v = fmin(fmax(100.0 * (double)w[2] / sv, 0.0), 100.0);
+                } else if (c == 3) v = kPpm * (tOut + 273.15) * (double)w[3];
+                else v = (double)w[c];
+            } else {                                     // time features (:149-161, tomato_env.py:126-128)
+                const int c = j - 18;
+                if (c == 0) v = (double)k;
+                else {
+                    const double doy = (double)a.start_day[b] + (double)ts * fmod(a.dt / 86400.0, 365.0);
+                    const double hod = fmod((double)ts * (a.dt / 3600.0), 24.0);
+                    const double two_pi = 6.283185307179586;
+                    const double ang = (c <= 2) ? two_pi * doy / 365.0 : two_pi * hod / 24.0;
+                    v = (c == 1 || c == 3) ? sin(ang) : cos(ang);
+                }
+            }
+            out[j] = (float)v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked reset: init_state (utils.py:13-46)
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void reset_kernel(int B, int ld, const unsigned char* mask, T* x, T* u, int* timestep, const T* weather,
+                             int weather_rows, const int* w_off)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || (mask && !mask[b])) return;
+    int r = w_off[b];
+    r = r < 0 ? 0 : (r >= weather_rows ? weather_rows - 1 : r);
+    const double co2Out = (double)weather[(size_t)r * ND + 3], tSoOut = (double)weather[(size_t)r * ND + 6];
+    const double tAir = 16.5;
+    double xi[NX];
+    xi[0] = xi[1] = co2Out;
+    for (int i = 2; i <= 10; ++i) xi[i] = tAir;
+    xi[4] = tAir + 4;
+    xi[11] = 0.25 * (3.0 * tAir + tSoOut);
+    xi[12] = 0.25 * (2.0 * tAir + 2 * tSoOut);
+    xi[13] = 0.25 * (tAir + 3 * tSoOut);
+    xi[14] = tSoOut;
+    xi[15] = xi[16] = 90.0 / 100.0 * (610.78 * exp(17.2694 * tAir / (tAir + 238.3)));
+    xi[17] = xi[18] = xi[19] = xi[20] = tAir;
+    xi[21] = xi[4];
+    xi[22] = 0.0; xi[23] = 9.5283e4; xi[24] = 2.5107e5; xi[25] = 5.5338e4; xi[26] = 3.0978e3; xi[27] = 0.0;
+    for (int i = 0; i < NX; ++i) x[(size_t)i * ld + b] = T(xi[i]);
+    for (int j = 0; j < NU; ++j) u[(size_t)j * ld + b] = T(0);
+    timestep[b] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// crop-parameter noise (noise.py:3-23) with a counter-based generator: Philox4x32-10
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned* out)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <class T>
+__global__ void crop_noise_kernel(T* crop_p, int B, int ld, const float* p0, float scale, unsigned long long seed,
+                                  unsigned long long draw)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float pn[NCROP + 2];
+    for (int blk = 0; blk < 9; ++blk) {
+        unsigned r[4];
+        philox4x32_10((unsigned)b, (unsigned)draw, (unsigned)(draw >> 32), (unsigned)blk, (unsigned)seed,
+                      (unsigned)(seed >> 32), r);
+        for (int q = 0; q < 4; ++q) {
+            const int i = blk * 4 + q;
+            if (i < NCROP) {
+                const float un = ((float)(r[q] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0,1), 24 bits
+                const float noise = (un - 0.5f) * scale;
+                pn[i] = p0[i] + noise * p0[i];
+            }
+        }
+    }
+    pn[144 - CROP0] = pn[141 - CROP0] / pn[142 - CROP0];            // cLeafMax = laiMax / sla (noise.py:22)
+    for (int i = 0; i < NCROP; ++i) crop_p[(size_t)i * ld + b] = T(pn[i]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------
+struct glgym_handle_s {
+    int device = 0;
+    int dtype = GLGYM_F32;
+    int n_sub = 256;
+    double dt = 900.0;
+    double p[NP];
+    ModelConst<float> mf;
+    ModelConst<double> md;
+    glgym_reward_cfg rcfg;
+    RewardConst<float> rf;
+    RewardConst<double> rd;
+    double max_profit = 0, min_profit = 0, fixed_costs = 0;
+    float* p0_crop_dev = nullptr;       // shared p[128..161] as f32 (noise kernel input)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scratch for the host-pointer entry points
+    double* scratch = nullptr;
+    size_t scratch_elems = 0;
+};
+
+static void default_reward(glgym_reward_cfg& c)
+{
+    c.elec_price = 0.3; c.heating_price = 0.09; c.co2_price = 0.3; c.fruit_price = 1.6; c.dmfm = 0.065;
+    c.fixed_greenhouse_cost = 15.0; c.fixed_co2_cost = 0.015; c.fixed_lamp_cost = 0.07; c.fixed_screen_cost = 2.0;
+    c.pen_lamp = 0.1;
+    c.co2_min = 300; c.co2_max = 1600; c.temp_min = 15; c.temp_max = 34; c.rh_min = 50; c.rh_max = 85;
+}
+
+static int refresh(glgym_handle h)
+{
+    make_model_const<float>(h->p, h->mf);
+    make_model_const<double>(h->p, h->md);
+    make_reward_const<float>(h->p, h->dt, h->rcfg, h->rf, &h->max_profit, &h->min_profit, &h->fixed_costs);
+    make_reward_const<double>(h->p, h->dt, h->rcfg, h->rd, nullptr, nullptr, nullptr);
+    float pc[NCROP];
+    for (int i = 0; i < NCROP; ++i) pc[i] = (float)h->p[CROP0 + i];
+    HIPCHK(hipMemcpy(h->p0_crop_dev, pc, sizeof pc, hipMemcpyHostToDevice));
+    return GLGYM_OK;
+}
+
+extern "C" {
+
+const char* glgym_version(void) { return "glgym 0.1 (gfx950; RK4 delta-form; thread-per-env)"; }
+const char* glgym_last_error(void) { return g_err.c_str(); }
+
+int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int dtype, int n_sub, int device,
+                 glgym_handle* out)
+{
+    if (!out || !p || nx != NX || nu != NU || nd != ND || np != NP || !(dt > 0) || n_sub < 1 ||
+        (dtype != GLGYM_F32 && dtype != GLGYM_F64)) {
+        g_err = "glgym_create: expected nx=28 nu=6 nd=10 np=208, dt>0, n_sub>=1, dtype in {F32,F64}";
+        return GLGYM_EINVAL;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+        g_err = "glgym_create: no usable HIP device (this library has no CPU fallback)";
+        return GLGYM_ENODEV;
+    }
+    HIPCHK(hipSetDevice(device));
+    glgym_handle h = new (std::nothrow) glgym_handle_s();
+    if (!h) return GLGYM_ENOMEM;
+    h->device = device; h->dtype = dtype; h->n_sub = n_sub; h->dt = dt;
+    std::memcpy(h->p, p, sizeof h->p);
+    default_reward(h->rcfg);
+    HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    const int rc = refresh(h);
+    if (rc != GLGYM_OK) return rc;
+    *out = h;
+    return GLGYM_OK;
+}
+
+int glgym_destroy(glgym_handle h)
+{
+    if (!h) return GLGYM_EINVAL;
+    (void)hipSetDevice(h->device);
+    if (h->p0_crop_dev) (void)hipFree(h->p0_crop_dev);
+    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return GLGYM_OK;
+}
+
+int glgym_set_params(glgym_handle h, const double* p)
+{
+    if (!h || !p) return GLGYM_EINVAL;
+    std::memcpy(h->p, p, sizeof h->p);
+    return refresh(h);
+}
+
+int glgym_set_n_sub(glgym_handle h, int n_sub)
+{
+    if (!h || n_sub < 1) return GLGYM_EINVAL;
+    h->n_sub = n_sub;
+    return GLGYM_OK;
+}
+
+int glgym_set_reward(glgym_handle h, const glgym_reward_cfg* cfg)
+{
+    if (!h || !cfg) return GLGYM_EINVAL;
+    h->rcfg = *cfg;
+    return refresh(h);
+}
+
+int glgym_get_reward_scale(glgym_handle h, double* max_profit, double* min_profit, double* fixed_costs)
+{
+    if (!h) return GLGYM_EINVAL;
+    if (max_profit) *max_profit = h->max_profit;
+    if (min_profit) *min_profit = h->min_profit;
+    if (fixed_costs) *fixed_costs = h->fixed_costs;
+    return GLGYM_OK;
+}
+
+}  // extern "C"
+
+// ---- host-pointer entry points --------------------------------------------------------------------
+static int ensure_scratch(glgym_handle h, size_t elems)
+{
+    if (h->scratch_elems >= elems) return GLGYM_OK;
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr; h->scratch_elems = 0;
+    HIPCHK(hipMalloc(&h->scratch, elems * sizeof(double)));
+    h->scratch_elems = elems;
+    return GLGYM_OK;
+}
+
+template <class T>
+static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_used, const double* dx, const double* du,
+                     const double* dd, const double* dcrop, int B, double* dout, int rhs_only)
+{
+    const dim3 grid((B + WAVE - 1) / WAVE), block(WAVE);
+    if (dcrop)
+        hipLaunchKernelGGL((evalf_kernel<T, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only);
+    else
+        hipLaunchKernelGGL((evalf_kernel<T, false>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+static int evalf_impl(glgym_handle h, const double* x, const double* u, const double* d, const double* p, int p_rows,
+                      int B, double* out, int rhs_only)
+{
+    if (!h || !x || !u || !d || !out || B < 1 || (p && p_rows != 1 && p_rows != B)) {
+        g_err = "glgym_evalF: bad arguments";
+        return GLGYM_EINVAL;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    const double* p_used = p ? p : h->p;
+    // per-row parameter blocks may differ only inside the crop block p[128..161] (what noise.py perturbs);
+    // anything else is handled one row at a time.
+    bool per_row = p && p_rows == B && B > 1;
+    if (per_row) {
+        for (int b = 1; b < B && per_row; ++b)
+            for (int i = 0; i < NP; ++i)
+                if ((i < CROP0 || i >= CROP0 + NCROP) && p[(size_t)b * NP + i] != p[i]) {
+                    for (int r = 0; r < B; ++r) {
+                        const int rc = evalf_impl(h, x + (size_t)r * NX, u + (size_t)r * NU, d + (size_t)r * ND,
+                                                  p + (size_t)r * NP, 1, 1, out + (size_t)r * NX, rhs_only);
+                        if (rc != GLGYM_OK) return rc;
+                    }
+                    return GLGYM_OK;
+                }
+    }
+    const size_t n_in = (size_t)B * (NX + NU + ND + (per_row ? NCROP : 0));
+    int rc = ensure_scratch(h, n_in + (size_t)B * NX);
+    if (rc != GLGYM_OK) return rc;
+    double* dx = h->scratch; double* du = dx + (size_t)B * NX; double* dd = du + (size_t)B * NU;
+    double* dcrop = per_row ? dd + (size_t)B * ND : nullptr;
+    double* dout = h->scratch + n_in;
+    HIPCHK(hipMemcpy(dx, x, (size_t)B * NX * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(du, u, (size_t)B * NU * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dd, d, (size_t)B * ND * sizeof(double), hipMemcpyHostToDevice));
+    if (per_row) {
+        std::vector<double> crop((size_t)B * NCROP);
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < NCROP; ++i) crop[(size_t)b * NCROP + i] = p[(size_t)b * NP + CROP0 + i];
+        HIPCHK(hipMemcpy(dcrop, crop.data(), crop.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (h->dtype == GLGYM_F32) {
+        ModelConst<float> m = h->mf;
+        if (p) make_model_const<float>(p_used, m);
+        rc = run_evalf<float>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only);
+    } else {
+        ModelConst<double> m = h->md;
+        if (p) make_model_const<double>(p_used, m);
+        rc = run_evalf<double>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only);
+    }
+    if (rc != GLGYM_OK) return rc;
+    HIPCHK(hipMemcpy(out, dout, (size_t)B * NX * sizeof(double), hipMemcpyDeviceToHost));
+    return GLGYM_OK;
+}
+
+extern "C" {
+
+int glgym_evalF(glgym_handle h, const double* x, const double* u, const double* d, const double* p, int p_rows, int B,
+                double* x_next)
+{
+    return evalf_impl(h, x, u, d, p, p_rows, B, x_next, 0);
+}
+
+int glgym_rhs(glgym_handle h, const double* x, const double* u, const double* d, int B, double* dx)
+{
+    return evalf_impl(h, x, u, d, nullptr, 1, B, dx, 1);
+}
+
+}  // extern "C"
+
+// ---- device-pointer hot path ----------------------------------------------------------------------
+template <class T>
+static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelConst<T>& m, const RewardConst<T>& rw,
+                       hipStream_t st)
+{
+    StepArgsT<T> k;
+    k.B = a->B; k.ld = a->ld;
+    k.x = (T*)a->x; k.u = (T*)a->u; k.action = a->action; k.control = (const T*)a->control;
+    k.weather = (const T*)a->weather; k.weather_rows = a->weather_rows;
+    k.w_off = a->w_off; k.timestep = a->timestep; k.crop_p = (const T*)a->crop_p; k.N = a->N;
+    k.reward = (T*)a->reward; k.info = (T*)a->info; k.done = a->done; k.metrics = a->metrics;
+    k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]);
+    const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
+    if (a->crop_p)
+        hipLaunchKernelGGL((step_kernel<T, true>), grid, block, 0, st, k, m, rw);
+    else
+        hipLaunchKernelGGL((step_kernel<T, false>), grid, block, 0, st, k, m, rw);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+extern "C" int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream)
+{
+    if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
+        !a->reward || !a->done || (!a->action) == (!a->control) || a->weather_rows < 1) {
+        g_err = "glgym_step: bad arguments (exactly one of action/control, ld >= B, non-null state/outputs)";
+        return GLGYM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return h->dtype == GLGYM_F32 ? launch_step<float>(h, a, h->mf, h->rf, st)
+                                 : launch_step<double>(h, a, h->md, h->rd, st);
+}
+
+template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a, hipStream_t st)
+{
+    ObsArgsT<T> k;
+    k.B = a->B; k.ld = a->ld; k.x = (const T*)a->x; k.u = (const T*)a->u; k.weather = (const T*)a->weather;
+    k.weather_rows = a->weather_rows; k.w_off = a->w_off; k.timestep = a->timestep; k.start_day = a->start_day;
+    k.Np = a->Np; k.obs = a->obs; k.dt = h->dt;
+    const int waves_per_block = 256 / WAVE;
+    int blocks = (a->B + waves_per_block - 1) / waves_per_block;
+    if (blocks > 2048) blocks = 2048;           // grid-stride over env rows beyond that
+    hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), 0, st, k);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+extern "C" {
+
+int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream)
+{
+    if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
+        !a->start_day || !a->obs || a->Np < 0) {
+        g_err = "glgym_obs: bad arguments";
+        return GLGYM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return h->dtype == GLGYM_F32 ? launch_obs<float>(h, a, st) : launch_obs<double>(h, a, st);
+}
+
+int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
+{
+    if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->timestep || !a->weather || !a->w_off) {
+        g_err = "glgym_reset: bad arguments";
+        return GLGYM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((a->B + 255) / 256), block(256);
+    if (h->dtype == GLGYM_F32)
+        hipLaunchKernelGGL((reset_kernel<float>), grid, block, 0, st, a->B, a->ld, a->mask, (float*)a->x, (float*)a->u,
+                           a->timestep, (const float*)a->weather, a->weather_rows, a->w_off);
+    else
+        hipLaunchKernelGGL((reset_kernel<double>), grid, block, 0, st, a->B, a->ld, a->mask, (double*)a->x,
+                           (double*)a->u, a->timestep, (const double*)a->weather, a->weather_rows, a->w_off);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, uint64_t seed, uint64_t draw_index,
+                     void* stream)
+{
+    if (!h || !crop_p || B < 1 || ld < B) return GLGYM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((B + 255) / 256), block(256);
+    if (h->dtype == GLGYM_F32)
+        hipLaunchKernelGGL((crop_noise_kernel<float>), grid, block, 0, st, (float*)crop_p, B, ld, h->p0_crop_dev,
+                           (float)scale, (unsigned long long)seed, (unsigned long long)draw_index);
+    else
+        hipLaunchKernelGGL((crop_noise_kernel<double>), grid, block, 0, st, (double*)crop_p, B, ld, h->p0_crop_dev,
+                           (float)scale, (unsigned long long)seed, (unsigned long long)draw_index);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+int glgym_timer_start(glgym_handle h, void* stream)
+{
+    if (!h) return GLGYM_EINVAL;
+    HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
+    return GLGYM_OK;
+}
+
+int glgym_timer_stop(glgym_handle h, void* stream, float* elapsed_ms)
+{
+    if (!h || !elapsed_ms) return GLGYM_EINVAL;
+    HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return GLGYM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""ctypes binding of libglgym.so (include/glgym.h).  No CPU fallback: a missing library or a missing
+HIP device raises -- the product path never routes through the oracle or any host implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
+
+NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 8
+F32, F64 = 0, 1
+OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
+
+INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
+             "temp_violation", "co2_violation", "rh_violation", "lamp_violation")      # tomato_env.py:208-222
+METRIC_KEYS = ("sum_reward", "sum_EPI", "n_done", "n_ode_fail", "sum_co2_violation", "sum_temp_violation",
+               "sum_rh_violation", "n_env_steps")
+
+
+class GlgymError(RuntimeError):
+    pass
+
+
+class RewardCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "elec_price", "heating_price", "co2_price", "fruit_price", "dmfm", "fixed_greenhouse_cost", "fixed_co2_cost",
+        "fixed_lamp_cost", "fixed_screen_cost", "pen_lamp", "co2_min", "co2_max", "temp_min", "temp_max", "rh_min",
+        "rh_max")]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("u", C.c_void_p), ("action", C.c_void_p),
+                ("control", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p),
+                ("timestep", C.c_void_p), ("crop_p", C.c_void_p), ("N", C.c_int32), ("reward", C.c_void_p),
+                ("info", C.c_void_p), ("done", C.c_void_p), ("metrics", C.c_void_p)]
+
+
+class ObsArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("u", C.c_void_p), ("weather", C.c_void_p),
+                ("weather_rows", C.c_int32), ("w_off", C.c_void_p), ("timestep", C.c_void_p), ("start_day", C.c_void_p),
+                ("Np", C.c_int32), ("obs", C.c_void_p)]
+
+
+class ResetArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("mask", C.c_void_p), ("x", C.c_void_p), ("u", C.c_void_p),
+                ("timestep", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p)]
+
+
+# every symbol include/glgym.h declares, with its prototype
+_DP = C.POINTER(C.c_double)
+PROTOTYPES = {
+    "glgym_version": (C.c_char_p, []),
+    "glgym_last_error": (C.c_char_p, []),
+    "glgym_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _DP, C.c_int, C.c_int, C.c_int,
+                               C.POINTER(C.c_void_p)]),
+    "glgym_destroy": (C.c_int, [C.c_void_p]),
+    "glgym_set_params": (C.c_int, [C.c_void_p, _DP]),
+    "glgym_set_n_sub": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_reward": (C.c_int, [C.c_void_p, C.POINTER(RewardCfg)]),
+    "glgym_get_reward_scale": (C.c_int, [C.c_void_p, _DP, _DP, _DP]),
+    "glgym_evalF": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),
+    "glgym_rhs": (C.c_int, [C.c_void_p, _DP, _DP, _DP, C.c_int, _DP]),
+    "glgym_step": (C.c_int, [C.c_void_p, C.POINTER(StepArgs), C.c_void_p]),
+    "glgym_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsArgs), C.c_void_p]),
+    "glgym_reset": (C.c_int, [C.c_void_p, C.POINTER(ResetArgs), C.c_void_p]),
+    "glgym_crop_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
+                                   C.c_void_p]),
+    "glgym_timer_start": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "glgym_timer_stop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libglgym.so and bind every prototype.  Raises GlgymError if the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise GlgymError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/glgym.h
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "glgym"):
+    if rc != OK:
+        msg = load().glgym_last_error().decode() or {EINVAL: "invalid argument", ENODEV: "no HIP device",
+                                                       EHIP: "HIP error", ENOMEM: "out of memory"}.get(rc, "")
+        raise GlgymError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,397 @@
+"""Batched TomatoEnv on the MI355X.
+
+``TomatoVecEnv`` keeps B independent greenhouse environments resident in HBM (state, controls, clocks,
+weather window offsets) and advances all of them with ONE fused kernel launch per env-step
+(libglgym.so: glgym_step), then assembles the row-major observation block (glgym_obs).  It exposes
+
+  * the Stable-Baselines3 ``VecEnv`` calling convention that the reference's experiment manager consumes
+    (gl_gym/RL/utils.py:44-69, gl_gym/common/evaluation.py:73-104): reset() / step(actions) -> (obs, rewards,
+    dones, infos) with auto-reset and ``infos[i]["terminal_observation"]``, step_async/step_wait, num_envs,
+    observation_space / action_space, get_attr / set_attr / env_method / env_is_wrapped / close;
+  * a zero-copy tensor interface (``step_tensor``) for device-resident RL loops.
+
+``TomatoEnv`` is the single-environment Gymnasium-style view (reset(seed) -> (obs, {}), step(a) ->
+(obs, reward, terminated, False, info)) with the attributes the reference's tooling reads
+(x, u, p, N, Np, timestep, weather_data, start_day, growth_year, ...; tomato_env.py:28-270).
+
+Semantics reproduced from the reference (file:line in gl_gym/environments/):
+  action -> control clip            tomato_env.py:109-113      episode = N+1 steps        tomato_env.py:131-137
+  weather row = timestep (pre-++)   tomato_env.py:120          obs at step k uses row k   observations.py:133,161
+  reward / info keys                rewards.py:218-231, tomato_env.py:208-222
+  ODE failure -> terminated, x kept tomato_env.py:119-123
+PyTorch is used for device memory, streams and RNG plumbing only; all arithmetic is in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .parameters import init_default_params
+from .utils import synthetic_weather
+
+try:  # spaces are optional plumbing: use gymnasium's when present
+    from gymnasium import spaces as _spaces
+
+    def _box(low, high, shape, dtype=np.float32):
+        return _spaces.Box(low=low, high=high, shape=shape, dtype=dtype)
+except Exception:  # pragma: no cover - gymnasium is absent in the build image
+    class _Box:
+        def __init__(self, low, high, shape, dtype):
+            self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape).copy()
+            self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape).copy()
+            self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+            self._rng = np.random.default_rng()
+
+        def seed(self, seed=None):
+            self._rng = np.random.default_rng(seed)
+
+        def sample(self):
+            return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+        def contains(self, v):
+            v = np.asarray(v)
+            return v.shape == self.shape and bool(np.all(v >= self.low) and np.all(v <= self.high))
+
+    def _box(low, high, shape, dtype=np.float32):
+        return _Box(low, high, shape, dtype)
+
+DEFAULT_REWARD = dict(fixed_greenhouse_cost=15., fixed_co2_cost=0.015, fixed_lamp_cost=0.07, fixed_screen_cost=2.,
+                      elec_price=0.3, heating_price=0.09, co2_price=0.3, fruit_price=1.6, dmfm=0.065,
+                      pen_weights=[4.e-4, 5.e-3, 7.e-4], pen_lamp=0.1)               # TomatoEnv.yml:56-67
+DEFAULT_CONSTRAINTS = dict(co2_min=300., co2_max=1600., temp_min=15., temp_max=34., rh_min=50., rh_max=85.)
+
+OBS_NAMES_CORE = ["co2_air", "temp_air", "rh_air", "pipe_temp", "24CanTemp", "cFruit", "tSum", "uBoil", "uCo2",
+                  "uThScr", "uVent", "uLamp", "uBlScr", "glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed",
+                  "timestep", "day of year sin", "day of year cos", "hour of day sin", "hour of day cos"]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class TomatoVecEnv:
+    def __init__(self, num_envs: int, weather: Optional[np.ndarray] = None, params: Optional[np.ndarray] = None,
+                 dt: float = 900.0, season_length: float = 60, pred_horizon: float = 0.5, dtype: str = "float32",
+                 n_sub: int = 256, device: str = "cuda:0", seed: int = 0, uncertainty_scale: float = 0.0,
+                 start_rows: Optional[Sequence[int]] = None, start_days: Optional[Sequence[float]] = None,
+                 reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
+                 auto_reset: bool = True, collect_metrics: bool = True):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise L.GlgymError("TomatoVecEnv needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self._lib = L.load()
+        self.torch = torch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.num_envs = self.B = int(num_envs)
+        self.ld = (self.B + 63) // 64 * 64
+        self.dt = float(dt)
+        self.c = 86400
+        self.nx, self.nu, self.nd, self.num_params = L.NX, L.NU, L.ND, L.NP
+        self.season_length = season_length
+        self.N = int(season_length * self.c / self.dt)                     # base_env.py:88
+        self.Np = int(pred_horizon * self.c / self.dt)                     # base_env.py:80
+        self.obs_dim = 23 + 5 * self.Np
+        self.f64 = str(dtype) in ("float64", "f64", "double")
+        self.tdtype = torch.float64 if self.f64 else torch.float32
+        self.n_sub = int(n_sub)
+        self.uncertainty_scale = float(uncertainty_scale)
+        self.auto_reset = auto_reset
+        self.seed_value = int(seed)
+
+        self.p = np.asarray(init_default_params(L.NP) if params is None else params, dtype=np.float32)
+        self._h = C.c_void_p()
+        p64 = np.ascontiguousarray(self.p, dtype=np.float64)
+        L.check(self._lib.glgym_create(L.NX, L.NU, L.ND, L.NP, self.dt, p64.ctypes.data_as(L._DP),
+                                       L.F64 if self.f64 else L.F32, self.n_sub, self.device.index or 0,
+                                       C.byref(self._h)), "glgym_create")
+        rp = dict(DEFAULT_REWARD, **(reward_params or {}))
+        cs = dict(DEFAULT_CONSTRAINTS, **(constraints or {}))
+        self.reward_params, self.constraints = rp, cs
+        cfg = L.RewardCfg(rp["elec_price"], rp["heating_price"], rp["co2_price"], rp["fruit_price"], rp["dmfm"],
+                          rp["fixed_greenhouse_cost"], rp["fixed_co2_cost"], rp["fixed_lamp_cost"],
+                          rp["fixed_screen_cost"], rp["pen_lamp"], cs["co2_min"], cs["co2_max"], cs["temp_min"],
+                          cs["temp_max"], cs["rh_min"], cs["rh_max"])
+        L.check(self._lib.glgym_set_reward(self._h, C.byref(cfg)), "glgym_set_reward")
+        mx, mn, fx = C.c_double(), C.c_double(), C.c_double()
+        L.check(self._lib.glgym_get_reward_scale(self._h, C.byref(mx), C.byref(mn), C.byref(fx)))
+        self.max_profit, self.min_profit, self.fixed_costs = mx.value, mn.value, fx.value
+
+        # ---- weather tensor (shared by all envs) and the admissible episode start rows
+        if weather is None:
+            weather = synthetic_weather(dt=self.dt)
+        self.weather_data = np.ascontiguousarray(weather, dtype=np.float64)
+        self.weather_rows = int(self.weather_data.shape[0])
+        need = self.N + 1 + self.Np + 1
+        if self.weather_rows < need:
+            raise ValueError(f"weather tensor has {self.weather_rows} rows, an episode needs {need}")
+        if start_rows is None:
+            start_rows = [0]
+        self.start_rows = np.asarray(start_rows, dtype=np.int64)
+        if np.any(self.start_rows + need > self.weather_rows) or np.any(self.start_rows < 0):
+            raise ValueError("start_rows + episode length exceeds the weather tensor")
+        self.start_days = np.asarray(start_days if start_days is not None
+                                     else self.start_rows * self.dt / self.c, dtype=np.float32)
+
+        dev, T = self.device, self.tdtype
+        z = lambda *s, dtype=T: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        self.weather_t = torch.as_tensor(self.weather_data, dtype=T, device=dev).contiguous()
+        self.x_T, self.u_T = z(L.NX, self.ld), z(L.NU, self.ld)
+        self.ctrl_T = z(L.NU, self.ld)
+        self.info_T = z(L.NINFO, self.ld)
+        self.reward_t = z(self.ld)
+        self.done_t = z(self.B, dtype=torch.uint8)
+        self.timestep_t = z(self.B, dtype=torch.int32)
+        self.w_off_t = z(self.B, dtype=torch.int32)
+        self.start_day_t = z(self.B, dtype=torch.float32)
+        self.action_t = z(self.B, L.NU, dtype=torch.float32)
+        self.obs_t = z(self.B, self.obs_dim, dtype=torch.float32)
+        self.term_obs_t = z(self.B, self.obs_dim, dtype=torch.float32)
+        self.metrics_t = z(L.NMETRIC, dtype=torch.float32) if collect_metrics else None
+        self.crop_T = z(L.NCROP, self.ld) if self.uncertainty_scale > 0 else None
+        self._start_rows_t = torch.as_tensor(self.start_rows, dtype=torch.int32, device=dev)
+        self._start_days_t = torch.as_tensor(self.start_days, dtype=torch.float32, device=dev)
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(self.seed_value)
+        self._draw = 0
+        self.x, self.u = self.x_T[:, :self.B].t(), self.u_T[:, :self.B].t()      # [B,28] / [B,6] views
+
+        self.observation_space = _box(-1e4, 1e4, (self.obs_dim,), np.float32)
+        self.action_space = _box(-1.0, 1.0, (L.NU,), np.float32)
+        self._actions = None
+        self.reset_infos: List[dict] = [{} for _ in range(self.B)]
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _sample_starts(self, n=None):
+        torch = self.torch
+        idx = torch.randint(0, len(self.start_rows), (self.B,), generator=self._gen, device=self.device)
+        return self._start_rows_t[idx], self._start_days_t[idx]
+
+    def _launch_reset(self, mask_t):
+        a = L.ResetArgs(self.B, self.ld, mask_t.data_ptr() if mask_t is not None else None, self.x_T.data_ptr(),
+                        self.u_T.data_ptr(), self.timestep_t.data_ptr(), self.weather_t.data_ptr(), self.weather_rows,
+                        self.w_off_t.data_ptr())
+        L.check(self._lib.glgym_reset(self._h, C.byref(a), self._stream()), "glgym_reset")
+
+    def _launch_obs(self, out_t):
+        a = L.ObsArgs(self.B, self.ld, self.x_T.data_ptr(), self.u_T.data_ptr(), self.weather_t.data_ptr(),
+                      self.weather_rows, self.w_off_t.data_ptr(), self.timestep_t.data_ptr(),
+                      self.start_day_t.data_ptr(), self.Np, out_t.data_ptr())
+        L.check(self._lib.glgym_obs(self._h, C.byref(a), self._stream()), "glgym_obs")
+
+    def _launch_step(self, raw_control: bool):
+        if self.crop_T is not None:       # noise.py: a fresh draw every step
+            L.check(self._lib.glgym_crop_noise(self._h, self.crop_T.data_ptr(), self.B, self.ld,
+                                               self.uncertainty_scale, self.seed_value, self._draw, self._stream()),
+                    "glgym_crop_noise")
+            self._draw += 1
+        a = L.StepArgs(self.B, self.ld, self.x_T.data_ptr(), self.u_T.data_ptr(),
+                       None if raw_control else self.action_t.data_ptr(),
+                       self.ctrl_T.data_ptr() if raw_control else None, self.weather_t.data_ptr(), self.weather_rows,
+                       self.w_off_t.data_ptr(), self.timestep_t.data_ptr(),
+                       self.crop_T.data_ptr() if self.crop_T is not None else None, self.N,
+                       self.reward_t.data_ptr(), self.info_T.data_ptr(), self.done_t.data_ptr(),
+                       self.metrics_t.data_ptr() if self.metrics_t is not None else None)
+        L.check(self._lib.glgym_step(self._h, C.byref(a), self._stream()), "glgym_step")
+
+    # ---- tensor interface (no host synchronisation) ---------------------------------------------
+    def reset_tensor(self, seed: Optional[int] = None):
+        if seed is not None:
+            self._gen.manual_seed(int(seed))
+        rows, days = self._sample_starts()
+        self.w_off_t.copy_(rows)
+        self.start_day_t.copy_(days)
+        self._launch_reset(None)
+        self._launch_obs(self.obs_t)
+        return self.obs_t
+
+    def step_tensor(self, actions_t=None, controls_t=None, want_obs: bool = True):
+        """actions_t [B,6] f32 in [-1,1] (step) or controls_t [B,6] (step_raw_control).  Returns
+        (obs [B,dim] f32, reward [B], done [B] uint8, info [11,B]) as device tensors; with auto_reset the
+        finished envs are re-initialised and ``term_obs_t`` keeps their last observation."""
+        if (actions_t is None) == (controls_t is None):
+            raise ValueError("give exactly one of actions_t / controls_t")
+        if actions_t is not None:
+            self.action_t.copy_(actions_t.reshape(self.B, L.NU))
+        else:
+            self.ctrl_T[:, :self.B].copy_(controls_t.reshape(self.B, L.NU).t())
+        self._launch_step(raw_control=controls_t is not None)
+        if want_obs:
+            self._launch_obs(self.obs_t)
+        if self.auto_reset:
+            if want_obs:
+                self.term_obs_t.copy_(self.obs_t)
+            rows, days = self._sample_starts()
+            m = self.done_t.bool()
+            self.w_off_t.copy_(self.torch.where(m, rows, self.w_off_t))
+            self.start_day_t.copy_(self.torch.where(m, days, self.start_day_t))
+            self._launch_reset(self.done_t)
+            if want_obs:
+                self._launch_obs(self.obs_t)
+        return self.obs_t, self.reward_t[:self.B], self.done_t, self.info_T[:, :self.B]
+
+    # ---- SB3 VecEnv calling convention ------------------------------------------------------------
+    def reset(self):
+        return self.reset_tensor().cpu().numpy()
+
+    def seed(self, seed: Optional[int] = None):
+        if seed is not None:
+            self._gen.manual_seed(int(seed))
+        return [seed] * self.B
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32)
+
+    def step_wait(self):
+        torch = self.torch
+        obs_t, r_t, d_t, info_T = self.step_tensor(torch.as_tensor(self._actions, device=self.device))
+        obs, rew = obs_t.cpu().numpy(), r_t.float().cpu().numpy()
+        dones = d_t.cpu().numpy().astype(bool)
+        info = info_T.double().cpu().numpy()
+        ctrl = self.u.double().cpu().numpy()
+        infos = []
+        term = self.term_obs_t.cpu().numpy() if (self.auto_reset and dones.any()) else None
+        for b in range(self.B):
+            d = {k: float(info[i, b]) for i, k in enumerate(L.INFO_KEYS)}
+            d["controls"] = ctrl[b]
+            d["TimeLimit.truncated"] = False
+            if term is not None and dones[b]:
+                d["terminal_observation"] = term[b]
+            infos.append(d)
+        return obs, rew, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_raw_control(self, controls):
+        torch = self.torch
+        obs_t, r_t, d_t, info_T = self.step_tensor(controls_t=torch.as_tensor(np.asarray(controls), dtype=self.tdtype,
+                                                                              device=self.device))
+        return obs_t.cpu().numpy(), r_t.float().cpu().numpy(), d_t.cpu().numpy().astype(bool), info_T.cpu().numpy()
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.B))
+        return [indices] if isinstance(indices, int) else list(indices)
+
+    def get_attr(self, attr_name: str, indices=None):
+        idx = self._indices(indices)
+        per_env = {"x": lambda b: self.x[b].double().cpu().numpy(), "u": lambda b: self.u[b].double().cpu().numpy(),
+                   "timestep": lambda b: int(self.timestep_t[b]), "start_day": lambda b: float(self.start_day_t[b]),
+                   "w_off": lambda b: int(self.w_off_t[b])}
+        if attr_name in per_env:
+            return [per_env[attr_name](b) for b in idx]
+        return [getattr(self, attr_name) for _ in idx]
+
+    def set_attr(self, attr_name: str, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name: str, *args, indices=None, **kwargs):
+        return [getattr(self, method_name)(*args, **kwargs) for _ in self._indices(indices)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._indices(indices)]
+
+    def get_obs_names(self):
+        return OBS_NAMES_CORE + ["glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed"] * self.Np
+
+    def metrics(self) -> Dict[str, float]:
+        if self.metrics_t is None:
+            return {}
+        v = self.metrics_t.cpu().numpy()
+        return {k: float(v[i]) for i, k in enumerate(L.METRIC_KEYS)}
+
+    def set_n_sub(self, n_sub: int):
+        self.n_sub = int(n_sub)
+        L.check(self._lib.glgym_set_n_sub(self._h, self.n_sub), "glgym_set_n_sub")
+
+    def timer_start(self):
+        L.check(self._lib.glgym_timer_start(self._h, self._stream()))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        L.check(self._lib.glgym_timer_stop(self._h, self._stream(), C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.torch.cuda.synchronize(self.device)
+            self._lib.glgym_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TomatoEnv:
+    """Single-environment Gymnasium-style view over a B = 1 ``TomatoVecEnv`` (no auto-reset)."""
+
+    def __init__(self, weather=None, params=None, dt=900.0, season_length=60, pred_horizon=0.5, dtype="float64",
+                 n_sub=256, device="cuda:0", uncertainty_scale=0.0, start_day=0.0, growth_year=2010,
+                 reward_params=None, constraints=None, location="synthetic", training=True):
+        self.vec = TomatoVecEnv(1, weather=weather, params=params, dt=dt, season_length=season_length,
+                                pred_horizon=pred_horizon, dtype=dtype, n_sub=n_sub, device=device,
+                                uncertainty_scale=uncertainty_scale, start_rows=[0], start_days=[start_day],
+                                reward_params=reward_params, constraints=constraints, auto_reset=False)
+        v = self.vec
+        self.nx, self.nu, self.nd, self.num_params, self.dt, self.c = v.nx, v.nu, v.nd, v.num_params, v.dt, v.c
+        self.N, self.Np, self.p = v.N, v.Np, v.p
+        self.weather_data = v.weather_data
+        self.observation_space, self.action_space = v.observation_space, v.action_space
+        self.start_day, self.growth_year, self.location, self.training = start_day, growth_year, location, training
+        self.u_min, self.u_max = np.zeros(6, np.float32), np.ones(6, np.float32)
+        self.delta_u_max = np.ones(6, np.float32) * 0.1
+        self.terminated = False
+
+    x = property(lambda self: self.vec.x[0].double().cpu().numpy())
+    u = property(lambda self: self.vec.u[0].double().cpu().numpy())
+    timestep = property(lambda self: int(self.vec.timestep_t[0]))
+    day_of_year = property(lambda self: self.start_day + self.timestep * ((self.dt / self.c) % 365))
+    hour_of_day = property(lambda self: (self.timestep * self.dt / 3600) % 24)
+
+    def reset(self, seed: Optional[int] = None):
+        obs = self.vec.reset_tensor(seed)
+        self.terminated = False
+        return obs[0].double().cpu().numpy(), {}
+
+    def action_to_control(self, action):
+        return np.clip(self.u + np.asarray(action) * self.delta_u_max, self.u_min, self.u_max)
+
+    def _finish(self, out):
+        obs_t, r_t, d_t, info_T = out
+        info = {k: float(info_T[i, 0]) for i, k in enumerate(L.INFO_KEYS)}
+        info["controls"] = self.u
+        self.terminated = bool(d_t[0])
+        return obs_t[0].double().cpu().numpy(), float(r_t[0]), self.terminated, False, info
+
+    def step(self, action):
+        t = self.vec.torch
+        return self._finish(self.vec.step_tensor(t.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, 6),
+                                                             device=self.vec.device)))
+
+    def step_raw_control(self, control):
+        t = self.vec.torch
+        return self._finish(self.vec.step_tensor(controls_t=t.as_tensor(np.asarray(control).reshape(1, 6),
+                                                                        dtype=self.vec.tdtype, device=self.vec.device)))
+
+    def set_crop_state(self, cBuf, cLeaf, cStem, cFruit, tCanSum):
+        for i, v in zip((22, 23, 24, 25, 26), (cBuf, cLeaf, cStem, cFruit, tCanSum)):
+            self.vec.x_T[i, 0] = v
+
+    def get_obs_names(self):
+        return self.vec.get_obs_names()
+
+    def close(self):
+        self.vec.close()

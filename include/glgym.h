@@ -1,0 +1,147 @@
+/*
+ * glgym.h -- C ABI of libglgym.so: the MI355X (gfx950) implementation of GreenLight-Gym's
+ * per-timestep ODE integration, i.e. the path TomatoEnv.step() drives.
+ *
+ * Plain C, pointers and sizes only (no torch / pybind types).  One handle = one HIP device + one
+ * parameter block + one dtype.  The library never allocates per call on the hot path and never
+ * synchronises the stream in glgym_step / glgym_obs / glgym_reset (safe to capture in a hipGraph);
+ * the host-pointer convenience entry points (glgym_evalF, glgym_rhs) do synchronise.
+ * Every function returns a glgym_status; nothing throws.  There is NO CPU fallback: without a HIP
+ * device glgym_create() returns GLGYM_ENODEV.
+ *
+ * Reference interface each entry point replaces (paths relative to the GreenLight-Gym2 repo):
+ *   glgym_create   <- GreenLight::GreenLight(nx,nu,nd,np,dt)   gl_gym/environments/models/greenlight_model.cpp:31-94
+ *                     + env.p = init_default_params(np)         gl_gym/environments/tomato_env.py:62
+ *   glgym_evalF    <- GreenLight::evalF(x,u,d,p) -> x_next      gl_gym/environments/models/greenlight_model.cpp:96-120
+ *                     (pybind binding                            gl_gym/environments/models/greenlight_model.cpp:130-136)
+ *   glgym_step     <- TomatoEnv.step / step_raw_control         gl_gym/environments/tomato_env.py:115-173
+ *                     (action_to_control :109-113, evalF call :120, terminal test :131-132,
+ *                      reward rewards.py:218-231, info tomato_env.py:208-222), batched over B envs
+ *   glgym_obs      <- TomatoEnv._get_obs + 6 observation modules gl_gym/environments/observations.py:59-182
+ *   glgym_reset    <- TomatoEnv.reset (state part)               gl_gym/environments/tomato_env.py:262-266,
+ *                     init_state                                  gl_gym/environments/utils.py:13-46
+ *   glgym_crop_noise <- parametric_crop_uncertainty               gl_gym/environments/noise.py:3-23
+ *   glgym_rhs      <- ODE(x,u,d,p) (test hook; no reference binding) gl_gym/environments/models/ode.hpp:6-124
+ *
+ * Layouts.  "SoA [n][ld]" = n planes of ld elements, element (i, b) at base[i*ld + b]; lane b of a
+ * wavefront touches consecutive addresses.  Element type T is float (GLGYM_F32) or double (GLGYM_F64).
+ */
+#ifndef GLGYM_H
+#define GLGYM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLGYM_NX 28
+#define GLGYM_NU 6
+#define GLGYM_ND 10
+#define GLGYM_NP 208
+#define GLGYM_NCROP 34      /* p[128..161], the block noise.py perturbs */
+#define GLGYM_NINFO 11      /* EPI, revenue, variable_costs, fixed_costs, co2_cost, heat_cost, elec_cost,
+                               temp_violation, co2_violation, rh_violation, lamp_violation (tomato_env.py:208-222) */
+#define GLGYM_NMETRIC 8     /* sum reward, sum EPI, n done, n ODE failures, sum co2/temp/rh violation, n env-steps */
+
+typedef struct glgym_handle_s* glgym_handle;
+
+typedef enum { GLGYM_F32 = 0, GLGYM_F64 = 1 } glgym_dtype;
+
+typedef enum {
+    GLGYM_OK = 0,
+    GLGYM_EINVAL = -1,   /* bad argument (sizes other than 28/6/10/208, null pointer, n_sub < 1 ...) */
+    GLGYM_ENODEV = -2,   /* no usable HIP device */
+    GLGYM_EHIP = -3,     /* a HIP runtime call failed; see glgym_last_error() */
+    GLGYM_ENOMEM = -4
+} glgym_status;
+
+/* Reward constants (gl_gym/configs/envs/TomatoEnv.yml:38-67; rewards.py:47-124). */
+typedef struct {
+    double elec_price, heating_price, co2_price, fruit_price, dmfm;
+    double fixed_greenhouse_cost, fixed_co2_cost, fixed_lamp_cost, fixed_screen_cost;
+    double pen_lamp;
+    double co2_min, co2_max, temp_min, temp_max, rh_min, rh_max;
+} glgym_reward_cfg;
+
+/* Device-pointer arguments of one batched env-step.  Exactly one of `action` / `control` is non-null. */
+typedef struct {
+    int32_t B;                 /* environments in this shard */
+    int32_t ld;                /* leading dimension of every SoA array (>= B) */
+    void* x;                   /* SoA [28][ld] T, in/out: state */
+    void* u;                   /* SoA [6][ld]  T, in/out: previous control in, applied control out */
+    const float* action;       /* [B][6] row-major f32 in [-1,1]: u <- clip(u + 0.1f*a, 0, 1)   (step)            */
+    const void* control;       /* SoA [6][ld] T: u <- control                                    (step_raw_control) */
+    const void* weather;       /* [weather_rows][10] row-major T, shared by all envs            */
+    int32_t weather_rows;
+    const int32_t* w_off;      /* [B] first weather row of each env's episode                    */
+    int32_t* timestep;         /* [B] in/out; row integrated over = w_off[b] + timestep[b]; then ++ */
+    const void* crop_p;        /* SoA [34][ld] T per-env p[128..161] (config 5) or NULL = shared  */
+    int32_t N;                 /* terminal test `timestep >= N` before the increment (episode = N+1 steps) */
+    void* reward;              /* [ld] T out */
+    void* info;                /* SoA [11][ld] T out, order of GLGYM_NINFO */
+    uint8_t* done;             /* [B] out: terminated (season end, or ODE failure -> state left unchanged) */
+    float* metrics;            /* [8] f32 accumulators (atomicAdd, GLGYM_NMETRIC order) or NULL */
+} glgym_step_args;
+
+/* Device-pointer arguments of observation assembly (row-major output, what SB3 / Gymnasium consume). */
+typedef struct {
+    int32_t B, ld;
+    const void* x;             /* SoA [28][ld] T */
+    const void* u;             /* SoA [6][ld]  T */
+    const void* weather;       /* [weather_rows][10] T */
+    int32_t weather_rows;
+    const int32_t* w_off;      /* [B] */
+    const int32_t* timestep;   /* [B] value AFTER the step's increment; 0 = freshly reset env */
+    const float* start_day;    /* [B] day of year at reset */
+    int32_t Np;                /* forecast rows (int(pred_horizon*86400/dt)); obs_dim = 23 + 5*Np */
+    float* obs;                /* [B][23 + 5*Np] row-major f32 out */
+} glgym_obs_args;
+
+/* Device-pointer arguments of a masked reset. */
+typedef struct {
+    int32_t B, ld;
+    const uint8_t* mask;       /* [B] reset env b iff mask[b] != 0; NULL = all */
+    void* x;                   /* SoA [28][ld] T out: init_state(weather[w_off[b]]) */
+    void* u;                   /* SoA [6][ld]  T out: zeros */
+    int32_t* timestep;         /* [B] out: 0 */
+    const void* weather;
+    int32_t weather_rows;
+    const int32_t* w_off;      /* [B] (already holding the NEW offsets of the envs being reset) */
+} glgym_reset_args;
+
+const char* glgym_version(void);
+const char* glgym_last_error(void);
+
+/* p: host, np doubles (the reference promotes its float32 parameter block to double before evalF). */
+int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int dtype, int n_sub, int device,
+                 glgym_handle* out);
+int glgym_destroy(glgym_handle h);
+int glgym_set_params(glgym_handle h, const double* p);
+int glgym_set_n_sub(glgym_handle h, int n_sub);
+int glgym_set_reward(glgym_handle h, const glgym_reward_cfg* cfg);
+int glgym_get_reward_scale(glgym_handle h, double* max_profit, double* min_profit, double* fixed_costs);
+
+/* Host pointers, row-major, double.  p_rows = 1 (one block for all rows) or B.  Synchronous. */
+int glgym_evalF(glgym_handle h, const double* x, const double* u, const double* d, const double* p, int p_rows,
+                int B, double* x_next);
+int glgym_rhs(glgym_handle h, const double* x, const double* u, const double* d, int B, double* dx);
+
+/* Device pointers; asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream);
+int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream);
+int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream);
+/* crop_p[i][b] = fl(p[128+i] * (1 + U(-scale/2, scale/2))), then p144 = p141/p142; Philox4x32-10 keyed by
+ * (seed, stream_id), counter (env index, draw_index).  crop_p: SoA [34][ld] T. */
+int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, uint64_t seed, uint64_t draw_index,
+                     void* stream);
+
+/* Kernel timing on the stream the kernels are launched on (bench.py's roofline leg). */
+int glgym_timer_start(glgym_handle h, void* stream);
+int glgym_timer_stop(glgym_handle h, void* stream, float* elapsed_ms);   /* synchronises the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLGYM_H */

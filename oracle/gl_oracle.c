@@ -1,0 +1,688 @@
+/*
+ * gl_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle), not the product path.
+ *
+ * Plain-C, fp64 restatement of the GreenLight greenhouse + tomato-crop ODE that
+ * the reference integrates inside TomatoEnv.step():
+ *   - helper physics          gl_gym/environments/models/aux_states.hpp:5-93
+ *   - update(): 239 aux       gl_gym/environments/models/aux_states.hpp:96-1271
+ *   - ODE(): 28 derivatives   gl_gym/environments/models/ode.hpp:6-124
+ *   - step map x -> x(dt)     gl_gym/environments/models/greenlight_model.cpp:46-63,96-120
+ *     (reference: CasADi 3.6.7 "cvodes", BDF, abstol = reltol = 1e-6, (u,d,p) frozen)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Parity status
+ *   RHS (aux + dx): PINNED -- checked against tests/golden/rhs_kat.npz, produced by
+ *     tests/golden/make_golden.py evaluating the reference's own statement text
+ *     (read from /root/reference at generation time) in IEEE double.
+ *   Integrator: the reference's CVODES cannot be built here (CasADi/SUNDIALS absent and
+ *     un-vendored; no stand-ins written).  "parity unpinned" for CVODES itself: the step
+ *     map is bounded against a tight stiff solve (tests/golden/step_tight.npz) instead.
+ *
+ * Aux numbering a[0..238] follows the reference one-for-one so every intermediate
+ * can be compared with the golden vectors.  AUX(i, name, expr) defines the named
+ * value and stores it at the reference's index i.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#define GL_NX 28
+#define GL_NU 6
+#define GL_ND 10
+#define GL_NP 208
+#define GL_NAUX 239
+
+#define AUX(i, name, expr) const double name = (expr); a[i] = name
+#define ZERO_AUX(i) a[i] = 0.0
+
+static const double PI_ = 3.14159265358979323846;
+static const double C2K = 273.15;
+
+/* aux_states.hpp:5-12  Magnus saturation vapour pressure [Pa] */
+static double sat_vp(double t) { return 610.78 * exp(17.2694 * t / (t + 238.3)); }
+
+/* aux_states.hpp:14-23  CO2 density [kg m-3] -> ppm */
+static double co2_dens_to_ppm(double t, double dens)
+{
+    const double R = 8.3144598, M_CO2 = 44.01e-3, P_ATM = 101325.0;
+    return 1e6 * R * (t + C2K) * dens / (P_ATM * M_CO2);
+}
+
+/* aux_states.hpp:25-41  double-layer optics */
+static double tau12(double tau1, double tau2, double rho1dn, double rho2up)
+{
+    return tau1 * tau2 / (1.0 - rho1dn * rho2up);
+}
+static double rho_up(double tau1, double rho1up, double rho1dn, double rho2up)
+{
+    return rho1up + (tau1 * tau1 * rho2up) / (1.0 - rho1dn * rho2up);
+}
+static double rho_dn(double tau2, double rho1dn, double rho2up, double rho2dn)
+{
+    return rho2dn + (tau2 * tau2 * rho1dn) / (1.0 - rho1dn * rho2up);
+}
+
+/* aux_states.hpp:48-52  net far-infrared exchange 1 -> 2 [W m-2] */
+static double fir(double a1, double e1, double e2, double f12, double t1, double t2, double sigma)
+{
+    return a1 * e1 * e2 * f12 * sigma * (pow(t1 + C2K, 4.0) - pow(t2 + C2K, 4.0));
+}
+
+/* aux_states.hpp:54-58  sensible heat 1 -> 2 [W m-2] */
+static double sensible(double hec, double t1, double t2) { return fabs(hec) * (t1 - t2); }
+
+/* aux_states.hpp:60-63  logistic-gated condensation [kg m-2 s-1] */
+static double cond(double hec, double vp1, double vp2)
+{
+    return 1.0 / (1.0 + exp(-0.1 * (vp1 - vp2))) * 6.4e-9 * hec * (vp1 - vp2);
+}
+
+/* aux_states.hpp:75-79  harvest switch, tanh form (the live one) */
+static double smooth_har(double v, double cutoff, double smooth, double max_rate)
+{
+    const double k = 2.0 * 4.6052 / smooth;
+    const double z = k * (v - cutoff) / 2.0;
+    return max_rate * (tanh(z) + 1.0) / 2.0;
+}
+
+/* aux_states.hpp:81-87  vapour carried by an air flux; NB the reference declares the
+ * Kelvin offset as `const float`, so it is the float32-rounded 273.15 here. */
+static double air_mv(double f12, double vp1, double vp2, double t1, double t2)
+{
+    const double c2k_f32 = (double)273.15f;
+    return 0.002165 * fabs(f12) * (vp1 / (t1 + c2k_f32) - vp2 / (t2 + c2k_f32));
+}
+
+/* aux_states.hpp:89-93  CO2 carried by an air flux */
+static double air_mc(double f12, double c1, double c2) { return fabs(f12) * (c1 - c2); }
+
+/* ------------------------------------------------------------------------------------
+ * update(): aux_states.hpp:96-1271
+ * ---------------------------------------------------------------------------------- */
+void gl_oracle_aux(const double *x, const double *u, const double *d, const double *p, double *a)
+{
+    const double uThScr = u[2], uBlScr = u[5];
+    const double sigma = p[2];
+
+    /* thermal screen + roof, PAR (:111-122) and NIR (:127-139) */
+    AUX(0, tauThScrPar, 1.0 - uThScr * (1.0 - p[80]));
+    AUX(1, rhoThScrPar, uThScr * p[77]);
+    AUX(2, tauCovThScrPar, tau12(p[69], tauThScrPar, p[66], rhoThScrPar));
+    AUX(3, rhoCovThScrParUp, rho_up(p[69], p[66], p[66], rhoThScrPar));
+    AUX(4, rhoCovThScrParDn, rho_dn(tauThScrPar, p[66], rhoThScrPar, rhoThScrPar));
+    AUX(5, tauThScrNir, 1.0 - uThScr * (1.0 - p[79]));
+    AUX(6, rhoThScrNir, uThScr * p[76]);
+    AUX(7, tauCovThScrNir, tau12(p[68], tauThScrNir, p[65], rhoThScrNir));
+    AUX(8, rhoCovThScrNirUp, rho_up(p[68], p[65], p[65], rhoThScrNir));
+    AUX(9, rhoCovThScrNirDn, rho_dn(tauThScrNir, p[65], rhoThScrNir, rhoThScrNir));
+
+    /* + blackout screen (:145-177) */
+    AUX(10, tauBlScrPar, 1.0 - uBlScr * (1.0 - p[90]));
+    AUX(11, rhoBlScrPar, uBlScr * p[88]);
+    AUX(12, tauCovBlScrPar, tau12(tauCovThScrPar, tauBlScrPar, rhoCovThScrParDn, rhoBlScrPar));
+    AUX(13, rhoCovBlScrParUp, rho_up(tauCovThScrPar, rhoCovThScrParUp, rhoCovThScrParDn, rhoBlScrPar));
+    AUX(14, rhoCovBlScrParDn, rho_dn(tauBlScrPar, rhoCovThScrParDn, rhoBlScrPar, rhoBlScrPar));
+    AUX(15, tauBlScrNir, 1.0 - uBlScr * (1.0 - p[89]));
+    AUX(16, rhoBlScrNir, uBlScr * p[87]);
+    AUX(17, tauCovBlScrNir, tau12(tauCovThScrNir, tauBlScrNir, rhoCovThScrNirDn, rhoBlScrNir));
+    AUX(18, rhoCovBlScrNirUp, rho_up(tauCovThScrNir, rhoCovThScrNirUp, rhoCovThScrNirDn, rhoBlScrNir));
+    AUX(19, rhoCovBlScrNirDn, rho_dn(tauBlScrNir, rhoCovThScrNirDn, rhoBlScrNir, rhoBlScrNir));
+
+    /* + lamp layer: whole cover (:183-220) */
+    AUX(20, tauCovPar, tau12(tauCovBlScrPar, p[176], rhoCovBlScrParDn, p[179]));
+    AUX(21, rhoCovPar, rho_up(tauCovBlScrPar, rhoCovBlScrParUp, rhoCovBlScrParDn, p[179]));
+    AUX(22, tauCovNir, tau12(tauCovBlScrNir, p[177], rhoCovBlScrNirDn, p[180]));
+    AUX(23, rhoCovNir, rho_up(tauCovBlScrNir, rhoCovBlScrNirUp, rhoCovBlScrNirDn, p[180]));
+    AUX(24, tauCovFir, p[70]);
+    AUX(25, rhoCovFir, p[67]);
+    AUX(26, aCovPar, 1.0 - tauCovPar - rhoCovPar);
+    AUX(27, aCovNir, 1.0 - tauCovNir - rhoCovNir);
+    AUX(28, aCovFir, 1.0 - tauCovFir - rhoCovFir);
+    AUX(29, epsCovFir, aCovFir);
+
+    /* capacities (:227-249) */
+    AUX(30, capCov, cos(p[45] * PI_ / 180.0) * p[73] * p[64] * p[72]);
+    AUX(31, lai, p[142] * x[23]);
+    AUX(32, capCan, p[16] * lai);
+    AUX(33, capCovE, 0.1 * capCov);
+    AUX(34, capCovIn, 0.1 * capCov);
+    AUX(35, capVpAir, p[38] * p[48] / (p[39] * (x[2] + C2K)));
+    AUX(36, capVpTop, p[38] * (p[49] - p[48]) / (p[39] * (x[3] + C2K)));
+
+    /* short-wave radiation (:256-470) */
+    AUX(37, qLampIn, p[172] * u[4]);
+    AUX(38, qIntLampIn, 0.0);
+    AUX(39, rParGhSun, (1.0 - p[44]) * tauCovPar * p[6] * d[0]);
+    AUX(40, rParGhLamp, p[174] * qLampIn);
+    AUX(41, rParGhIntLamp, p[192] * qIntLampIn);
+    AUX(42, rCanSun, (1.0 - p[44]) * d[0] * (p[6] * tauCovPar + p[5] * tauCovNir));
+    AUX(43, rCanLamp, (p[174] + p[175]) * qLampIn);
+    AUX(44, rCanIntLamp, (p[192] + p[193]) * qIntLampIn);
+    AUX(45, rCan, rCanSun + rCanLamp + rCanIntLamp);
+    AUX(46, rParSunCanDown, rParGhSun * (1.0 - p[10]) * (1.0 - exp(-p[32] * lai)));
+    AUX(47, rParLampCanDown, rParGhLamp * (1.0 - p[10]) * (1.0 - exp(-p[32] * lai)));
+    AUX(48, fIntLampCanPar,
+        1.0 - p[190] * exp(-p[200] * p[189] * lai) + (p[190] - 1.0) * exp(-p[200] * (1.0 - p[189]) * lai));
+    AUX(49, fIntLampCanNir,
+        1.0 - p[190] * exp(-p[202] * p[189] * lai) + (p[190] - 1.0) * exp(-p[202] * (1.0 - p[189]) * lai));
+    AUX(50, rParIntLampCanDown, rParGhIntLamp * fIntLampCanPar * (1.0 - p[10]));
+    AUX(51, rParSunFlrCanUp,
+        rParGhSun * exp(-p[32] * lai) * p[98] * (1.0 - p[10]) * (1.0 - exp(-p[33] * lai)));
+    AUX(52, rParLampFlrCanUp,
+        rParGhLamp * exp(-p[32] * lai) * p[98] * (1.0 - p[10]) * (1.0 - exp(-p[33] * lai)));
+    AUX(53, rParIntLampFlrCanUp,
+        rParGhIntLamp * p[190] * exp(-p[200] * p[189] * lai) * p[98] * (1.0 - p[10]) *
+            (1.0 - exp(-p[201] * lai)));
+    AUX(54, rParSunCan, rParSunCanDown + rParSunFlrCanUp);
+    AUX(55, rParLampCan, rParLampCanDown + rParLampFlrCanUp);
+    AUX(56, rParIntLampCan, rParIntLampCanDown + rParIntLampFlrCanUp);
+    AUX(57, tauHatCovNir, 1.0 - rhoCovNir);
+    AUX(58, tauHatFlrNir, 1.0 - p[97]);
+    AUX(59, tauHatCanNir, exp(-p[34] * lai));
+    AUX(60, rhoHatCanNir, p[11] * (1.0 - tauHatCanNir));
+    AUX(61, tauCovCanNir, tau12(tauHatCovNir, tauHatCanNir, rhoCovNir, rhoHatCanNir));
+    AUX(62, rhoCovCanNirUp, rho_up(tauHatCovNir, rhoCovNir, rhoCovNir, rhoHatCanNir));
+    AUX(63, rhoCovCanNirDn, rho_dn(tauHatCanNir, rhoCovNir, rhoHatCanNir, rhoHatCanNir));
+    AUX(64, tauCovCanFlrNir, tau12(tauCovCanNir, tauHatFlrNir, rhoCovCanNirDn, p[97]));
+    AUX(65, rhoCovCanFlrNir, rho_up(tauCovCanNir, rhoCovCanNirUp, rhoCovCanNirDn, p[97]));
+    AUX(66, aCanNir, 1.0 - tauCovCanFlrNir - rhoCovCanFlrNir);
+    AUX(67, aFlrNir, tauCovCanFlrNir);
+    AUX(68, rNirSunCan, (1.0 - p[44]) * aCanNir * p[5] * d[0]);
+    AUX(69, rNirLampCan, p[175] * qLampIn * (1.0 - p[11]) * (1.0 - exp(-p[34] * lai)));
+    AUX(70, rNirIntLampCan, p[193] * qIntLampIn * fIntLampCanNir * (1.0 - p[11]));
+    AUX(71, rNirSunFlr, (1.0 - p[44]) * aFlrNir * p[5] * d[0]);
+    AUX(72, rNirLampFlr, (1.0 - p[97]) * exp(-p[34] * lai) * p[175] * qLampIn);
+    AUX(73, rNirIntLampFlr, p[190] * (1.0 - p[97]) * exp(-p[202] * lai * p[189]) * p[193] * qIntLampIn);
+    AUX(74, rParSunFlr, (1.0 - p[98]) * exp(-p[32] * lai) * rParGhSun);
+    AUX(75, rParLampFlr, (1.0 - p[98]) * exp(-p[32] * lai) * rParGhLamp);
+    AUX(76, rParIntLampFlr, rParGhIntLamp * p[190] * (1.0 - p[98]) * exp(-p[200] * lai * p[189]));
+    AUX(77, rLampAir, (p[174] + p[175]) * qLampIn - rParLampCan - rNirLampCan - rParLampFlr - rNirLampFlr);
+    AUX(78, rIntLampAir,
+        (p[192] + p[193]) * qIntLampIn - rParIntLampCan - rNirIntLampCan - rParIntLampFlr - rNirIntLampFlr);
+    AUX(79, rGlobSunAir, p[44] * d[0] * (tauCovPar * p[6] + (aCanNir + aFlrNir) * p[5]));
+    AUX(80, rGlobSunCovE, (aCovPar * p[6] + aCovNir * p[5]) * d[0]);
+
+    /* long-wave view factors (:476-484) */
+    AUX(81, tauThScrFirU, 1.0 - uThScr * (1.0 - p[81]));
+    AUX(82, tauBlScrFirU, 1.0 - uBlScr * (1.0 - p[91]));
+    AUX(83, aCan, 1.0 - exp(-p[35] * lai));
+
+    const double tCan = x[4], tCovIn = x[5], tCovE = x[6], tThScr = x[7], tFlr = x[8], tPipe = x[9];
+    const double tLamp = x[17], tIntLamp = x[18], tGroPipe = x[19], tBlScr = x[20];
+    const double tSky = d[5];
+    const double canGap = exp(-p[35] * lai);                    /* FIR transmission of the canopy */
+    const double pipeShade = 1.0 - 0.49 * PI_ * p[107] * p[105];  /* floor area not under pipes  */
+    const double pipeCover = 0.49 * PI_ * p[107] * p[105];
+
+    /* FIR exchange between objects (:493-632) */
+    AUX(84, rCanCovIn, fir(aCan, p[3], epsCovFir, p[178] * tauThScrFirU * tauBlScrFirU, tCan, tCovIn, sigma));
+    AUX(85, rCanSky, fir(aCan, p[3], p[4], p[178] * tauCovFir * tauThScrFirU * tauBlScrFirU, tCan, tSky, sigma));
+    AUX(86, rCanThScr, fir(aCan, p[3], p[74], p[178] * uThScr * tauBlScrFirU, tCan, tThScr, sigma));
+    AUX(87, rCanFlr, fir(aCan, p[3], p[95], p[125], tCan, tFlr, sigma));
+    AUX(88, rPipeCovIn,
+        fir(p[124], p[104], epsCovFir, p[199] * p[178] * tauThScrFirU * tauBlScrFirU * 0.49 * canGap, tPipe, tCovIn,
+            sigma));
+    /* :520 -- no blackout-screen factor here, unlike its siblings (reference quirk) */
+    AUX(89, rPipeSky,
+        fir(p[124], p[104], p[4], p[199] * p[178] * tauCovFir * tauThScrFirU * 0.49 * canGap, tPipe, tSky, sigma));
+    AUX(90, rPipeThScr,
+        fir(p[124], p[104], p[74], p[199] * p[178] * uThScr * tauBlScrFirU * 0.49 * canGap, tPipe, tThScr, sigma));
+    AUX(91, rPipeFlr, fir(p[124], p[104], p[95], 0.49, tPipe, tFlr, sigma));
+    AUX(92, rPipeCan, fir(p[124], p[104], p[3], 0.49 * (1.0 - canGap), tPipe, tCan, sigma));
+    AUX(93, rFlrCovIn,
+        fir(1.0, p[95], epsCovFir, p[199] * p[178] * tauThScrFirU * tauBlScrFirU * pipeShade * canGap, tFlr, tCovIn,
+            sigma));
+    AUX(94, rFlrSky,
+        fir(1.0, p[95], p[4], p[199] * p[178] * tauCovFir * tauThScrFirU * tauBlScrFirU * pipeShade * canGap, tFlr,
+            tSky, sigma));
+    AUX(95, rFlrThScr,
+        fir(1.0, p[95], p[74], p[199] * p[178] * uThScr * tauBlScrFirU * pipeShade * canGap, tFlr, tThScr, sigma));
+    AUX(96, rThScrCovIn, fir(1.0, p[74], epsCovFir, uThScr, tThScr, tCovIn, sigma));
+    AUX(97, rThScrSky, fir(1.0, p[74], p[4], tauCovFir * uThScr, tThScr, tSky, sigma));
+    AUX(98, rCovESky, fir(1.0, aCovFir, p[4], 1.0, tCovE, tSky, sigma));
+    AUX(99, rFirLampFlr, fir(p[181], p[183], p[95], p[199] * pipeShade * canGap, tLamp, tFlr, sigma));
+    AUX(100, rLampPipe, fir(p[181], p[183], p[104], p[199] * pipeCover * canGap, tLamp, tPipe, sigma));
+    AUX(101, rFirLampCan, fir(p[181], p[183], p[3], aCan, tLamp, tCan, sigma));
+    AUX(102, rLampThScr, fir(p[181], p[182], p[74], uThScr * tauBlScrFirU, tLamp, tThScr, sigma));
+    AUX(103, rLampCovIn, fir(p[181], p[182], epsCovFir, tauThScrFirU * tauBlScrFirU, tLamp, tCovIn, sigma));
+    AUX(104, rLampSky, fir(p[181], p[182], p[4], tauCovFir * tauThScrFirU * tauBlScrFirU, tLamp, tSky, sigma));
+    AUX(105, rGroPipeCan, fir(p[169], p[165], p[3], 1.0, tGroPipe, tCan, sigma));
+    AUX(106, rFlrBlScr, fir(1.0, p[95], p[85], p[199] * p[178] * uBlScr * pipeShade * canGap, tFlr, tBlScr, sigma));
+    AUX(107, rPipeBlScr,
+        fir(p[124], p[104], p[85], p[199] * p[178] * uBlScr * 0.49 * canGap, tPipe, tBlScr, sigma));
+    AUX(108, rCanBlScr, fir(aCan, p[3], p[85], p[178] * uBlScr, tCan, tBlScr, sigma));
+    AUX(109, rBlScrThScr, fir(uBlScr, p[85], p[74], uThScr, tBlScr, tThScr, sigma));
+    AUX(110, rBlScrCovIn, fir(uBlScr, p[85], epsCovFir, tauThScrFirU, tBlScr, tCovIn, sigma));
+    AUX(111, rBlScrSky, fir(uBlScr, p[85], p[4], tauCovFir * tauThScrFirU, tBlScr, tSky, sigma));
+    AUX(112, rLampBlScr, fir(p[181], p[182], p[85], uBlScr, tLamp, tBlScr, sigma));
+
+    /* interlights (:637-691); their input power is zero but the terms are evaluated */
+    AUX(113, fIntLampCanUp, 1.0 - exp(-p[203] * (1.0 - p[189]) * lai));
+    AUX(114, fIntLampCanDown, 1.0 - exp(-p[203] * p[189] * lai));
+    AUX(115, rFirIntLampFlr, fir(p[194], p[195], p[95], pipeShade * (1.0 - fIntLampCanDown), tIntLamp, tFlr, sigma));
+    AUX(116, rIntLampPipe, fir(p[194], p[195], p[104], pipeCover * (1.0 - fIntLampCanDown), tIntLamp, tPipe, sigma));
+    AUX(117, rFirIntLampCan, fir(p[194], p[195], p[3], fIntLampCanDown + fIntLampCanUp, tIntLamp, tCan, sigma));
+    AUX(118, rIntLampLamp, fir(p[194], p[195], p[183], (1.0 - fIntLampCanUp) * p[181], tIntLamp, tLamp, sigma));
+    AUX(119, rIntLampBlScr,
+        fir(p[194], p[195], p[85], uBlScr * p[178] * (1.0 - fIntLampCanUp), tIntLamp, tBlScr, sigma));
+    AUX(120, rIntLampThScr,
+        fir(p[194], p[195], p[74], uThScr * tauBlScrFirU * p[178] * (1.0 - fIntLampCanUp), tIntLamp, tThScr, sigma));
+    AUX(121, rIntLampCovIn,
+        fir(p[194], p[195], epsCovFir, tauThScrFirU * tauBlScrFirU * p[178] * (1.0 - fIntLampCanUp), tIntLamp,
+            tCovIn, sigma));
+    AUX(122, rIntLampSky,
+        fir(p[194], p[195], p[4], tauCovFir * tauThScrFirU * tauBlScrFirU * p[178] * (1.0 - fIntLampCanUp), tIntLamp,
+            tSky, sigma));
+
+    /* natural ventilation (:698-779) */
+    const double tAir = x[2], tTop = x[3], tOut = d[1], wind = d[4];
+    AUX(123, aRoofU, u[3] * p[55]);
+    AUX(124, aRoofUMax, p[55]);
+    ZERO_AUX(125);
+    AUX(126, aSideU, 0.0);
+    AUX(127, etaRoof, 1.0);
+    AUX(128, etaRoofNoSide, 1.0);
+    AUX(129, etaSide, 0.0);
+    AUX(130, cD, p[59]);
+    AUX(131, cW, p[61]);
+    (void)aRoofUMax;
+    (void)etaRoofNoSide;
+    AUX(132, fVentRoof2,
+        u[3] * p[55] * cD / (2.0 * p[46]) *
+            sqrt(fabs(p[26] * p[56] * (tAir - tOut) / (2.0 * (0.5 * tAir + 0.5 * tOut + C2K)) + cW * (wind * wind))));
+    const double aMix = aRoofU * aSideU / sqrt(fmax(aRoofU * aRoofU + aSideU * aSideU, 0.01));
+    const double aSum = aRoofU + aSideU / 2.0;
+    AUX(133, fVentRoofSide2,
+        cD / p[46] *
+            sqrt(1e-8 + (aMix * aMix) * (2.0 * p[26] * p[62] * (tAir - tOut) / (0.5 * tAir + 0.5 * tOut + C2K)) +
+                 (aSum * aSum) * cW * (wind * wind)));
+    AUX(134, fVentSide2, cD * aSideU * wind / (2.0 * p[46]) * sqrt(cW));
+    AUX(135, fLeakage, (wind < p[205]) ? p[205] * p[60] : p[60] * wind);
+    const double scrMax = fmax(uThScr, uBlScr);
+    AUX(136, fVentRoof,
+        (etaRoof >= p[8]) ? p[57] * fVentRoof2 + p[204] * fLeakage
+                          : p[57] * (scrMax * fVentRoof2 + (1.0 - scrMax) * fVentRoofSide2 * etaRoof) +
+                                p[204] * fLeakage);
+    AUX(137, fVentSide,
+        (etaRoof >= p[8]) ? p[57] * fVentSide2 + (1.0 - p[204]) * fLeakage
+                          : p[57] * (scrMax * fVentSide2 + (1.0 - scrMax) * fVentRoofSide2 * etaSide) +
+                                (1.0 - p[204]) * fLeakage);
+
+    /* indoor CO2 in ppm, air densities, air flux through the screens (:782-820) */
+    AUX(138, co2InPpm, co2_dens_to_ppm(tAir, 1e-6 * x[0]));
+    AUX(139, rhoTop, p[36] * p[126] / ((tTop + C2K) * p[39]));
+    AUX(140, rhoAir, p[36] * p[126] / ((tAir + C2K) * p[39]));
+    AUX(141, rhoAirMean, 0.5 * (rhoTop + rhoAir));
+    AUX(142, fThScr,
+        uThScr * p[84] * pow(fabs(tAir - tTop + 1e-10), 0.66) +
+            ((1.0 - uThScr) / rhoAirMean) *
+                sqrt(0.5 * rhoAirMean * (1.0 - uThScr) * p[26] * fabs(rhoAir - rhoTop) + 1e-10));
+    AUX(143, fBlScr,
+        uBlScr * p[94] * pow(fabs(tAir - tTop + 1e-10), 0.66) +
+            ((1.0 - uBlScr) / rhoAirMean) *
+                sqrt(0.5 * rhoAirMean * (1.0 - uBlScr) * p[26] * fabs(rhoAir - rhoTop) + 1e-10));
+    AUX(144, fScr, fmin(fThScr, fBlScr));
+    AUX(145, fVentForced, 0.0);
+
+    /* convection / conduction (:824-935) */
+    AUX(146, hCanAir, sensible(2.0 * p[0] * lai, tCan, tAir));
+    AUX(147, hAirFlr,
+        (tFlr > tAir) ? sensible(1.7 * pow(fabs(tFlr - tAir + 1e-10), 1.0 / 3.0), tAir, tFlr)
+                      : sensible(1.3 * pow(fabs(tAir - tFlr + 1e-10), 1.0 / 4.0), tAir, tFlr));
+    AUX(148, hAirThScr, sensible(1.7 * uThScr * pow(fabs(tAir - tThScr + 1e-10), 1.0 / 3.0), tAir, tThScr));
+    AUX(149, hAirBlScr, sensible(1.7 * uBlScr * pow(fabs(tAir - tBlScr + 1e-10), 1.0 / 3.0), tAir, tBlScr));
+    AUX(150, hAirOut, sensible(p[111] * p[23] * (fVentSide + fVentForced), tAir, tOut));
+    AUX(151, hAirTop, sensible(p[111] * p[23] * fScr, tAir, tTop));
+    AUX(152, hThScrTop, sensible(1.7 * uThScr * pow(fabs(tThScr - tTop + 1e-10), 1.0 / 3.0), tThScr, tTop));
+    AUX(153, hBlScrTop, sensible(1.7 * uBlScr * pow(fabs(tBlScr - tTop + 1e-10), 1.0 / 3.0), tBlScr, tTop));
+    AUX(154, hTopCovIn,
+        sensible(p[50] * pow(fabs(tTop - tCovIn + 1e-10), 1.0 / 3.0) * p[47] / p[46], tTop, tCovIn));
+    AUX(155, hTopOut, sensible(p[111] * p[23] * fVentRoof, tTop, tOut));
+    AUX(156, hCovEOut, sensible(p[47] / p[46] * (p[51] + p[52] * pow(wind, p[53])), tCovE, tOut));
+    AUX(157, hPipeAir,
+        sensible(1.99 * PI_ * p[105] * p[107] * pow(fabs(tPipe - tAir + 1e-10), 0.32), tPipe, tAir));
+    AUX(158, hFlrSo1, sensible(2.0 / (p[101] / p[99] + p[27] / p[103]), tFlr, x[10]));
+    AUX(159, hSo1So2, sensible(2.0 * p[103] / (p[27] + p[28]), x[10], x[11]));
+    AUX(160, hSo2So3, sensible(2.0 * p[103] / (p[28] + p[29]), x[11], x[12]));
+    AUX(161, hSo3So4, sensible(2.0 * p[103] / (p[29] + p[30]), x[12], x[13]));
+    AUX(162, hSo4So5, sensible(2.0 * p[103] / (p[30] + p[31]), x[13], x[14]));
+    AUX(163, hSo5SoOut, sensible(2.0 * p[103] / (p[31] + p[37]), x[14], d[6]));
+    AUX(164, hCovInCovE, sensible(1.0 / (p[73] / p[71]), tCovIn, tCovE));
+    AUX(165, hLampAir, sensible(p[185], tLamp, tAir));
+    AUX(166, hGroPipeAir,
+        sensible(1.99 * PI_ * p[167] * p[166] * pow(fabs(tGroPipe - tAir + 1e-10), 0.32), tGroPipe, tAir));
+    AUX(167, hIntLampAir, sensible(p[198], tIntLamp, tAir));
+
+    /* stomata and transpiration (:940-981) */
+    AUX(168, sRs, 1.0 / (1.0 + exp(p[43] * (rCan - p[40]))));
+    AUX(169, cEvap3, p[20] * (1.0 - sRs) + p[19] * sRs);
+    AUX(170, cEvap4, p[22] * (1.0 - sRs) + p[21] * sRs);
+    AUX(171, rfRCan, (rCan + p[17]) / (rCan + p[18]));
+    const double co2Dev = p[7] * x[0] - 200.0;
+    AUX(172, rfCo2, fmin(1.5, 1.0 + cEvap3 * (co2Dev * co2Dev)));
+    const double vpd = sat_vp(tCan) - x[15];
+    AUX(173, rfVp, fmin(5.8, 1.0 + cEvap4 * (vpd * vpd)));
+    AUX(174, rS, p[42] * rfRCan * rfCo2 * rfVp);
+    AUX(175, vecCanAir, 2.0 * p[111] * p[23] * lai / (p[1] * p[14] * (p[41] + rS)));
+    AUX(176, mvCanAir, vpd * vecCanAir);
+
+    /* vapour fluxes (:987-1024) */
+    ZERO_AUX(177);
+    ZERO_AUX(178);
+    ZERO_AUX(179);
+    ZERO_AUX(180);
+    AUX(181, mvAirThScr, cond(1.7 * uThScr * pow(fabs(tAir - tThScr + 1e-10), 1.0 / 3.0), x[15], sat_vp(tThScr)));
+    AUX(182, mvAirBlScr, cond(1.7 * uBlScr * pow(fabs(tAir - tBlScr + 1e-10), 1.0 / 3.0), x[15], sat_vp(tBlScr)));
+    AUX(183, mvTopCovIn,
+        cond(p[50] * pow(fabs(tTop - tCovIn + 1e-10), 1.0 / 3.0) * p[47] / p[46], x[16], sat_vp(tCovIn)));
+    AUX(184, mvAirTop, air_mv(fScr, x[15], x[16], tAir, tTop));
+    AUX(185, mvTopOut, air_mv(fVentRoof, x[16], d[2], tTop, tOut));
+    AUX(186, mvAirOut, air_mv(fVentSide + fVentForced, x[15], d[2], tAir, tOut));
+
+    /* latent heat (:1027-1030) */
+    AUX(187, lCanAir, p[1] * mvCanAir);
+    AUX(188, lAirThScr, p[1] * mvAirThScr);
+    AUX(189, lAirBlScr, p[1] * mvAirBlScr);
+    AUX(190, lTopCovIn, p[1] * mvTopCovIn);
+
+    /* photosynthesis (:1041-1097) */
+    AUX(191, parCan, p[187] * rParLampCan + p[140] * rParSunCan + p[197] * rParIntLampCan);
+    AUX(192, j25CanMax, lai * p[129]);
+    AUX(193, gammaStar, (p[129] / j25CanMax) * p[130] * tCan + 20.0 * p[130] * (1.0 - (p[129] / j25CanMax)));
+    AUX(194, co2Stom, p[131] * co2InPpm);
+    const double tCanK = tCan + C2K;
+    AUX(195, jPot,
+        j25CanMax * exp(p[132] * (tCanK - p[133]) / (1e-3 * p[39] * tCanK * p[133])) *
+            (1.0 + exp((p[134] * p[133] - p[135]) / (1e-3 * p[39] * p[133]))) /
+            (1.0 + exp((p[134] * tCanK - p[135]) / (1e-3 * p[39] * tCanK))));
+    const double jSum = jPot + p[137] * parCan;
+    AUX(196, jRate,
+        (1.0 / (2.0 * p[136])) * (jSum - sqrt(jSum * jSum - 4.0 * p[136] * jPot * p[137] * parCan + 1e-10)));
+    AUX(197, photo, jRate * (co2Stom - gammaStar) / (4.0 * (co2Stom + 2.0 * gammaStar)));
+    AUX(198, photoResp, photo * gammaStar / co2Stom);
+    AUX(199, hAirBuf, 1.0 / (1.0 + exp(5e-4 * (x[22] - p[157]))));
+    AUX(200, mcAirBuf, p[138] * hAirBuf * (photo - photoResp));
+
+    /* carbohydrate flows (:1103-1194) */
+    const double tCan24 = x[21];
+    AUX(201, gTCan24, 0.047 * tCan24 + 0.06);
+    AUX(202, hTCan24,
+        1.0 / (1.0 + exp(-1.1587 * (tCan24 - p[160]))) * 1.0 / (1.0 + exp(1.3904 * (tCan24 - p[159]))));
+    AUX(203, hTCan, 1.0 / (1.0 + exp(-0.869 * (tCan - p[162]))) * 1.0 / (1.0 + exp(0.5793 * (tCan - p[161]))));
+    const double devA = x[26] / p[163];
+    const double devB = (x[26] - p[163]) / p[163];
+    AUX(204, hTCanSum, 0.5 * (devA + sqrt(devA * devA + 1e-4)) - 0.5 * (devB + sqrt(devB * devB + 1e-4)));
+    AUX(205, hBufOrg, 1.0 / (1.0 + exp(-5e-3 * (x[22] - p[158]))));
+    AUX(206, mcBufLeaf, hBufOrg * hTCan24 * gTCan24 * p[155]);
+    AUX(207, mcBufStem, hBufOrg * hTCan24 * gTCan24 * p[156]);
+    AUX(208, mcBufFruit, hBufOrg * hTCan * hTCan24 * hTCanSum * gTCan24 * p[154]);
+    AUX(209, mcBufAir, p[147] * mcBufLeaf + p[148] * mcBufStem + p[146] * mcBufFruit);
+    const double maint = (1.0 - exp(-p[149] * p[143])) * pow(p[150], 0.1 * (tCan24 - 25.0));
+    AUX(210, mcLeafAir, maint * x[23] * p[152]);
+    AUX(211, mcStemAir, maint * x[24] * p[153]);
+    AUX(212, mcFruitAir, maint * x[25] * p[151]);
+    AUX(213, mcOrgAir, mcLeafAir + mcStemAir + mcFruitAir);
+    AUX(214, mcLeafHar, smooth_har(x[23], p[144], 1e4, 5e4));
+    AUX(215, mcFruitHar, smooth_har(x[25], p[145], 1e4, 5e4));
+    AUX(216, mcAirCan, (p[139] / p[138]) * (mcAirBuf - mcBufAir - mcOrgAir));
+
+    /* CO2 carried by air exchange (:1201-1209) */
+    AUX(217, mcAirTop, air_mc(fScr, x[0], x[1]));
+    AUX(218, mcTopOut, air_mc(fVentRoof, x[1], d[3]));
+    AUX(219, mcAirOut, air_mc(fVentSide + fVentForced, x[0], d[3]));
+
+    /* actuators (:1216-1228) and absent equipment (:1232-1269) */
+    AUX(220, hBoilPipe, u[0] * p[108] / p[46]);
+    ZERO_AUX(221);
+    AUX(222, mcExtAir, u[1] * p[109] / p[46]);
+    for (int i = 223; i <= 232; ++i) ZERO_AUX(i);
+    AUX(233, hLampCool, p[186] * qLampIn);
+    for (int i = 234; i <= 238; ++i) ZERO_AUX(i);
+
+    (void)rhoCovFir; (void)capCan; (void)capCovE; (void)capCovIn; (void)capVpAir; (void)capVpTop;
+    (void)rCanFlr; (void)rPipeSky; (void)rPipeFlr; (void)rPipeCan; (void)rThScrCovIn; (void)rThScrSky;
+    (void)rCovESky; (void)rFirLampFlr; (void)rLampPipe; (void)rFirLampCan; (void)rLampThScr; (void)rLampCovIn;
+    (void)rLampSky; (void)rGroPipeCan; (void)rFlrBlScr; (void)rPipeBlScr; (void)rCanBlScr; (void)rBlScrThScr;
+    (void)rBlScrCovIn; (void)rBlScrSky; (void)rLampBlScr; (void)rFirIntLampFlr; (void)rIntLampPipe;
+    (void)rFirIntLampCan; (void)rIntLampLamp; (void)rIntLampBlScr; (void)rIntLampThScr; (void)rIntLampCovIn;
+    (void)rIntLampSky; (void)rCanCovIn; (void)rCanSky; (void)rCanThScr; (void)rPipeCovIn; (void)rPipeThScr;
+    (void)rFlrCovIn; (void)rFlrSky; (void)rFlrThScr; (void)rLampAir; (void)rIntLampAir; (void)rGlobSunAir;
+    (void)rGlobSunCovE; (void)rNirSunCan; (void)rNirIntLampCan; (void)rNirSunFlr; (void)rNirIntLampFlr;
+    (void)rParSunFlr; (void)rParIntLampFlr; (void)hCanAir; (void)hAirFlr; (void)hAirThScr; (void)hAirBlScr;
+    (void)hAirOut; (void)hAirTop; (void)hThScrTop; (void)hBlScrTop; (void)hTopCovIn; (void)hTopOut;
+    (void)hCovEOut; (void)hPipeAir; (void)hFlrSo1; (void)hSo1So2; (void)hSo2So3; (void)hSo3So4; (void)hSo4So5;
+    (void)hSo5SoOut; (void)hCovInCovE; (void)hLampAir; (void)hGroPipeAir; (void)hIntLampAir; (void)mvAirTop;
+    (void)mvTopOut; (void)mvAirOut; (void)lCanAir; (void)lAirThScr; (void)lAirBlScr; (void)lTopCovIn;
+    (void)mcBufAir; (void)mcOrgAir; (void)mcLeafHar; (void)mcFruitHar; (void)mcAirCan; (void)mcAirTop;
+    (void)mcTopOut; (void)mcAirOut; (void)hBoilPipe; (void)mcExtAir; (void)hLampCool; (void)rS; (void)rCanIntLamp;
+}
+
+/* ------------------------------------------------------------------------------------
+ * ODE(): ode.hpp:6-124   dx_i = (1/C_i) * (sum of gains - sum of losses)
+ * ---------------------------------------------------------------------------------- */
+void gl_oracle_rhs(const double *x, const double *u, const double *d, const double *p, double *dx, double *aux_out)
+{
+    double a[GL_NAUX];
+    gl_oracle_aux(x, u, d, p, a);
+    if (aux_out) memcpy(aux_out, a, sizeof a);
+
+    dx[0] = (1.0 / p[122]) * (a[223] + a[222] + a[224] - a[216] - a[217] - a[219]);              /* :14  */
+    dx[1] = (1.0 / p[123]) * (a[217] - a[218]);                                                  /* :18  */
+    dx[2] = (1.0 / p[112]) * (a[146] + a[225] - a[235] + a[157] + a[226] + a[227] + a[79] - a[147] - a[148] -
+                              a[150] - a[151] - a[229] - a[230] - a[149] + a[165] + a[77] + a[166] + a[167] +
+                              a[78]);                                                            /* :21  */
+    dx[3] = (1.0 / p[120]) * (a[152] + a[151] - a[154] - a[155] + a[153]);                        /* :28  */
+    dx[4] = (1.0 / a[32]) * (a[54] + a[68] + a[92] - a[146] - a[187] - a[84] - a[87] - a[85] - a[86] - a[108] +
+                             a[55] + a[69] + a[101] + a[105] + a[56] + a[70] + a[117]);           /* :31  */
+    dx[5] = (1.0 / a[34]) *
+            (a[154] + a[190] + a[84] + a[93] + a[88] + a[96] - a[164] + a[103] + a[110] + a[121]); /* :37  */
+    dx[6] = (1.0 / a[33]) * (a[80] + a[164] - a[156] - a[98]);                                    /* :42  */
+    dx[7] = (1.0 / p[119]) * (a[148] + a[188] + a[86] + a[95] + a[90] - a[152] - a[96] - a[97] + a[109] +
+                              a[102] + a[120]);                                                  /* :45  */
+    dx[8] = (1.0 / p[113]) * (a[147] + a[74] + a[71] + a[87] + a[91] - a[158] - a[93] - a[94] - a[95] + a[75] +
+                              a[72] + a[99] - a[106] + a[76] + a[73] + a[115]);                   /* :50  */
+    dx[9] = (1.0 / p[110]) * (a[220] + a[231] + a[232] - a[89] - a[88] - a[92] - a[91] - a[90] - a[157] +
+                              a[100] - a[107] + a[238] + a[116]);                                /* :56  */
+    dx[10] = (1.0 / p[114]) * (a[158] - a[159]);                                                 /* :61  */
+    dx[11] = (1.0 / p[115]) * (a[159] - a[160]);
+    dx[12] = (1.0 / p[116]) * (a[160] - a[161]);
+    dx[13] = (1.0 / p[117]) * (a[161] - a[162]);
+    dx[14] = (1.0 / p[118]) * (a[162] - a[163]);                                                 /* :73  */
+    dx[15] = (1.0 / a[35]) *
+             (a[176] + a[177] + a[178] + a[179] - a[181] - a[184] - a[186] - a[180] - a[236] - a[182]); /* :76 */
+    dx[16] = (1.0 / a[36]) * (a[184] - a[183] - a[185]);                                         /* :80  */
+    dx[17] = (1.0 / p[184]) * (a[37] - a[165] - a[104] - a[103] - a[102] - a[100] - a[77] - a[112] - a[75] -
+                               a[72] - a[99] - a[55] - a[69] - a[101] - a[233] + a[118]);        /* :83  */
+    dx[18] = (1.0 / p[191]) * (a[38] - a[167] - a[122] - a[121] - a[120] - a[116] - a[78] - a[119] - a[76] -
+                               a[73] - a[115] - a[56] - a[70] - a[117] - a[118]);                /* :89  */
+    dx[19] = (1.0 / p[171]) * (a[221] - a[105] - a[166]);                                        /* :95  */
+    dx[20] = (1.0 / p[121]) * (a[149] + a[189] + a[108] + a[106] + a[107] - a[153] - a[110] - a[111] - a[109] +
+                               a[112] + a[119]);                                                 /* :98  */
+    dx[21] = (1.0 / 86400.0) * (x[4] - x[21]);                                                   /* :103 */
+    dx[22] = a[200] - a[208] - a[206] - a[207] - a[209];                                         /* :106 */
+    dx[23] = a[206] - a[210] - a[214];                                                           /* :109 */
+    dx[24] = a[207] - a[211];                                                                    /* :112 */
+    dx[25] = a[208] - a[212] - a[215];                                                           /* :115 */
+    dx[26] = (1.0 / 86400.0) * x[4];                                                             /* :118 */
+    dx[27] = 1.0 / 86400.0;                                                                      /* :121 */
+}
+
+/* ------------------------------------------------------------------------------------
+ * Step maps.  Reference semantic (greenlight_model.cpp:59-63): x_next = x(dt) for
+ * x' = ODE(x; u, d, p) with (u, d, p) held constant over [0, dt].
+ * ---------------------------------------------------------------------------------- */
+
+/* Classical RK4 with n_sub equal sub-steps (the scheme the MI355X kernels implement). */
+void gl_oracle_rk4(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                   double *x1)
+{
+    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX];
+    const double h = dt / (double)n_sub;
+    memcpy(x, x0, sizeof x);
+    for (int s = 0; s < n_sub; ++s) {
+        gl_oracle_rhs(x, u, d, p, k1, NULL);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+        gl_oracle_rhs(xs, u, d, p, k2, NULL);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
+        gl_oracle_rhs(xs, u, d, p, k3, NULL);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
+        gl_oracle_rhs(xs, u, d, p, k4, NULL);
+        for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    memcpy(x1, x, sizeof x);
+}
+
+/* Batched RK4 over independent environments (row-major [B,*]; p is [B,np] if p_per_env
+ * else [np]).  Used for parity at batch sizes and as the "port" CPU baseline. */
+void gl_oracle_rk4_batch(const double *x0, const double *u, const double *d, const double *p, int p_per_env,
+                         int B, double dt, int n_sub, double *x1)
+{
+    for (int b = 0; b < B; ++b)
+        gl_oracle_rk4(x0 + (size_t)b * GL_NX, u + (size_t)b * GL_NU, d + (size_t)b * GL_ND,
+                      p + (p_per_env ? (size_t)b * GL_NP : 0), dt, n_sub, x1 + (size_t)b * GL_NX);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Adaptive stiff solver: extrapolated linearly-implicit Euler (Deuflhard's EULSIM idea)
+ * with a finite-difference Jacobian (frozen per macro step) and dense 28x28 LU.
+ *
+ * Role: (i) CPU baseline closest in kind to the reference's CVODES call (variable step,
+ * implicit, rtol = atol as given), (ii) on-box "tight" truth when run at small tolerances.
+ * It is cross-checked against scipy Radau/BDF in tests/golden/make_golden.py.
+ * ---------------------------------------------------------------------------------- */
+static int lu_factor(double *A, int *piv, int n)
+{
+    for (int k = 0; k < n; ++k) {
+        int m = k;
+        double best = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(A[i * n + k]) > best) { best = fabs(A[i * n + k]); m = i; }
+        if (best == 0.0) return -1;
+        piv[k] = m;
+        if (m != k)
+            for (int j = 0; j < n; ++j) { double t = A[k * n + j]; A[k * n + j] = A[m * n + j]; A[m * n + j] = t; }
+        for (int i = k + 1; i < n; ++i) {
+            A[i * n + k] /= A[k * n + k];
+            const double l = A[i * n + k];
+            if (l != 0.0)
+                for (int j = k + 1; j < n; ++j) A[i * n + j] -= l * A[k * n + j];
+        }
+    }
+    return 0;
+}
+
+static void lu_solve(const double *A, const int *piv, int n, double *b)
+{
+    for (int k = 0; k < n; ++k) {
+        if (piv[k] != k) { double t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
+        for (int i = k + 1; i < n; ++i) b[i] -= A[i * n + k] * b[k];
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        for (int j = k + 1; j < n; ++j) b[k] -= A[k * n + j] * b[j];
+        b[k] /= A[k * n + k];
+    }
+}
+
+static void fd_jacobian(const double *x, const double *f0, const double *u, const double *d, const double *p,
+                        double *J, long *nfev)
+{
+    double xp[GL_NX], fp[GL_NX];
+    memcpy(xp, x, sizeof xp);
+    for (int j = 0; j < GL_NX; ++j) {
+        const double dxj = 1.4901161193847656e-8 * fmax(fabs(x[j]), 1.0);
+        xp[j] = x[j] + dxj;
+        gl_oracle_rhs(xp, u, d, p, fp, NULL);
+        ++*nfev;
+        for (int i = 0; i < GL_NX; ++i) J[i * GL_NX + j] = (fp[i] - f0[i]) / dxj;
+        xp[j] = x[j];
+    }
+}
+
+/* One linearly-implicit Euler step of size h from x with Jacobian J: (I - hJ) dx = h f(x). */
+static int lie_step(const double *x, const double *f, const double *J, double h, double *xn)
+{
+    double M[GL_NX * GL_NX], r[GL_NX];
+    int piv[GL_NX];
+    for (int i = 0; i < GL_NX; ++i) {
+        for (int j = 0; j < GL_NX; ++j) M[i * GL_NX + j] = -h * J[i * GL_NX + j];
+        M[i * GL_NX + i] += 1.0;
+        r[i] = h * f[i];
+    }
+    if (lu_factor(M, piv, GL_NX)) return -1;
+    lu_solve(M, piv, GL_NX, r);
+    for (int i = 0; i < GL_NX; ++i) xn[i] = x[i] + r[i];
+    return 0;
+}
+
+/* Column 0 of the tableau: n linearly-implicit Euler sub-steps of h/n with one Jacobian.
+ * Aitken-Neville in powers of h (non-symmetric method): T[k][j] = T[k][j-1] +
+ * (T[k][j-1] - T[k-1][j-1]) / (n_k / n_{k-j} - 1).  Error estimate |T[k][k] - T[k][k-1]|. */
+#define EX_K 8
+long gl_oracle_stiff(const double *x0, const double *u, const double *d, const double *p, double dt, double rtol,
+                     double atol, double *x1, long *n_steps_out)
+{
+    static const int nseq[EX_K] = {1, 2, 3, 4, 6, 8, 12, 16};
+    static double T[EX_K][EX_K][GL_NX];
+    double x[GL_NX], f0[GL_NX], J[GL_NX * GL_NX];
+    long nfev = 0, nsteps = 0;
+    double t = 0.0, h = dt / 16.0;
+    memcpy(x, x0, sizeof x);
+    while (t < dt * (1.0 - 1e-14)) {
+        if (t + h > dt) h = dt - t;
+        gl_oracle_rhs(x, u, d, p, f0, NULL);
+        ++nfev;
+        fd_jacobian(x, f0, u, d, p, J, &nfev);
+        for (;;) {
+            double err = 1e300;
+            int kacc = -1, fail = 0;
+            for (int k = 0; k < EX_K && !fail; ++k) {
+                const int n = nseq[k];
+                const double hs = h / n;
+                double y[GL_NX], fy[GL_NX], yn[GL_NX];
+                memcpy(y, x, sizeof y);
+                memcpy(fy, f0, sizeof fy);
+                for (int s = 0; s < n && !fail; ++s) {
+                    if (s > 0) { gl_oracle_rhs(y, u, d, p, fy, NULL); ++nfev; }
+                    if (lie_step(y, fy, J, hs, yn)) fail = 1;
+                    for (int i = 0; i < GL_NX; ++i)
+                        if (!isfinite(yn[i])) fail = 1;
+                    memcpy(y, yn, sizeof y);
+                }
+                if (fail) break;
+                memcpy(T[k][0], y, sizeof y);
+                for (int j = 1; j <= k; ++j) {
+                    const double ratio = (double)nseq[k] / (double)nseq[k - j];
+                    for (int i = 0; i < GL_NX; ++i)
+                        T[k][j][i] = T[k][j - 1][i] + (T[k][j - 1][i] - T[k - 1][j - 1][i]) / (ratio - 1.0);
+                }
+                if (k >= 2) {
+                    double e = 0.0;
+                    for (int i = 0; i < GL_NX; ++i) {
+                        const double sc = atol + rtol * fmax(fabs(x[i]), fabs(T[k][k][i]));
+                        const double r = (T[k][k][i] - T[k][k - 1][i]) / sc;
+                        e += r * r;
+                    }
+                    err = sqrt(e / GL_NX);
+                    if (err <= 1.0) { kacc = k; break; }
+                }
+            }
+            if (!fail && kacc >= 0) {
+                memcpy(x, T[kacc][kacc], sizeof x);
+                t += h;
+                ++nsteps;
+                h *= (kacc <= 3) ? 2.0 : (kacc <= 5 ? 1.25 : 0.8);
+                break;
+            }
+            h *= 0.5;
+            if (h < 1e-9 * dt) {
+                if (n_steps_out) *n_steps_out = -1;
+                memcpy(x1, x, sizeof x);
+                return -nfev;
+            }
+        }
+    }
+    memcpy(x1, x, sizeof x);
+    if (n_steps_out) *n_steps_out = nsteps;
+    return nfev;
+}

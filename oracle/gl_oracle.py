@@ -1,0 +1,106 @@
+"""ctypes wrapper around oracle/_build/libgl_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (greenlight-gym2_amd/) never does.
+
+Restates (CPU, fp64): aux_states.hpp:5-1271, ode.hpp:6-124, greenlight_model.cpp:46-120.
+Parity status: RHS pinned by tests/golden/rhs_kat.npz; CVODES integrator "parity unpinned"
+(bounded against a tight stiff solve instead) -- see oracle/gl_oracle.c header.
+"""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libgl_oracle.so"
+
+NX, NU, ND, NP, NAUX = 28, 6, 10, 208, 239
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force: bool = False) -> Path:
+    if force or not _SO.exists() or _SO.stat().st_mtime < (_HERE / "gl_oracle.c").stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(str(_SO))
+        L.gl_oracle_aux.argtypes = [_dp] * 5
+        L.gl_oracle_rhs.argtypes = [_dp] * 6
+        L.gl_oracle_rk4.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_stiff.argtypes = [_dp] * 4 + [ctypes.c_double] * 3 + [_dp, ctypes.POINTER(ctypes.c_long)]
+        L.gl_oracle_stiff.restype = ctypes.c_long
+        _lib = L
+    return _lib
+
+
+def _c(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None:
+        assert a.size == n, (a.shape, n)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def rhs(x, u, d, p, want_aux=False):
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    dx = np.empty(NX)
+    aux = np.empty(NAUX)
+    lib().gl_oracle_rhs(_p(x), _p(u), _p(d), _p(p), _p(dx), _p(aux))
+    return (dx, aux) if want_aux else dx
+
+
+def rk4(x, u, d, p, dt=900.0, n_sub=256):
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    lib().gl_oracle_rk4(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
+    return out
+
+
+def rk4_batch(X, U, D, P, dt=900.0, n_sub=256):
+    X, U, D = _c(X), _c(U), _c(D)
+    B = X.shape[0]
+    assert X.shape == (B, NX) and U.shape == (B, NU) and D.shape == (B, ND)
+    P = _c(P)
+    per_env = int(P.ndim == 2)
+    assert P.shape == ((B, NP) if per_env else (NP,))
+    out = np.empty((B, NX))
+    lib().gl_oracle_rk4_batch(_p(X), _p(U), _p(D), _p(P), per_env, B, float(dt), int(n_sub), _p(out))
+    return out
+
+
+def stiff(x, u, d, p, dt=900.0, rtol=1e-6, atol=1e-6):
+    """Adaptive implicit step map (extrapolated linearly-implicit Euler). Returns (x_next, n_rhs_evals)."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    ns = ctypes.c_long(0)
+    nfev = lib().gl_oracle_stiff(_p(x), _p(u), _p(d), _p(p), float(dt), float(rtol), float(atol), _p(out),
+                                 ctypes.byref(ns))
+    if nfev < 0:
+        raise RuntimeError("gl_oracle_stiff: step size underflow")
+    return out, int(nfev)
+
+
+def scaled_rel_err(X, Xref):
+    """max_t,i |X - Xref| / max(|Xref|, 1e-3 * max_t |Xref_i|)   (hard part 3)."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+    Xref = np.atleast_2d(np.asarray(Xref, dtype=np.float64))
+    scale = np.maximum(np.abs(Xref), 1e-3 * np.max(np.abs(Xref), axis=0, keepdims=True))
+    scale = np.where(scale == 0.0, 1.0, scale)
+    return float(np.max(np.abs(X - Xref) / scale))

@@ -1,0 +1,73 @@
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "greenlight-gym2_amd"
+for p in (str(ROOT), str(PKG)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import gl_oracle
+    gl_oracle.build()
+    return gl_oracle
+
+
+@pytest.fixture(scope="session")
+def hostmath():
+    """Host (g++) instantiation of the product's gl_model.hpp -- tests only, see tests/hostmath/hostmath.cpp."""
+    import ctypes
+    d = ROOT / "tests" / "hostmath"
+    so = d / "libhostmath.so"
+    srcs = [d / "hostmath.cpp", PKG / "csrc" / "gl_model.hpp"]
+    if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               f"-I{PKG / 'csrc'}", "-o", str(so), str(d / "hostmath.cpp")])
+    lib = ctypes.CDLL(str(so))
+    dp = ctypes.POINTER(ctypes.c_double)
+
+    def P(a):
+        return a.ctypes.data_as(dp)
+
+    class H:
+        @staticmethod
+        def rhs(x, u, d_, p, f32=False, per_env_crop=False):
+            out = np.empty(28)
+            x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
+            lib.hostmath_rhs(P(x), P(u), P(d_), P(p), int(f32), int(per_env_crop), P(out))
+            return out
+
+        @staticmethod
+        def step(x, u, d_, p, f32=False, per_env_crop=False, dt=900.0, n_sub=256):
+            out = np.empty(28)
+            x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
+            lib.hostmath_step(P(x), P(u), P(d_), P(p), int(f32), int(per_env_crop), ctypes.c_double(dt), int(n_sub),
+                              P(out))
+            return out
+    return H
+
+
+def scaled_err(X, Xref):
+    X, Xref = np.atleast_2d(X), np.atleast_2d(Xref)
+    sc = np.maximum(np.abs(Xref), 1e-3 * np.abs(Xref).max(axis=0, keepdims=True))
+    sc[sc == 0] = 1.0
+    return float(np.max(np.abs(X - Xref) / sc))

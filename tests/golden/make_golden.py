@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures (tests/golden/*.npz).  BUILD CONTAINER ONLY.
+
+Needs /root/reference (read-only mount).  Run as
+    PYTHONPATH=/root/reference:/root/repo PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [names...]
+
+What is reference-anchored and how
+  * RHS known-answer vectors (rhs_kat): the reference's own aux/ODE statement text evaluated
+    in IEEE double by ref_text_eval.py (CasADi itself is absent; nothing is compiled).
+  * params / init_state / weather / reward / noise / rule-based controller: produced by
+    importing the reference's pure-Python modules, which import cleanly here
+    (parameters.py, environments/utils.py, rewards.py, noise.py, baseline.py).
+  * observations.py / tomato_env.py / base_env.py need `gymnasium` (absent) and the pybind
+    module, so they are NOT imported; the env sequencing in env_rulebased_1day is restated
+    by the oracle (oracle/gl_env_oracle.py) and only its importable pieces are reference code.
+  * Step maps (step_tight, rollout_10day): scipy Radau rtol=atol=1e-11 on the C oracle RHS
+    (which rhs_kat pins bit-for-bit to the reference expressions) -- the reference's CVODES is
+    not runnable here, so these bound rather than pin the integrator ("parity unpinned").
+"""
+from __future__ import annotations
+
+import sys
+import time
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+from scipy.integrate import solve_ivp
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+
+import ref_text_eval as R  # noqa: E402
+from oracle import gl_oracle as O  # noqa: E402
+
+from gl_gym.environments.parameters import init_default_params  # noqa: E402  (reference)
+from gl_gym.environments.utils import (  # noqa: E402  (reference)
+    load_weather_data, init_state, co2dens2ppm, vaporPres2rh, satVp, co2ppm2dens, rh2vaporDens,
+    vaporDens2pres, soilTempNl, dailLightSum, computeisDay)
+from gl_gym.environments.noise import parametric_crop_uncertainty  # noqa: E402  (reference)
+from gl_gym.environments.rewards import GreenhouseReward  # noqa: E402  (reference)
+from gl_gym.environments.baseline import RuleBasedController  # noqa: E402  (reference)
+
+WEATHER_DIR = "/root/reference/gl_gym/environments/weather"
+REWARD_PARAMS = dict(fixed_greenhouse_cost=15., fixed_co2_cost=0.015, fixed_lamp_cost=0.07, fixed_screen_cost=2.,
+                     elec_price=0.3, heating_price=0.09, co2_price=0.3, fruit_price=1.6,
+                     pen_weights=[4.e-4, 5.e-3, 7.e-4], pen_lamp=0.1, dmfm=0.065)  # configs/envs/TomatoEnv.yml:56-67
+RULE_BASED = dict(lamps_on=0, lamps_off=18, lamps_day_start=-1, lamps_day_stop=366, lamps_off_sun=400,
+                  lamp_rad_sum_limit=10, temp_setpoint_day=19.5, temp_setpoint_night=16.5, heat_correction=0,
+                  heat_deadzone=5, co2_day=800, vent_heat_Pband=4, rh_max=85, mech_dehumid_Pband=2,
+                  vent_rh_Pband=5, t_vent_off=1, vent_cold_Pband=-1, thScrSpDay=5, thScrSpNight=10, thScrPband=-1,
+                  thScrDeadZone=4, thScrRh=-2, thScrRhPband=2, lampExtraHeat=2, blScrExtraRh=100, rhMax=85,
+                  tHeatBand=-1, co2Band=-100, useBlScr=1)  # configs/agents/rule_based.yml
+
+
+def gym_rng(seed):
+    """gymnasium.utils.seeding.np_random(seed) == Generator(PCG64(SeedSequence(seed)))."""
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+
+def tight_step(x, u, d, p, dt=900.0, tol=1e-11, method="Radau"):
+    s = solve_ivp(lambda t, y: O.rhs(y, u, d, p), (0.0, dt), x, method=method, rtol=tol, atol=tol)
+    assert s.success
+    return s.y[:, -1], s.nfev
+
+
+def weather_10day():
+    return load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2009, 0, 10, 49, 900, 10)
+
+
+# ---------------------------------------------------------------------------------------------
+def g_params():
+    p = init_default_params(208)
+    assert p.dtype == np.float32
+    w = weather_10day()
+    np.savez_compressed(HERE / "params_default.npz", p=p, x0=init_state(w[0]), d0=w[0])
+    print("params_default: p[108]=%r p[110]=%r p[144]=%r" % (p[108], p[110], p[144]))
+
+
+def g_weather():
+    """(a) resampled tensor for the 10-day Bleiswijk case (first 1100 rows);
+    (b) a small raw->resampled loader case (1 day + 1 'day' of horizon) incl. the raw rows."""
+    import pandas as pd
+    w = weather_10day()
+    raw = pd.read_csv(WEATHER_DIR + "/Bleiswijk/GL2009.csv")
+    small = load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2009, 2, 1, 1, 900, 10)
+    # rows the small case touches: N0 = ceil(2*86400/300) = 576, Ns = 288, Np = 289
+    n0, n1 = 576, 576 + 288 + 289
+    cols = ["time", "global radiation", "wind speed", "air temperature", "sky temperature", "RH"]
+    np.savez_compressed(HERE / "weather_bleiswijk2009.npz", w_head=w[:1100], w_shape=np.array(w.shape),
+                        small_raw=raw[cols].values[n0:n1], small_raw_cols=np.array(cols), small_row0=n0,
+                        small_out=small, small_args=np.array([2, 1, 1, 900, 10]))
+    # unit-conversion helper KATs
+    t = np.linspace(-5, 35, 9)
+    rh = np.linspace(20, 100, 9)
+    np.savez_compressed(HERE / "weather_helpers.npz", t=t, rh=rh, satVp=satVp(t), co2ppm2dens=co2ppm2dens(t, 400.0),
+                        rh2vaporDens=rh2vaporDens(t, rh), vaporDens2pres=vaporDens2pres(t, rh2vaporDens(t, rh)),
+                        co2dens2ppm=co2dens2ppm(t, 7e-4), vaporPres2rh=vaporPres2rh(t, 1500.0),
+                        soilTempNl=soilTempNl(np.linspace(0, 3e7, 9)))
+    print("weather:", w.shape, small.shape)
+
+
+def _input_tuples(n, seed):
+    rng = np.random.default_rng(seed)
+    p0 = init_default_params(208)
+    w = weather_10day()
+    x0 = init_state(w[0])
+    # states from a random-walk-control rollout (oracle RK4; they are inputs only)
+    xs, us = [x0], [np.zeros(6)]
+    x, u = x0.copy(), np.zeros(6)
+    for k in range(96):
+        u = np.clip(u + 0.1 * rng.uniform(-1, 1, 6), 0, 1)
+        x = O.rk4(x, u, w[k], p0.astype(np.float64), 900.0, 256)
+        xs.append(x)
+        us.append(u)
+    X, U, D, P = [], [], [], []
+    for i in range(n):
+        k = int(rng.integers(0, len(xs)))
+        x = xs[k] * (1 + 0.02 * rng.standard_normal(28)) if i % 4 else xs[k].copy()
+        if i % 7 == 3:
+            x[8] = x[2] + abs(rng.standard_normal())          # floor warmer than air (if_else branch)
+        if i % 11 == 5:
+            x[23] = 1.1e5 + 5e3 * rng.standard_normal()       # leaf harvest switch active
+            x[25] = 2.99e6 + 2e4 * rng.standard_normal()      # fruit harvest switch active
+        mode = i % 5
+        u = {0: np.zeros(6), 1: np.ones(6), 2: us[k]}.get(mode, rng.uniform(0, 1, 6))
+        d = w[int(rng.integers(0, 1056))].copy()
+        if i % 13 == 7:
+            d[4] = 0.1                                        # wind below the leakage threshold
+        if i < 16 * 8 and i % 8 == 0:
+            p = parametric_crop_uncertainty(p0, 0.2, rng)     # reference noise.py, float32
+        else:
+            p = p0
+        X.append(x); U.append(u); D.append(d); P.append(np.asarray(p, dtype=np.float32))
+    return np.array(X), np.array(U), np.array(D), np.array(P)
+
+
+def g_rhs():
+    X, U, D, P = _input_tuples(256, 20240)
+    DX = np.empty((256, 28)); AUX = np.empty((256, 239))
+    worst = 0.0
+    for i in range(256):
+        DX[i], AUX[i] = R.ref_rhs(X[i], U[i], D[i], P[i].astype(np.float64))
+        dx_o, a_o = O.rhs(X[i], U[i], D[i], P[i].astype(np.float64), want_aux=True)
+        for r, o in ((DX[i], dx_o), (AUX[i], a_o)):
+            e = np.abs(r - o) / np.maximum(np.abs(r), 1e-300)
+            e[r == o] = 0
+            worst = max(worst, e.max())
+    assert np.all(np.isfinite(DX)) and np.all(np.isfinite(AUX))
+    print("rhs_kat: oracle vs reference-text worst rel diff = %.3e" % worst)
+    np.savez_compressed(HERE / "rhs_kat.npz", X=X, U=U, D=D, P=P, DX=DX, AUX=AUX)
+
+
+def g_step():
+    X, U, D, P = _input_tuples(64, 777)
+    XT = np.empty((64, 28)); XB = np.empty((64, 28)); nf = np.empty(64, dtype=np.int64)
+    for i in range(64):
+        p = P[i].astype(np.float64)
+        XT[i], _ = tight_step(X[i], U[i], D[i], p)
+        XB[i], nf[i] = tight_step(X[i], U[i], D[i], p, tol=1e-6, method="BDF")   # CVODES-tolerance proxy
+    print("step_tight: BDF-1e-6 proxy vs tight: %.2e, mean nfev %.0f" % (O.scaled_rel_err(XB, XT), nf.mean()))
+    np.savez_compressed(HERE / "step_tight.npz", X=X, U=U, D=D, P=P, X_tight=XT, X_bdf1e6=XB, nfev_bdf1e6=nf)
+
+
+def g_rollout():
+    """10-day / 961-step rollout through step() semantics with random actions, tight oracle."""
+    p = init_default_params(208).astype(np.float64)
+    w = weather_10day()
+    acts = np.random.default_rng(666).uniform(-1, 1, (961, 6)).astype(np.float32)
+    x = init_state(w[0]); u = np.zeros(6)
+    Xs = [x.copy()]; Us = []
+    t0 = time.time()
+    for k in range(961):
+        u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))   # tomato_env.py:113 (f32 bounds)
+        x, _ = tight_step(x, u, w[k], p)
+        Xs.append(x.copy()); Us.append(np.array(u, dtype=np.float64))
+        if k % 100 == 0:
+            print("  rollout step", k, "%.0fs" % (time.time() - t0), flush=True)
+    np.savez_compressed(HERE / "rollout_10day.npz", actions=acts, weather=w[:1010], X=np.array(Xs), U=np.array(Us))
+    print("rollout_10day done")
+
+
+def g_env():
+    """Config 1: 1-day rule-based rollout.  Reference pieces: controller, reward, weather, params,
+    init_state, obs unit conversions.  Sequencing (tomato_env.py:148-173, 231-270) restated."""
+    from oracle import gl_env_oracle as E
+    p32 = init_default_params(208)
+    env = E.OracleTomatoEnv(weather=load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2009, 0, 1, 49, 900, 10),
+                            season_length=1, start_day=0, p=p32, integrator="radau", seed=666)
+    # attach the REFERENCE reward + controller to the oracle env (duck-typed `env` argument)
+    ref_reward = GreenhouseReward(env, **REWARD_PARAMS)
+    ctrl = RuleBasedController(**RULE_BASED)
+    obs0 = env.reset()
+    rec = dict(u=[], x=[env.x.copy()], obs=[obs0], reward=[], reward_oracle=[], info=[], done=[])
+    done = False
+    while not done:
+        u = ctrl.predict(env.x, env.weather_data[env.timestep], env)
+        obs, r_or, done, info = env.step_raw_control(u, reward_hook=ref_reward)
+        rec["u"].append(np.array(u)); rec["x"].append(env.x.copy()); rec["obs"].append(obs)
+        rec["reward"].append(info["reward_ref"]); rec["reward_oracle"].append(r_or)
+        rec["info"].append([info[k] for k in E.INFO_KEYS]); rec["done"].append(done)
+    print("env_rulebased_1day: %d steps, obs dim %d, sum reward %.4f" % (len(rec["u"]), len(obs0), sum(rec["reward"])))
+    assert np.allclose(rec["reward"], rec["reward_oracle"], rtol=1e-12, atol=1e-14)
+    np.savez_compressed(HERE / "env_rulebased_1day.npz", weather=env.weather_data, p=p32,
+                        info_keys=np.array(E.INFO_KEYS), max_profit=ref_reward.max_profit,
+                        min_profit=ref_reward.min_profit, fixed_costs=ref_reward.fixed_costs,
+                        **{k: np.array(v) for k, v in rec.items()})
+
+
+def g_reward():
+    """Known-answer vectors for the reference GreenhouseReward on random (x, x_prev, u, obs)."""
+    rng = np.random.default_rng(5)
+    p32 = init_default_params(208)
+    n = 64
+    out = dict(x25=[], x25_prev=[], u=[], obs3=[], reward=[], info=[])
+    for i in range(n):
+        env = SimpleNamespace(p=p32, dt=900, x=np.zeros(28), x_prev=np.zeros(28), u=rng.uniform(0, 1, 6),
+                              obs=np.zeros(8), hour_of_day=float(rng.uniform(0, 24)),
+                              constraints_low=np.array([300., 15., 50.]), constraints_high=np.array([1600., 34., 85.]))
+        env.x_prev[25] = 5e4 + 1e4 * rng.standard_normal()
+        env.x[25] = env.x_prev[25] + rng.uniform(-5, 80)
+        env.obs[:3] = [rng.uniform(100, 2500), rng.uniform(5, 40), rng.uniform(30, 100)]
+        rw = GreenhouseReward(env, **REWARD_PARAMS)
+        r = rw.compute_reward()
+        out["x25"].append(env.x[25]); out["x25_prev"].append(env.x_prev[25]); out["u"].append(env.u)
+        out["obs3"].append(env.obs[:3].copy()); out["reward"].append(r)
+        out["info"].append([rw.profit, rw.gains, rw.variable_costs, rw.fixed_costs, rw.co2_costs, rw.heat_costs,
+                            rw.elec_costs, rw.temp_violation, rw.co2_violation, rw.rh_violation, rw.lamp_violation])
+    np.savez_compressed(HERE / "reward_kat.npz", max_profit=rw.max_profit, min_profit=rw.min_profit,
+                        fixed_costs=rw.fixed_costs, **{k: np.array(v) for k, v in out.items()})
+    # reference tests/env_test.py:20-21
+    assert abs(rw.max_profit - 0.328 * 900 * 1e-6 / 0.065 * 1.6) < 1e-7
+    print("reward_kat: max_profit %.9g min_profit %.9g" % (rw.max_profit, rw.min_profit))
+
+
+def g_noise():
+    """RNG order of config 5 (tomato_env.py:237-238 then noise.py:18 per step), scale 0.2, seed 666."""
+    rng = gym_rng(666)
+    year = rng.choice([2009]); day = rng.choice([0])
+    p0 = init_default_params(208)
+    draws = [parametric_crop_uncertainty(p0, 0.2, rng) for _ in range(8)]
+    assert all(d.dtype == np.float32 for d in draws)
+    np.savez_compressed(HERE / "noise_draws.npz", p0=p0, P=np.array(draws), seed=666, scale=0.2, year=year, day=day)
+    print("noise_draws: p[128] first draws", [float(d[128]) for d in draws[:3]])
+
+
+def g_controller():
+    """Known-answer vectors for the reference RuleBasedController.predict."""
+    rng = np.random.default_rng(11)
+    w = weather_10day()
+    x0 = init_state(w[0])
+    ctrl = RuleBasedController(**RULE_BASED)
+    X, D, H, DOY, Uo = [], [], [], [], []
+    for i in range(128):
+        x = x0 * (1 + 0.05 * rng.standard_normal(28))
+        x[2] = rng.uniform(10, 30); x[15] = rng.uniform(0.4, 1.0) * satVp(x[2]); x[0] = rng.uniform(400, 2000)
+        d = w[int(rng.integers(0, 1056))].copy()
+        env = SimpleNamespace(nu=6, hour_of_day=float(rng.uniform(0, 24)), day_of_year=float(rng.uniform(0, 365)))
+        X.append(x); D.append(d); H.append(env.hour_of_day); DOY.append(env.day_of_year)
+        Uo.append(ctrl.predict(x, d, env))
+    np.savez_compressed(HERE / "controller_kat.npz", X=np.array(X), D=np.array(D), hour=np.array(H),
+                        doy=np.array(DOY), U=np.array(Uo))
+    print("controller_kat: u range", np.min(Uo), np.max(Uo))
+
+
+ALL = dict(params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+           controller=g_controller, env=g_env, rollout=g_rollout)
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(ALL)
+    for n in names:
+        t = time.time()
+        ALL[n]()
+        print("[%s] %.1fs" % (n, time.time() - t), flush=True)

@@ -1,0 +1,51 @@
+// TESTS ONLY.  Host (g++) instantiation of greenlight-gym2_amd/csrc/gl_model.hpp so that the exact arithmetic the
+// gfx950 kernels run (tier-1/2/3 split, delta-form RK4, fp32 reformulations) can be unit-tested against the
+// oracle on a machine without a GPU.  The product library (libglgym.so) never links or loads this file.
+#include "gl_model.hpp"
+
+using namespace glm;
+
+template <class T>
+static void run(const double* x, const double* u, const double* d, const double* p, int per_env_crop, double dt,
+                int n_sub, double* out, int rhs_only)
+{
+    ModelConst<T> m;
+    make_model_const<T>(p, m);
+    T x0[NX], uu[NU], dd[7];
+    for (int i = 0; i < NX; ++i) x0[i] = T(x[i]);
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[i]);
+    CropConst<T> crLocal;
+    if (per_env_crop) {
+        T pc[NCROP];
+        for (int i = 0; i < NCROP; ++i) pc[i] = T(p[CROP0 + i]);
+        make_crop_const<T, T>(pc, T(p[39]), T(p[162]), crLocal);
+    }
+    const CropConst<T>& cr = per_env_crop ? crLocal : m.crop;
+    StepCoef<T> s;
+    precompute(uu, dd, m, cr, s);
+    if (rhs_only) {
+        T k[NX];
+        rhs(x0, s, m, cr, k);
+        for (int i = 0; i < NX; ++i) out[i] = (double)k[i];
+        return;
+    }
+    T del[NX];
+    rk4_delta(x0, s, m, cr, T(dt), n_sub, del);
+    for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
+}
+
+extern "C" {
+void hostmath_rhs(const double* x, const double* u, const double* d, const double* p, int f32, int per_env_crop,
+                  double* dx)
+{
+    if (f32) run<float>(x, u, d, p, per_env_crop, 0, 0, dx, 1);
+    else run<double>(x, u, d, p, per_env_crop, 0, 0, dx, 1);
+}
+void hostmath_step(const double* x, const double* u, const double* d, const double* p, int f32, int per_env_crop,
+                   double dt, int n_sub, double* x_next)
+{
+    if (f32) run<float>(x, u, d, p, per_env_crop, dt, n_sub, x_next, 0);
+    else run<double>(x, u, d, p, per_env_crop, dt, n_sub, x_next, 0);
+}
+}

@@ -1,0 +1,101 @@
+// Issue-rate microbenchmarks for gfx950 (what limits a VALU/transcendental-bound, one-lane-per-env kernel).
+// Build: hipcc -O3 --offload-arch=gfx950 tools/microbench.hip -o tools/microbench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 1; } } while (0)
+
+constexpr int ITER = 4096;
+
+template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const float* in, int n)
+{
+    __shared__ float lds[256];
+    float a0 = in[threadIdx.x], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float c = in[64], d = in[65];
+    lds[threadIdx.x] = a0; lds[threadIdx.x + 64] = a1; lds[threadIdx.x + 128] = a2; lds[threadIdx.x + 192] = a3;
+    __syncthreads();
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pc = {c, c}, pd = {d, d};
+    for (int i = 0; i < n; ++i) {
+        if (KIND == 0) {          // 8 independent v_fma_f32
+            a0 = fmaf(a0, c, d); a1 = fmaf(a1, c, d); a2 = fmaf(a2, c, d); a3 = fmaf(a3, c, d);
+            a4 = fmaf(a4, c, d); a5 = fmaf(a5, c, d); a6 = fmaf(a6, c, d); a7 = fmaf(a7, c, d);
+        } else if (KIND == 1) {   // 4 independent v_pk_fma_f32 (8 fmas)
+            p0 = __builtin_elementwise_fma(p0, pc, pd); p1 = __builtin_elementwise_fma(p1, pc, pd);
+            p2 = __builtin_elementwise_fma(p2, pc, pd); p3 = __builtin_elementwise_fma(p3, pc, pd);
+        } else if (KIND == 2) {   // 8 independent v_exp_f32
+            a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
+            a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
+        } else if (KIND == 3) {   // 4 fma + 4 exp interleaved
+            a0 = fmaf(a0, c, d); a1 = __builtin_amdgcn_exp2f(a1); a2 = fmaf(a2, c, d); a3 = __builtin_amdgcn_exp2f(a3);
+            a4 = fmaf(a4, c, d); a5 = __builtin_amdgcn_exp2f(a5); a6 = fmaf(a6, c, d); a7 = __builtin_amdgcn_exp2f(a7);
+        } else if (KIND == 4) {   // 8 x (v_readlane + v_fma) : SGPR-spill pattern
+            a0 = fmaf(a0, __builtin_amdgcn_readlane(a7, 3), d); a1 = fmaf(a1, __builtin_amdgcn_readlane(a0, 5), d);
+            a2 = fmaf(a2, __builtin_amdgcn_readlane(a1, 7), d); a3 = fmaf(a3, __builtin_amdgcn_readlane(a2, 9), d);
+            a4 = fmaf(a4, __builtin_amdgcn_readlane(a3, 11), d); a5 = fmaf(a5, __builtin_amdgcn_readlane(a4, 13), d);
+            a6 = fmaf(a6, __builtin_amdgcn_readlane(a5, 15), d); a7 = fmaf(a7, __builtin_amdgcn_readlane(a6, 17), d);
+        } else if (KIND == 5) {   // 8 x (ds_read broadcast + v_fma): constants staged in LDS
+            const volatile float* l = lds;
+            a0 = fmaf(a0, l[(i + 0) & 255], d); a1 = fmaf(a1, l[(i + 1) & 255], d); a2 = fmaf(a2, l[(i + 2) & 255], d); a3 = fmaf(a3, l[(i + 3) & 255], d);
+            a4 = fmaf(a4, l[(i + 4) & 255], d); a5 = fmaf(a5, l[(i + 5) & 255], d); a6 = fmaf(a6, l[(i + 6) & 255], d); a7 = fmaf(a7, l[(i + 7) & 255], d);
+        } else if (KIND == 6) {   // 8 x (per-lane ds_read + v_fma): coefficients staged in LDS
+            const volatile float* l = lds;
+            const int t = threadIdx.x;
+            a0 = fmaf(a0, l[t], d); a1 = fmaf(a1, l[t + 64], d); a2 = fmaf(a2, l[t + 128], d); a3 = fmaf(a3, l[t + 192], d);
+            a4 = fmaf(a4, l[t], d); a5 = fmaf(a5, l[t + 64], d); a6 = fmaf(a6, l[t + 128], d); a7 = fmaf(a7, l[t + 192], d);
+        } else if (KIND == 7) {   // dependent fma chain (latency)
+            a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d);
+            a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d);
+        } else if (KIND == 8) {   // 8 independent v_rcp_f32
+            a0 = __builtin_amdgcn_rcpf(a0); a1 = __builtin_amdgcn_rcpf(a1); a2 = __builtin_amdgcn_rcpf(a2); a3 = __builtin_amdgcn_rcpf(a3);
+            a4 = __builtin_amdgcn_rcpf(a4); a5 = __builtin_amdgcn_rcpf(a5); a6 = __builtin_amdgcn_rcpf(a6); a7 = __builtin_amdgcn_rcpf(a7);
+        } else if (KIND == 9) {   // 8 x v_mul_f32 with an SGPR operand (uniform constant resident in SGPR)
+            a0 *= c; a1 *= c; a2 *= c; a3 *= c; a4 *= c; a5 *= c; a6 *= c; a7 *= c;
+        }
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+}
+
+template <int KIND> int run(const char* name, float* out, float* in, int ops_per_iter)
+{
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    int n_cu = 256;
+    for (int wps : {1, 2, 4, 8}) {            // waves per SIMD
+        const int blocks = n_cu * 4 * wps;
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, in, 64);
+        CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, in, ITER);
+        CHK(hipEventRecord(e1));
+        CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        const double wave_instr = (double)ITER * ops_per_iter;              // per wave
+        const double ns_per_instr_per_simd = ms * 1e6 / (wave_instr * wps);  // time per wave-instruction on one SIMD
+        printf("%-34s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz)\n", name, wps, ms,
+               ns_per_instr_per_simd, ns_per_instr_per_simd * 2.4);
+    }
+    return 0;
+}
+
+int main()
+{
+    float *out, *in;
+    CHK(hipMalloc(&out, 256 * 4 * 8 * 64 * sizeof(float)));
+    CHK(hipMalloc(&in, 128 * sizeof(float)));
+    std::vector<float> h(128, 0.999f); h[64] = 0.9999f; h[65] = 1e-3f;
+    CHK(hipMemcpy(in, h.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
+    run<0>("v_fma_f32 x8", out, in, 8);
+    run<1>("v_pk_fma_f32 x4 (=8 fma)", out, in, 4);
+    run<2>("v_exp_f32 x8", out, in, 8);
+    run<8>("v_rcp_f32 x8", out, in, 8);
+    run<3>("4 fma + 4 exp", out, in, 8);
+    run<9>("v_mul_f32 sgpr-operand x8", out, in, 8);
+    run<4>("(v_readlane + v_fma) x8", out, in, 16);
+    run<5>("(ds_read bcast + v_fma) x8", out, in, 16);
+    run<6>("(ds_read per-lane + v_fma) x8", out, in, 16);
+    run<7>("dependent v_fma chain x8", out, in, 8);
+    return 0;
+}
