@@ -81,6 +81,12 @@ def load():
         if not LIB_PATH.exists():
             raise GlgymError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime; it must be the first one the process loads, otherwise
+            # torch.cuda.is_available() turns False once /opt/rocm's copy (our DT_NEEDED) is already resident.
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing only; GreenLight.evalF works without it
+            pass
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/glgym.h
