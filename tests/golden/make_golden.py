@@ -187,7 +187,8 @@ def g_env():
     from oracle import gl_env_oracle as E
     p32 = init_default_params(208)
     env = E.OracleTomatoEnv(weather=load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2009, 0, 1, 49, 900, 10),
-                            season_length=1, start_day=0, p=p32, integrator="radau", seed=666)
+                            season_length=1, start_day=0, growth_year=2009, p=p32, integrator="radau", seed=666,
+                            train_years=[2009], train_days=[0])
     # attach the REFERENCE reward + controller to the oracle env (duck-typed `env` argument)
     ref_reward = GreenhouseReward(env, **REWARD_PARAMS)
     ctrl = RuleBasedController(**RULE_BASED)

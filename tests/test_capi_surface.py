@@ -1,0 +1,63 @@
+"""CPU tests: the C-ABI library loads here (no GPU) and exports exactly what include/glgym.h declares."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from gl_gym_amd import _lib
+    if not _lib.LIB_PATH.exists():
+        g.build()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    header = (ROOT / "include" / "glgym.h").read_text()
+    declared = set(re.findall(r"\b(glgym_[a-z_A-Z0-9]+)\s*\(", header))
+    declared -= {"glgym_handle_s"}
+    L = lib.load()
+    assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.glgym_version()
+
+
+def test_struct_layouts_match_header_sizes(lib):
+    # 4-byte ints followed by 8-byte pointers: ctypes applies the same natural alignment as the C compiler
+    assert C.sizeof(lib.RewardCfg) == 16 * 8
+    assert C.sizeof(lib.StepArgs) == 8 + 8 * 5 + 8 + 8 * 3 + 8 + 8 * 4
+    assert C.sizeof(lib.ObsArgs) == 8 + 8 * 3 + 8 + 8 * 3 + 8 + 8
+    assert C.sizeof(lib.ResetArgs) == 8 + 8 * 5 + 8 + 8
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = lib.load()
+    h = C.c_void_p()
+    p = np.zeros(208)
+    rc = L.glgym_create(28, 6, 10, 208, 900.0, p.ctypes.data_as(lib._DP), 0, 256, 0, C.byref(h))
+    assert rc == lib.ENODEV and b"no CPU fallback" in L.glgym_last_error()
+    rc = L.glgym_create(27, 6, 10, 208, 900.0, p.ctypes.data_as(lib._DP), 0, 256, 0, C.byref(h))
+    assert rc == lib.EINVAL
+    from gl_gym_amd import GreenLight, GlgymError
+    with pytest.raises(GlgymError):
+        GreenLight(28, 6, 10, 208, 900.0)
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    with pytest.raises(GlgymError):
+        TomatoVecEnv(4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = ROOT / "greenlight-gym2_amd"
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")):
+        txt = f.read_text()
+        assert "oracle" not in txt.replace("the oracle", "").replace("against the oracle", "") or f.name == "gl_model.hpp", f

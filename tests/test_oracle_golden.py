@@ -1,0 +1,143 @@
+"""CPU tests (no GPU): the oracle against the committed golden fixtures and the reference's own known answers.
+
+Fixture provenance (tests/golden/make_golden.py): rhs_kat = the reference's RHS statement text evaluated in IEEE
+double; params / weather / reward / noise / controller = outputs of the reference's importable Python modules.
+"""
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+
+
+def test_oracle_rhs_bitwise_against_reference_text_vectors(oracle, golden):
+    g = golden("rhs_kat")
+    X, U, D, P, DX, AUX = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["DX"], g["AUX"]
+    assert X.shape == (256, 28) and AUX.shape == (256, 239)
+    for i in range(256):
+        dx, aux = oracle.rhs(X[i], U[i], D[i], P[i], want_aux=True)
+        np.testing.assert_allclose(aux, AUX[i], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(dx, DX[i], rtol=1e-12, atol=1e-300)
+
+
+def test_oracle_rk4_against_tight_step_fixture(oracle, golden):
+    g = golden("step_tight")
+    X, U, D, P, XT, XB = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"], g["X_bdf1e6"]
+    ok = (X[:, 23] < P[:, 144] - 1.2e4) & (X[:, 25] < P[:, 145] - 1.2e4)      # outside the harvest-switch zone
+    assert ok.sum() >= 50
+    got = np.array([oracle.rk4(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
+    assert scaled_err(got[ok], XT[ok]) < 1.3e-5
+    assert scaled_err(XB[ok], XT[ok]) < 2e-5          # the CVODES-tolerance proxy band recorded in the fixture
+    # RK4 below the stability floor (h > 2.785/lambda_max ~ 4.2 s) blows up: BASELINE config 3's "4 sub-steps"
+    bad = oracle.rk4(X[0], U[0], D[0], P[0], 900.0, 4)
+    assert not np.all(np.isfinite(bad))
+
+
+def test_oracle_stiff_solver_matches_radau_fixture(oracle, golden):
+    g = golden("step_tight")
+    X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
+    for i in (0, 3, 10):
+        xs, nfev = oracle.stiff(X[i], U[i], D[i], P[i], 900.0, 1e-10, 1e-10)
+        assert scaled_err(xs, XT[i]) < 1e-7 and nfev > 0
+
+
+def test_oracle_rollout_10day(oracle, golden):
+    g = golden("rollout_10day")
+    acts, w, XR = g["actions"], g["weather"], g["X"]
+    p = golden("params_default")["p"].astype(np.float64)
+    x, u = XR[0].copy(), np.zeros(6)
+    X = [x]
+    for k in range(961):
+        u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))
+        x = oracle.rk4(x, u, w[k], p, 900.0, 256)
+        X.append(x)
+    assert scaled_err(np.array(X), XR) < 5e-6         # fp64 RK4-256 vs Radau 1e-11 over 10 days
+
+
+def test_reward_restatement_against_reference_vectors(golden):
+    from types import SimpleNamespace
+    from oracle.gl_env_oracle import OracleReward, INFO_KEYS
+    g = golden("reward_kat")
+    p = golden("params_default")["p"]
+    # the reference's own known answer (tests/env_test.py:20-21)
+    assert abs(float(g["max_profit"]) - 0.328 * 900 * 1e-6 / 0.065 * 1.6) < 1e-7
+    for i in range(len(g["reward"])):
+        env = SimpleNamespace(p=p, dt=900, x=np.zeros(28), x_prev=np.zeros(28), u=g["u"][i], obs=np.zeros(8))
+        env.x[25], env.x_prev[25] = g["x25"][i], g["x25_prev"][i]
+        env.obs[:3] = g["obs3"][i]
+        rw = OracleReward(env)
+        r = rw.compute_reward()
+        assert abs(r - g["reward"][i]) < 1e-12
+        assert abs(rw.max_profit - g["max_profit"]) < 1e-15 and abs(rw.min_profit - g["min_profit"]) < 1e-15
+        info = rw.info()
+        for j, k in enumerate(INFO_KEYS):
+            assert abs(info[k] - g["info"][i][j]) < 1e-12, k
+    # reference tests/env_test.py:59-65: u = 0 -> zero variable costs
+    env.u = np.zeros(6)
+    rw = OracleReward(env); rw.compute_reward()
+    assert rw.variable_costs == 0
+
+
+def test_noise_restatement_rng_order(golden):
+    from oracle.gl_env_oracle import crop_noise, gym_rng
+    g = golden("noise_draws")
+    rng = gym_rng(int(g["seed"]))
+    rng.choice([2009]); rng.choice([0])                 # reset() consumes two draws first (tomato_env.py:237-238)
+    for k in range(len(g["P"])):
+        p = crop_noise(g["p0"], float(g["scale"]), rng)
+        assert p.dtype == np.float32 and np.array_equal(p, g["P"][k])
+    assert np.array_equal(g["P"][0][:128], g["p0"][:128]) and np.array_equal(g["P"][0][162:], g["p0"][162:])
+
+
+def test_env_oracle_sequencing_against_rulebased_fixture(golden):
+    """Replay the config-1 fixture (reference controller + reference reward on the oracle's sequencing)."""
+    from oracle.gl_env_oracle import OracleTomatoEnv, INFO_KEYS
+    g = golden("env_rulebased_1day")
+    U, X, OBS, R, INFO, DONE = g["u"], g["x"], g["obs"], g["reward"], g["info"], g["done"]
+    assert len(U) == 97 and OBS.shape == (98, 263)      # episode = N + 1 steps (tests/env_test.py:84-92)
+    assert DONE[-1] and not DONE[:-1].any()
+    env = OracleTomatoEnv(weather=g["weather"], p=g["p"], season_length=1, start_day=0, integrator="rk4", n_sub=256,
+                          seed=666, train_years=[2009], train_days=[0])
+    obs = env.reset()
+    np.testing.assert_allclose(obs, OBS[0], rtol=1e-12, atol=1e-12)
+    assert env.timestep == 0 and not env.terminated      # tests/env_test.py:32-41
+    for k in range(97):
+        obs, r, done, info = env.step_raw_control(U[k])
+        assert env.timestep == k + 1                     # tests/env_test.py:57
+        # RK4-256 vs the Radau states of the fixture, one step at a time.  The rule-based controller switches
+        # actuators 0 -> 1 in one step (no delta-u clip), the hardest transients this path sees: 1.2e-5 worst,
+        # inside the reference's own CVODES-tolerance band (BDF 1e-6 proxy: 1.3e-5)
+        assert scaled_err(env.x, X[k + 1]) < 2e-5
+        env.x = X[k + 1].copy(); env.x_prev = X[k + 1].copy()   # re-sync so errors do not compound
+        assert done == bool(DONE[k])
+        assert abs(r - R[k]) < 2e-4
+    assert done
+
+
+def test_params_and_init_state(golden):
+    from gl_gym_amd.parameters import init_default_params
+    from gl_gym_amd.utils import init_state
+    from oracle.gl_env_oracle import init_state as o_init
+    g = golden("params_default")
+    assert np.array_equal(init_default_params(208, "numpy2"), g["p"])
+    p1 = init_default_params(208, "numpy1")
+    assert np.max(np.abs(p1 - g["p"]) / np.maximum(np.abs(g["p"]), 1e-30)) < 1.3e-7        # <= 1 float32 ulp
+    assert np.array_equal(init_state(g["d0"]), g["x0"]) and np.array_equal(o_init(g["d0"]), g["x0"])
+
+
+def test_weather_loader_and_helpers(golden):
+    from gl_gym_amd import utils as U
+    g = golden("weather_bleiswijk2009")
+    raw, cols = g["small_raw"], [str(c) for c in g["small_raw_cols"]]
+    c = {n: raw[:, i] for i, n in enumerate(cols)}
+    out = U.weather_from_raw(c["time"], c["global radiation"], c["air temperature"], c["RH"], c["wind speed"],
+                             c["sky temperature"], 900, 10)
+    assert out.shape == g["small_out"].shape
+    np.testing.assert_allclose(out, g["small_out"], rtol=1e-13, atol=1e-13)
+    h = golden("weather_helpers")
+    t, rh = h["t"], h["rh"]
+    for name, v in dict(satVp=U.satVp(t), co2ppm2dens=U.co2ppm2dens(t, 400.), rh2vaporDens=U.rh2vaporDens(t, rh),
+                        vaporDens2pres=U.vaporDens2pres(t, U.rh2vaporDens(t, rh)), co2dens2ppm=U.co2dens2ppm(t, 7e-4),
+                        vaporPres2rh=U.vaporPres2rh(t, 1500.), soilTempNl=U.soilTempNl(np.linspace(0, 3e7, 9))).items():
+        np.testing.assert_allclose(v, h[name], rtol=1e-14, err_msg=name)
+    w = U.synthetic_weather(n_rows=960)
+    assert w.shape == (960, 10) and np.all(np.isfinite(w)) and w[:, 0].min() == 0 and w[:, 0].max() > 300
