@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,6 +37,20 @@ thread_local std::string g_err;
     } while (0)
 
 constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------------
+// constants of the DEFAULT parameter block, visible to the compiler (see gen_default_const.cpp)
+// ---------------------------------------------------------------------------------------------------
+#include "gl_default_const.inc"
+static_assert(sizeof(ModelConst<float>) == sizeof(kDefaultConstF32_image), "regenerate gl_default_const.inc");
+static_assert(sizeof(ModelConst<double>) == sizeof(kDefaultConstF64_image), "regenerate gl_default_const.inc");
+template <class T> struct DefaultConst;
+template <> struct DefaultConst<float> {
+    static constexpr ModelConst<float> value = __builtin_bit_cast(ModelConst<float>, kDefaultConstF32_bits);
+};
+template <> struct DefaultConst<double> {
+    static constexpr ModelConst<double> value = __builtin_bit_cast(ModelConst<double>, kDefaultConstF64_bits);
+};
 
 // ---------------------------------------------------------------------------------------------------
 // reward constants (rewards.py:96-124,156-231; TomatoEnv.yml:38-67)
@@ -99,9 +114,12 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 // ---------------------------------------------------------------------------------------------------
 // fused env-step
 // ---------------------------------------------------------------------------------------------------
-template <class T, bool PER_ENV_CROP>
-__global__ __launch_bounds__(WAVE) void step_kernel(StepArgsT<T> a, ModelConst<T> m, RewardConst<T> rw)
+// DEFAULT_P = true: the handle's parameter block is bit-identical to the default one, so every tier-1 constant is a
+// compile-time literal (no SGPRs, constant products folded, zero-coefficient exchange terms removed).
+template <class T, bool PER_ENV_CROP, bool DEFAULT_P>
+__global__ __launch_bounds__(WAVE) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
+    const ModelConst<T>& m = DEFAULT_P ? DefaultConst<T>::value : m_arg;
     __shared__ float sh_act[WAVE * NU];
     const int lane = threadIdx.x;
     const int b0 = blockIdx.x * WAVE;
@@ -397,6 +415,7 @@ struct glgym_handle_s {
     RewardConst<double> rd;
     double max_profit = 0, min_profit = 0, fixed_costs = 0;
     float* p0_crop_dev = nullptr;       // shared p[128..161] as f32 (noise kernel input)
+    int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-pointer entry points
     double* scratch = nullptr;
@@ -413,6 +432,8 @@ static void default_reward(glgym_reward_cfg& c)
 
 static int refresh(glgym_handle h)
 {
+    std::memset(&h->mf, 0, sizeof h->mf);
+    std::memset(&h->md, 0, sizeof h->md);
     make_model_const<float>(h->p, h->mf);
     make_model_const<double>(h->p, h->md);
     make_reward_const<float>(h->p, h->dt, h->rcfg, h->rf, &h->max_profit, &h->min_profit, &h->fixed_costs);
@@ -447,6 +468,7 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     h->device = device; h->dtype = dtype; h->n_sub = n_sub; h->dt = dt;
     std::memcpy(h->p, p, sizeof h->p);
     default_reward(h->rcfg);
+    if (const char* e = std::getenv("GLGYM_GENERIC")) h->use_specialised = (e[0] == '1') ? 0 : 1;
     HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
@@ -607,10 +629,14 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     k.reward = (T*)a->reward; k.info = (T*)a->info; k.done = a->done; k.metrics = a->metrics;
     k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]);
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
-    if (a->crop_p)
-        hipLaunchKernelGGL((step_kernel<T, true>), grid, block, 0, st, k, m, rw);
-    else
-        hipLaunchKernelGGL((step_kernel<T, false>), grid, block, 0, st, k, m, rw);
+    const bool def = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+    if (a->crop_p) {
+        if (def) hipLaunchKernelGGL((step_kernel<T, true, true>), grid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel<T, true, false>), grid, block, 0, st, k, m, rw);
+    } else {
+        if (def) hipLaunchKernelGGL((step_kernel<T, false, true>), grid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel<T, false, false>), grid, block, 0, st, k, m, rw);
+    }
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }

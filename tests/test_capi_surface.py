@@ -61,3 +61,16 @@ def test_product_never_imports_the_oracle():
     for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")):
         txt = f.read_text()
         assert "oracle" not in txt.replace("the oracle", "").replace("against the oracle", "") or f.name == "gl_model.hpp", f
+
+
+def test_default_constant_image_is_current(tmp_path):
+    """csrc/gl_default_const.inc (compile-time constants of the specialised kernels) matches the generator."""
+    import subprocess
+    from gl_gym_amd.parameters import init_default_params
+    csrc = ROOT / "greenlight-gym2_amd" / "csrc"
+    exe = tmp_path / "gen"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", f"-I{csrc}", "-o", str(exe),
+                           str(csrc / "gen_default_const.cpp")])
+    txt = " ".join(repr(float(v)) for v in init_default_params())
+    out = subprocess.run([str(exe)], input=txt, capture_output=True, text=True, check=True).stdout
+    assert out == (csrc / "gl_default_const.inc").read_text()

@@ -164,3 +164,36 @@ def test_batch_properties_at_full_size():
     assert torch.equal(env.reward_t[:B], r1[:B][perm])
     assert torch.isfinite(env.x_T).all()
     env.close()
+
+
+def test_generic_kernel_with_non_default_parameters(golden, oracle):
+    """A parameter block that differs from the default one takes the generic step kernel (constants in SGPRs
+    instead of compile-time literals) and exercises the branches the default block folds away: interlights on,
+    FIR-transparent cover, grow-pipe emissivity, roof-only ventilation switched off."""
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"]
+    p = golden("params_default")["p"].astype(np.float64).copy()
+    rng = np.random.default_rng(42)
+    p[:127] *= 1 + 0.05 * rng.uniform(-1, 1, 127)
+    p[70], p[67] = 0.05, 0.12                 # cover transmits some FIR -> sky terms live
+    p[165] = 0.5                              # grow pipes radiate
+    p[194], p[195], p[198] = 0.02, 0.8, 1.5   # interlight geometry present (their power stays 0)
+    p[8] = 1.2                                # etaRoofThr > 1 -> the "else" ventilation branch
+    for dtype, tol in (("float64", 1e-8), ("float32", 5e-5)):
+        env = TomatoVecEnv(64, weather=w, params=p.astype(np.float32), dtype=dtype, n_sub=256, season_length=1,
+                           start_rows=[0, 50], seed=2, auto_reset=False)
+        p32 = env.p.astype(np.float64)
+        env.reset()
+        w_off = env.w_off_t.cpu().numpy()
+        acts = rng.uniform(-1, 1, (64, 6)).astype(np.float32)
+        x = env.x.double().cpu().numpy().copy()
+        for k in range(3):
+            u_prev = env.u.double().cpu().numpy().copy()
+            x_prev = env.x.double().cpu().numpy().copy()
+            env.step(acts)
+            xg = env.x.double().cpu().numpy()
+            for b in range(0, 64, 9):
+                u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
+                ref = oracle.rk4(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256)
+                assert scaled_err(xg[b], ref) < tol, (dtype, k, b)
+        env.close()
