@@ -137,20 +137,13 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     m = env.metrics()
-    # final metric gather: the only collective on this path (RCCL all_gather of 6 floats per rank)
-    mine = torch.tensor([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
-                         m.get("n_done", 0.0), kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        allv = torch.stack(allv).cpu().numpy()
-    else:
-        allv = mine.cpu().numpy()[None]
+    # final metric gather: the only collective on this path (RCCL all_gather of 6 doubles per rank)
+    from gl_gym_amd.dist import gather_metrics, aggregate
+    rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
+                           m.get("n_done", 0.0), kern_ms], device=dev)
     if rank == 0:
-        t_max = float(allv[:, 0].max())
-        total_steps = float(allv[:, 1].sum())
-        value = total_steps / t_max
-        kern_ms_max = float(allv[:, 5].max())
+        agg = aggregate(rows)
+        t_max, value, kern_ms_max = agg["t_max"], agg["value"], agg["kernel_ms_max"]
         per_gpu_kernel_rate = B / (kern_ms_max * 1e-3)
         flops = 4 * args.n_sub * F_RHS
         specials = 4 * args.n_sub * S_RHS
@@ -179,8 +172,8 @@ def main():
                          "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                  "frac": hbm_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                                  "obs_bytes_per_env_step": obs_bytes}},
-            "sum_reward": float(allv[:, 2].sum()), "ode_failures": float(allv[:, 3].sum()),
-            "episodes_finished": float(allv[:, 4].sum()),
+            "sum_reward": agg["sum_reward"], "ode_failures": agg["ode_failures"],
+            "episodes_finished": agg["episodes_finished"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.n_sub)

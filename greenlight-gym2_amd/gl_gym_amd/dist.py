@@ -1,0 +1,37 @@
+"""Multi-GPU plumbing for the env-sharded path: one process per GPU, no data-path collective.
+
+Environments are independent (no cross-env term anywhere in the model), so rank r simply owns a contiguous block of
+envs.  The only communication is the end-of-run metric gather: a single small all_gather (RCCL when the backend is
+"nccl" on ROCm; gloo in the CPU tests)."""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+
+def shard_range(global_batch: int, rank: int, world: int):
+    """Contiguous env-index range [lo, hi) of `rank`; sizes differ by at most one."""
+    base, rem = divmod(int(global_batch), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_metrics(local: Sequence[float], device=None) -> List[List[float]]:
+    """all_gather a short float64 vector from every rank (identity when torch.distributed is not initialised)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor(list(local), dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [mine.cpu().tolist()]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [t.cpu().tolist() for t in out]
+
+
+def aggregate(rows: List[List[float]]) -> Dict[str, float]:
+    """rows[r] = [elapsed_s, env_steps, sum_reward, ode_failures, episodes_done, kernel_ms].
+    Whole-job throughput = all env-steps / the slowest rank's wall time."""
+    t_max = max(r[0] for r in rows)
+    steps = sum(r[1] for r in rows)
+    return {"value": steps / t_max, "t_max": t_max, "env_steps": steps, "sum_reward": sum(r[2] for r in rows),
+            "ode_failures": sum(r[3] for r in rows), "episodes_finished": sum(r[4] for r in rows),
+            "kernel_ms_max": max(r[5] for r in rows)}
