@@ -304,6 +304,23 @@ class TomatoVecEnv:
     def get_obs_names(self):
         return OBS_NAMES_CORE + ["glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed"] * self.Np
 
+    # ---- clocks and the weather row of the coming step, as device tensors (for controllers) ---------
+    def current_weather(self):
+        """[B,10] rows weather[w_off + timestep] -- what the reference passes to RuleBasedController.predict."""
+        idx = (self.w_off_t + self.timestep_t).long().clamp_(0, self.weather_rows - 1)
+        return self.weather_t[idx]
+
+    def hour_of_day(self):
+        return (self.timestep_t.double() * (self.dt / 3600.0)) % 24.0            # tomato_env.py:127-128
+
+    def day_of_year(self):
+        return self.start_day_t.double() + self.timestep_t.double() * ((self.dt / self.c) % 365)   # :126
+
+    def rule_based_controls(self, controller):
+        """u[B,6] of a gl_gym_amd.baseline.RuleBasedController for the current state (experiments/evaluate_baseline.py:22)."""
+        return controller.predict(self.x.double(), self.current_weather().double(), self.hour_of_day(),
+                                  self.day_of_year())
+
     def metrics(self) -> Dict[str, float]:
         if self.metrics_t is None:
             return {}

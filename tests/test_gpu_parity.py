@@ -197,3 +197,75 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
                 ref = oracle.rk4(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256)
                 assert scaled_err(xg[b], ref) < tol, (dtype, k, b)
         env.close()
+
+
+def test_config1_rule_based_day_against_fixture(golden):
+    """BASELINE config 1 (rule-based controls, 1 day, Bleiswijk), batched on the GPU, against the fixture built from
+    the reference's own controller and reward classes.
+
+    The closed loop (rule-based controller at dt = 900 s) is chaotic: the controller bang-bangs and a 1e-7 state
+    perturbation grows to O(1) within ~50 steps for ANY integrator (checked on the CPU oracle with n_sub = 1024), so
+    free-running trajectories are not comparable.  Parity is therefore teacher-forced: at every step the env state
+    is set to the fixture state, then (controls, next state, reward, info, obs) of that one step are compared."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.baseline import RuleBasedController
+    from gl_gym_amd import INFO_KEYS
+    g = golden("env_rulebased_1day")
+    X, R, U, INFO, OBS = g["x"], g["reward"], g["u"], g["info"], g["obs"]
+    keys = [str(k) for k in g["info_keys"]]
+    ctrl = RuleBasedController()
+    for n_sub, tol in ((512, 1e-6), (256, 6e-5)):
+        env = TomatoVecEnv(8, weather=g["weather"], params=g["p"], dtype="float64", n_sub=n_sub, season_length=1,
+                           start_rows=[0], start_days=[0.0], auto_reset=False)
+        obs = env.reset()
+        np.testing.assert_allclose(obs[0], OBS[0], rtol=1e-6, atol=1e-5)
+        worst_x = worst_r = worst_u = 0.0
+        for k in range(97):
+            env.x_T[:, :8] = torch.as_tensor(X[k], device=env.device)[:, None]
+            u = env.rule_based_controls(ctrl)
+            worst_u = max(worst_u, float(np.abs(u[0].cpu().numpy() - U[k]).max()))
+            obs, rew, done, info = env.step_raw_control(U[k][None].repeat(8, 0))
+            worst_x = max(worst_x, scaled_err(env.x[0].cpu().numpy(), X[k + 1]) if k else 0.0)
+            sc = np.maximum(np.abs(X[k + 1]), 1e-3 * np.abs(X).max(axis=0))
+            worst_x = max(worst_x, float(np.max(np.abs(env.x[0].cpu().numpy() - X[k + 1]) / sc)))
+            worst_r = max(worst_r, abs(float(rew[0]) - R[k]))
+            assert bool(done[0]) == (k == 96)                      # episode = N + 1 = 97 steps
+            if n_sub == 512:
+                for j, key in enumerate(keys):
+                    assert abs(info[INFO_KEYS.index(key), 0] - INFO[k][j]) < 5e-6 * max(1.0, abs(INFO[k][j])), key
+                np.testing.assert_allclose(obs[0], OBS[k + 1], rtol=2e-6, atol=2e-5)
+        print(f"config 1, n_sub={n_sub}: one-step state err {worst_x:.2e}, |d reward| {worst_r:.2e}, |d u| {worst_u:.2e}")
+        assert worst_u < 1e-9 and worst_x < tol and worst_r < 20 * tol
+        env.close()
+
+
+def test_crop_noise_kernel_and_config5_step(golden, oracle):
+    """BASELINE config 5: per-env +-10 % crop-parameter noise, re-drawn every step (noise.py).  (1) the device
+    generator reproduces the Philox4x32-10 definition bit for bit; (2) a step with the drawn blocks equals the
+    oracle step fed the same 208-vectors."""
+    from test_controller_and_noise import expected_crop_noise
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"]
+    B = 96
+    env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=256, season_length=1, uncertainty_scale=0.2, seed=4242,
+                       auto_reset=False)
+    env.reset()
+    rng = np.random.default_rng(3)
+    for k in range(2):
+        acts = rng.uniform(-1, 1, (B, 6)).astype(np.float32)
+        x_prev = env.x.double().cpu().numpy().copy(); u_prev = env.u.double().cpu().numpy().copy()
+        env.step(acts)
+        crop = env.crop_T[:, :B].cpu().numpy()
+        exp = expected_crop_noise(env.p[128:162], B, 0.2, 4242, k)
+        # identical Philox stream; the only freedom is fma contraction of p + noise*p on the device (<= 1 ulp)
+        assert np.max(np.abs(crop - exp) / np.abs(exp)) < 1.3e-7
+        assert np.all(np.abs(crop[:13] / env.p[128:141, None] - 1) <= 0.1 + 1e-6)      # +-scale/2
+        xg = env.x.double().cpu().numpy()
+        for b in range(0, B, 11):
+            p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
+            u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
+            ref = oracle.rk4(x_prev[b], u, w[k], p, 900.0, 256)
+            assert scaled_err(xg[b], ref) < 5e-5
+    assert len(np.unique(crop[1])) > B // 2                                            # envs really differ
+    env.close()
