@@ -265,64 +265,82 @@ template <class T> struct ObsArgsT {
     int B, ld;
     const T* x; const T* u; const T* weather; int weather_rows;
     const int* w_off; const int* timestep; const float* start_day;
-    int Np; float* obs; double dt;
+    int Np; float* obs; double doy_inc, hod_inc;     // (dt/86400) mod 365 [days], dt/3600 [h] per env-step
 };
 
+// 8 consecutive env rows = one contiguous span of the row-major output.  Phase 1: 8 x 23 lanes convert the
+// state / current-weather / clock features into LDS (the only divergent, transcendental work).  Phase 2: all 256
+// lanes stream the span: lane t writes elements t, t+256, ... (fully coalesced), taking the 23 leading floats of a
+// row from LDS and the 5*Np forecast floats straight from the L2-resident weather table.
 template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T> a)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int n_waves = gridDim.x * blockDim.x / WAVE;
-    const int dim = 23 + 5 * a.Np;
-    const double kPpm = 8.3144598 / (101325.0 * 44.01e-3);
-    for (int b = wave; b < a.B; b += n_waves) {
-        const int ts = a.timestep[b];
-        const int k = ts > 0 ? ts - 1 : 0;               // weather row / "timestep" the reference shows (pre-increment)
-        const int base = a.w_off[b] + k;
-        float* out = a.obs + (size_t)b * dim;
-        for (int j = lane; j < dim; j += WAVE) {
-            double v;
-            if (j >= 23) {                               // raw forecast rows, no unit conversion (:175-182)
-                const int i = (j - 23) / 5 + 1, c = (j - 23) % 5;
-                int r = base + i;
-                r = r >= a.weather_rows ? a.weather_rows - 1 : r;
-                v = (double)a.weather[(size_t)r * ND + c];
-            } else if (j < 4) {                          // indoor climate (:70-77)
-                const double tAir = (double)a.x[(size_t)2 * a.ld + b];
-                if (j == 0) v = kPpm * (tAir + 273.15) * (double)a.x[b];
-                else if (j == 1) v = tAir;
-                else if (j == 2) {
-                    const double sv = 610.78 * exp(17.2694 * tAir / (tAir + 238.3));
-                    v = fmin(fmax(100.0 * (double)a.x[(size_t)15 * a.ld + b] / sv, 0.0), 100.0);
-                } else v = (double)a.x[(size_t)9 * a.ld + b];
-            } else if (j < 7) {                          // crop (:90-95)
-                const int idx = j == 4 ? 21 : (j == 5 ? 25 : 26);
-                v = (double)a.x[(size_t)idx * a.ld + b];
-            } else if (j < 13) {                         // controls (:108-112)
-                v = (double)a.u[(size_t)(j - 7) * a.ld + b];
-            } else if (j < 18) {                         // current weather (:129-136)
-                int r = base >= a.weather_rows ? a.weather_rows - 1 : base;
-                const T* w = a.weather + (size_t)r * ND;
-                const double tOut = (double)w[1];
-                const int c = j - 13;
-                if (c == 2) {
-                    const double sv = 610.78 * exp(17.2694 * tOut / (tOut + 238.3));
-                    v = fmin(fmax(100.0 * (double)w[2] / sv, 0.0), 100.0);
-                } else if (c == 3) v = kPpm * (tOut + 273.15) * (double)w[3];
-                else v = (double)w[c];
-            } else {                                     // time features (:149-161, tomato_env.py:126-128)
-                const int c = j - 18;
-                if (c == 0) v = (double)k;
-                else {
-                    const double doy = (double)a.start_day[b] + (double)ts * fmod(a.dt / 86400.0, 365.0);
-                    const double hod = fmod((double)ts * (a.dt / 3600.0), 24.0);
-                    const double two_pi = 6.283185307179586;
-                    const double ang = (c <= 2) ? two_pi * doy / 365.0 : two_pi * hod / 24.0;
-                    v = (c == 1 || c == 3) ? sin(ang) : cos(ang);
+    constexpr int ROWS = 8, NCORE = 23;
+    __shared__ float core[ROWS][NCORE + 1];
+    __shared__ int base_s[ROWS];
+    const int tid = threadIdx.x;
+    const int dim = NCORE + 5 * a.Np;
+    const float kPpm = (float)(8.3144598 / (101325.0 * 44.01e-3));
+    for (int rb = blockIdx.x * ROWS; rb < a.B; rb += gridDim.x * ROWS) {
+        const int nrows = min(ROWS, a.B - rb);
+        if (tid < ROWS * NCORE) {
+            const int r = tid / NCORE, j = tid - r * NCORE, b = rb + r;
+            if (r < nrows) {
+                const int ts = a.timestep[b];
+                const int k = ts > 0 ? ts - 1 : 0;       // row / "timestep" the reference shows (pre-increment)
+                int base = a.w_off[b] + k;
+                if (j == 0) base_s[r] = base;
+                base = base >= a.weather_rows ? a.weather_rows - 1 : (base < 0 ? 0 : base);
+                // fp32 hardware transcendentals: the observation block is float32 (observation_space dtype)
+                auto sat_vp = [](float t) { return 610.78f * __builtin_amdgcn_exp2f(1.44269504f * 17.2694f * t * __builtin_amdgcn_rcpf(t + 238.3f)); };
+                float v;
+                if (j < 4) {                                 // indoor climate (observations.py:70-77)
+                    const float tAir = (float)a.x[(size_t)2 * a.ld + b];
+                    if (j == 0) v = kPpm * (tAir + 273.15f) * (float)a.x[b];
+                    else if (j == 1) v = tAir;
+                    else if (j == 2) v = fminf(fmaxf(100.0f * (float)a.x[(size_t)15 * a.ld + b] * __builtin_amdgcn_rcpf(sat_vp(tAir)), 0.0f), 100.0f);
+                    else v = (float)a.x[(size_t)9 * a.ld + b];
+                } else if (j < 7) {                          // crop (:90-95)
+                    const int idx = j == 4 ? 21 : (j == 5 ? 25 : 26);
+                    v = (float)a.x[(size_t)idx * a.ld + b];
+                } else if (j < 13) {                         // controls (:108-112)
+                    v = (float)a.u[(size_t)(j - 7) * a.ld + b];
+                } else if (j < 18) {                         // current weather (:129-136)
+                    const T* w = a.weather + (size_t)base * ND;
+                    const float tOut = (float)w[1];
+                    const int c = j - 13;
+                    if (c == 2) v = fminf(fmaxf(100.0f * (float)w[2] * __builtin_amdgcn_rcpf(sat_vp(tOut)), 0.0f), 100.0f);
+                    else if (c == 3) v = kPpm * (tOut + 273.15f) * (float)w[3];
+                    else v = (float)w[c];
+                } else {                                     // time features (:149-161, tomato_env.py:126-128)
+                    const int c = j - 18;
+                    if (c == 0) v = (float)k;
+                    else {
+                        // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*x)
+                        const double rev = (c <= 2) ? ((double)a.start_day[b] + (double)ts * a.doy_inc) * (1.0 / 365.0)
+                                                    : (double)ts * a.hod_inc * (1.0 / 24.0);
+                        const float fr = (float)(rev - floor(rev));
+                        v = (c == 1 || c == 3) ? __builtin_amdgcn_sinf(fr) : __builtin_amdgcn_cosf(fr);
+                    }
                 }
+                core[r][j] = v;
             }
-            out[j] = (float)v;
         }
+        __syncthreads();
+        const int total = nrows * dim;
+        float* out = a.obs + (size_t)rb * dim;
+        for (int e = tid; e < total; e += 256) {
+            const int r = e / dim, j = e - r * dim;
+            float v;
+            if (j < NCORE) v = core[r][j];
+            else {                                           // raw forecast rows, no unit conversion (:175-182)
+                const int q = j - NCORE, i = q / 5, c = q - i * 5;
+                int row = base_s[r] + i + 1;
+                row = row >= a.weather_rows ? a.weather_rows - 1 : (row < 0 ? 0 : row);
+                v = (float)a.weather[(size_t)row * ND + c];
+            }
+            out[e] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -658,10 +676,9 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     ObsArgsT<T> k;
     k.B = a->B; k.ld = a->ld; k.x = (const T*)a->x; k.u = (const T*)a->u; k.weather = (const T*)a->weather;
     k.weather_rows = a->weather_rows; k.w_off = a->w_off; k.timestep = a->timestep; k.start_day = a->start_day;
-    k.Np = a->Np; k.obs = a->obs; k.dt = h->dt;
-    const int waves_per_block = 256 / WAVE;
-    int blocks = (a->B + waves_per_block - 1) / waves_per_block;
-    if (blocks > 2048) blocks = 2048;           // grid-stride over env rows beyond that
+    k.Np = a->Np; k.obs = a->obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0;
+    int blocks = (a->B + 7) / 8;                 // 8 env rows per block-iteration
+    if (blocks > 4096) blocks = 4096;            // grid-stride beyond that
     hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), 0, st, k);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
