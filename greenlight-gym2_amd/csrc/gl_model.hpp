@@ -52,6 +52,7 @@ template <> struct Math<double> {
     static GL_HD double abs(double v) { return ::fabs(v); }
     static GL_HD double min(double a, double b) { return ::fmin(a, b); }
     static GL_HD double max(double a, double b) { return ::fmax(a, b); }
+    static GL_HD double expm1(double v) { return ::expm1(v); }
 };
 
 template <> struct Math<float> {
@@ -67,6 +68,11 @@ template <> struct Math<float> {
     static GL_HD float powa(float av, float e) { return ::powf(av, e); }
 #endif
     static GL_HD float log(float v) { return ::logf(v); }
+    static GL_HD float expm1(float v)        // |v| < 0.25: Horner series (rel. error < 1e-7), else exp - 1
+    {
+        const float ser = v * (1.0f + v * (0.5f + v * (1.0f / 6.0f + v * (1.0f / 24.0f + v * (1.0f / 120.0f + v * (1.0f / 720.0f))))));
+        return (::fabsf(v) < 0.25f) ? ser : (exp(v) - 1.0f);
+    }
     static GL_HD float abs(float v) { return ::fabsf(v); }
     static GL_HD float min(float a, float b) { return ::fminf(a, b); }
     static GL_HD float max(float a, float b) { return ::fmaxf(a, b); }
@@ -483,7 +489,9 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
 // ---------------------------------------------------------------------------------------------------
 // tier 3: the state-dependent right-hand side.  x[28] -> dx[28]
 // ---------------------------------------------------------------------------------------------------
-template <class T>
+// HARVEST_IN_RHS = true gives the reference's complete right-hand side (test hook).  The integrator uses false:
+// the two harvest terms are advanced by their exact flow instead (harvest_flow below).
+template <class T, bool HARVEST_IN_RHS = true>
 GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
 {
     using M = Math<T>;
@@ -695,9 +703,12 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     const T maint = cr.maintBase * M::exp(cr.q10k * (tCan24 - T(25)));
     const T mcLeafAir = maint * cLeaf * cr.cLeafM, mcStemAir = maint * cStem * cr.cStemM;
     const T mcFruitAir = maint * cFruit * cr.cFruitM;
-    const T kHar = T(2.0 * 4.6052 / 1e4);
-    const T mcLeafHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cLeaf - cr.cLeafMax)));
-    const T mcFruitHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cFruit - cr.cFruitMax)));
+    T mcLeafHar = T(0), mcFruitHar = T(0);
+    if (HARVEST_IN_RHS) {
+        const T kHar = T(2.0 * 4.6052 / 1e4);
+        mcLeafHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cLeaf - cr.cLeafMax)));
+        mcFruitHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cFruit - cr.cFruitMax)));
+    }
     const T mcAirCan = cr.co2PerCh2o * (mcAirBuf - mcBufAir - (mcLeafAir + mcStemAir + mcFruitAir));
 
     // ---- CO2 carried by air (aux_states.hpp:1201-1209)
@@ -748,8 +759,91 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
 }
 
 // ---------------------------------------------------------------------------------------------------
+// rhs_stage: how the integrator calls rhs().  fp32: inlined (4 copies per sub-step, everything in registers).
+// fp64 on the device: ONE out-of-line copy.  The fully inlined fp64 step kernel needs > 512 registers per lane and
+// spills VGPR -> AGPR -> scratch plus SGPRs; hipcc 7.2 -O3 then produced wrong results that changed with the
+// optimisation level (fp32 and the host build were unaffected).  Out of line, each function fits its register budget.
+// ---------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__ inline void rhs_stage_f64(const double* x, const StepCoef<double>* s, const ModelConst<double>* m,
+                                                  const CropConst<double>* cr, double* dx)
+{
+    rhs<double, false>(x, *s, *m, *cr, dx);
+}
+#endif
+template <class T>
+GL_HD void rhs_stage(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
+{
+    rhs<T, false>(x, s, m, cr, dx);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+GL_HD void rhs_stage<double>(const double* x, const StepCoef<double>& s, const ModelConst<double>& m,
+                             const CropConst<double>& cr, double* dx)
+{
+    rhs_stage_f64(x, &s, &m, &cr, dx);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Harvest switch (aux_states.hpp:75-79, 1184-1188):  dc/dt = -M / (1 + exp(-k (c - cMax))),  M = 5e4, k = 2*4.6052/1e4.
+// Its slope reaches k*M/4 = 11.5 1/s when c is within a few thousand mg of cMax -- far outside the stability region of
+// any explicit scheme at h ~ 3.5 s, and reachable whenever cMax moves (per-step parameter noise, config 5).
+// It is a scalar autonomous ODE with a closed-form flow: with z = k (c - cMax),  z - exp(-z) = z0 - exp(-z0) - k M t,
+// i.e. w = exp(-z) solves w + ln w = D (Wright omega).  harvest_flow returns the INCREMENT of c over time t.
+//   * z0 < -40: the rate is below 2e-13 mg/s -> 0.
+//   * z0 < -6 : increment form (Newton on dz, expm1) so that the tiny nominal change is not lost in fp32.
+//   * else    : Newton on w + ln w = D from the asymptotic initial guess (monotone, no overflow).
+// ---------------------------------------------------------------------------------------------------
+template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
+{
+    using M = Math<T>;
+    const T k = T(2.0 * 4.6052 / 1e4), one = T(1);
+    const T z0 = k * (c - cMax);
+    const T a = k * T(5e4) * t;
+#if defined(GL_HARVEST_SELECT)
+    // branch-free form (both regimes evaluated on clamped inputs, result selected)
+    const T zc = M::max(z0, T(-40));
+    const T E0 = M::exp(-zc);
+    T d1 = -a * M::rcp(one + E0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const T em = M::expm1(-d1);
+        d1 -= (d1 - E0 * em + a) * M::rcp(one + E0 * (em + one));
+    }
+    const T D = E0 - zc + a;
+    T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
+    const T d2 = -M::log(w) - zc;
+    const T dz = (z0 < T(-6)) ? d1 : d2;
+    return (z0 < T(-40)) ? T(0) : dz * T(1e4 / (2.0 * 4.6052));
+#else
+    if (z0 < T(-40)) return T(0);
+    const T E0 = M::exp(-z0);
+    T dz;
+    if (z0 < T(-6)) {
+        dz = -a * M::rcp(one + E0);                                   // first Newton step from dz = 0
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const T em = M::expm1(-dz);
+            dz -= (dz - E0 * em + a) * M::rcp(one + E0 * (em + one));
+        }
+    } else {
+        const T D = E0 - z0 + a;                                      // w + ln w = D,  w = exp(-z1)
+        T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
+        dz = -M::log(w) - z0;
+    }
+    return dz * T(1e4 / (2.0 * 4.6052));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // RK4 over one env-step in delta form: the state stays x0 + del, only del is accumulated, so slow,
 // large states (cFruit ~5e4, tCanSum ~3e3) do not lose their small increments in fp32.
+// Each sub-step is Strang-split: exact harvest flow (h/2) -> classical RK4 of the remaining RHS (h) -> harvest (h/2).
 // Returns del (x(dt) - x0); the caller adds it once.
 // ---------------------------------------------------------------------------------------------------
 template <class T>
@@ -761,21 +855,27 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
     for (int it = 0; it < n_sub; ++it) {
+        // Strang splitting: half a step of the exact harvest flow, RK4 on everything else, half a step again
+        del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, h2);
+        del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, h2);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xs[i] = x0[i] + del[i];
-        rhs(xs, s, m, cr, k);
+        rhs_stage(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = x0[i] + (del[i] + h2 * k[i]); }
-        rhs(xs, s, m, cr, k);
+        rhs_stage(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = x0[i] + (del[i] + h2 * k[i]); }
-        rhs(xs, s, m, cr, k);
+        rhs_stage(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = x0[i] + (del[i] + h * k[i]); }
-        rhs(xs, s, m, cr, k);
+        rhs_stage(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) del[i] += h6 * (acc[i] + k[i]);
+        del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, h2);
+        del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, h2);
     }
+    del[NX - 1] = dt * T(1.0 / 86400.0);     // x27 = time [days]: dx = 1/86400 exactly, nothing depends on it
 }
 
 }  // namespace glm

@@ -533,6 +533,54 @@ void gl_oracle_rk4(const double *x0, const double *u, const double *d, const dou
     memcpy(x1, x, sizeof x);
 }
 
+/* The kernels' actual scheme: per sub-step  H(h/2) -> RK4 of (ODE minus the two harvest terms)(h) -> H(h/2), where H is
+ * the exact flow of dc/dt = -5e4 / (1 + exp(-k (c - cMax))) (aux_states.hpp:75-79).  Here the flow is obtained by
+ * bisection on the monotone first integral  G(z) = z - exp(-z)  (independent of the kernels' Newton / Wright-omega). */
+static double harvest_flow_ref(double c, double cmax, double t)
+{
+    const double k = 2.0 * 4.6052 / 1e4, M = 5e4;
+    const double z0 = k * (c - cmax);
+    if (z0 < -40.0) return c;
+    const double target = z0 - exp(-z0) - k * M * t;      /* G(z1) = target, z1 in [z0 - kMt, z0] */
+    double lo = z0 - k * M * t, hi = z0;
+    for (int i = 0; i < 200; ++i) {
+        const double mid = 0.5 * (lo + hi);
+        if (mid - exp(-mid) > target) hi = mid; else lo = mid;
+    }
+    return cmax + 0.5 * (lo + hi) / k;
+}
+
+static void rhs_no_harvest(const double *x, const double *u, const double *d, const double *p, double *dx)
+{
+    double a[GL_NAUX];
+    gl_oracle_rhs(x, u, d, p, dx, a);
+    dx[23] += a[214];
+    dx[25] += a[215];
+}
+
+void gl_oracle_rk4_split(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                         double *x1)
+{
+    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX];
+    const double h = dt / (double)n_sub;
+    memcpy(x, x0, sizeof x);
+    for (int s = 0; s < n_sub; ++s) {
+        x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
+        x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
+        rhs_no_harvest(x, u, d, p, k1);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+        rhs_no_harvest(xs, u, d, p, k2);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
+        rhs_no_harvest(xs, u, d, p, k3);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
+        rhs_no_harvest(xs, u, d, p, k4);
+        for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
+        x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
+    }
+    memcpy(x1, x, sizeof x);
+}
+
 /* Batched RK4 over independent environments (row-major [B,*]; p is [B,np] if p_per_env
  * else [np]).  Used for parity at batch sizes and as the "port" CPU baseline. */
 void gl_oracle_rk4_batch(const double *x0, const double *u, const double *d, const double *p, int p_per_env,

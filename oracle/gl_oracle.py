@@ -40,6 +40,7 @@ def lib():
         L.gl_oracle_aux.argtypes = [_dp] * 5
         L.gl_oracle_rhs.argtypes = [_dp] * 6
         L.gl_oracle_rk4.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk4_split.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_stiff.argtypes = [_dp] * 4 + [ctypes.c_double] * 3 + [_dp, ctypes.POINTER(ctypes.c_long)]
         L.gl_oracle_stiff.restype = ctypes.c_long
@@ -70,6 +71,14 @@ def rk4(x, u, d, p, dt=900.0, n_sub=256):
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
     out = np.empty(NX)
     lib().gl_oracle_rk4(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
+    return out
+
+
+def rk4_split(x, u, d, p, dt=900.0, n_sub=256):
+    """The kernels' scheme: Strang-split exact harvest flow + RK4 of the remaining RHS (see gl_oracle.c)."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    lib().gl_oracle_rk4_split(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
     return out
 
 
