@@ -1,0 +1,76 @@
+"""GPU tests of the env-level drop-in surface: SB3 VecEnv calling convention (auto-reset, terminal_observation,
+get_attr/env_method) and the single-env Gymnasium-style wrapper, following the reference's own tests/env_test.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vecenv_autoreset_and_terminal_observation(golden):
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd import INFO_KEYS
+    w = golden("rollout_10day")["weather"]
+    B = 8
+    env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=224, season_length=0.05, start_rows=[0, 96], seed=1)
+    assert env.N == 4 and env.num_envs == B and env.observation_space.shape == (263,) and env.action_space.shape == (6,)
+    obs = env.reset()
+    assert obs.shape == (B, 263) and obs.dtype == np.float32
+    reset_obs = obs.copy()
+    rng = np.random.default_rng(0)
+    for k in range(5):                                   # episode = N + 1 = 5 steps (tests/env_test.py:77-92)
+        obs, rew, dones, infos = env.step(rng.uniform(-1, 1, (B, 6)).astype(np.float32))
+        assert rew.shape == (B,) and dones.shape == (B,) and len(infos) == B
+        assert all(k_ in infos[0] for k_ in INFO_KEYS) and "controls" in infos[0]
+        assert dones.all() == (k == 4)
+    # SB3 semantics: the returned obs of a finished env is the first obs of the NEXT episode, the last obs of the old
+    # one travels in info["terminal_observation"]
+    for b in range(B):
+        assert "terminal_observation" in infos[b]
+        assert infos[b]["terminal_observation"][18] == 4.0          # "timestep" feature of the terminal step
+        assert obs[b][18] == 0.0 and np.allclose(obs[b][7:13], 0.0)   # fresh episode: timestep 0, controls 0
+        assert np.allclose(obs[b][4:7], reset_obs[b][4:7])          # crop state back at init_state
+    assert env.get_attr("timestep") == [0] * B and env.get_attr("N", [0, 1]) == [4, 4]
+    assert env.env_is_wrapped(object) == [False] * B and len(env.get_obs_names()) == 263
+    assert len(env.get_attr("u")[0]) == 6 and len(env.get_attr("x", 0)[0]) == 28
+    m = env.metrics()
+    assert m["n_done"] == B and m["n_env_steps"] == 5 * B
+    env.close()
+
+
+def test_single_env_wrapper_follows_reference_unit_tests(golden):
+    """tests/env_test.py of the reference, on the B = 1 wrapper: max_profit known answer, reset/step shapes,
+    action = -1 -> zero variable costs, action scaling inside bounds, episode length N + 1."""
+    from gl_gym_amd.tomato_env import TomatoEnv
+    w = golden("rollout_10day")["weather"]
+    env = TomatoEnv(weather=w, dtype="float64", season_length=0.1, start_day=0.0)
+    obs, info = env.reset(seed=42)
+    assert len(obs) == env.observation_space.shape[0] and info == {} and env.timestep == 0 and not env.terminated
+    assert abs(env.vec.max_profit - 0.328 * 900 * 1e-6 / 0.065 * 1.6) < 1e-7           # env_test.py:20-21
+    obs, reward, terminated, truncated, info = env.step(np.ones(6, np.float32) * -1)
+    assert isinstance(reward, float) and env.timestep == 1 and truncated is False      # env_test.py:44-57
+    assert info["variable_costs"] == 0 and np.all(info["controls"] == 0)               # env_test.py:59-65
+    a = env.action_space.sample()
+    u = env.action_to_control(a)
+    assert np.all(u >= env.u_min) and np.all(u <= env.u_max)                            # env_test.py:68-75
+    steps, terminated = 1, False
+    while not terminated and steps < 100:
+        _, _, terminated, _, _ = env.step(env.action_space.sample())
+        steps += 1
+    assert terminated and steps == int(0.1 * 86400 // 900) + 1                          # env_test.py:77-92
+    env.set_crop_state(cBuf=0, cLeaf=0.9e5, cStem=2.5e5, cFruit=2.8e5, tCanSum=3000)
+    assert env.x[25] == 2.8e5
+    env.close()
+
+
+def test_greenlight_drop_in_signature(golden):
+    """gl_gym.environments.models.greenlight_model.GreenLight contract (greenlight_model.cpp:130-136)."""
+    from gl_gym_amd import GreenLight, GlgymError
+    g = golden("params_default")
+    m = GreenLight(28, 6, 10, 208, 900.0)
+    x1 = m.evalF(list(g["x0"]), [0.0] * 6, list(g["d0"]), g["p"])       # lists / float32 array like the reference
+    assert isinstance(x1, list) and len(x1) == 28
+    x2 = m.evalF(x1, np.zeros(6), g["d0"], g["p"].astype(np.float64))   # feed the returned list back in
+    assert np.all(np.isfinite(x2)) and abs(x2[27] - 2 * 900 / 86400) < 1e-12
+    with pytest.raises(GlgymError):
+        GreenLight(27, 6, 10, 208, 900.0)
+    m.close()
