@@ -82,7 +82,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or (os.environ.get("GLGYM_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
@@ -124,14 +125,14 @@ def main():
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     if env.metrics_t is not None:
         env.metrics_t.zero_()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
         one_step(W + i, events[i])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
@@ -179,7 +180,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.n_sub)
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -124,8 +124,11 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 // ---------------------------------------------------------------------------------------------------
 // DEFAULT_P = true: the handle's parameter block is bit-identical to the default one, so every tier-1 constant is a
 // compile-time literal (no SGPRs, constant products folded, zero-coefficient exchange terms removed).
+#ifndef GL_STEP_WAVES_PER_SIMD
+#define GL_STEP_WAVES_PER_SIMD 1
+#endif
 template <class T, bool PER_ENV_CROP, bool DEFAULT_P>
-__global__ __launch_bounds__(WAVE) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
+__global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
     __shared__ float sh_act[WAVE * NU];

@@ -74,3 +74,30 @@ def test_default_constant_image_is_current(tmp_path):
     txt = " ".join(repr(float(v)) for v in init_default_params())
     out = subprocess.run([str(exe)], input=txt, capture_output=True, text=True, check=True).stdout
     assert out == (csrc / "gl_default_const.inc").read_text()
+
+
+def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
+    """ISA regression: the hot fp32 kernels must stay MFMA-free, scratch-free and free of SGPR-spill
+    reloads (v_readlane) in the specialised variant.  hipcc cross-compiles here without a GPU."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("hipcc not available")
+    csrc = ROOT / "greenlight-gym2_amd" / "csrc"
+    out = tmp_path / "glgym.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17",
+                           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(csrc / "glgym.hip")])
+    s = out.read_text()
+    assert "v_mfma" not in s
+    for variant, allow_readlane in (("step_kernelIfLb0ELb1", False), ("step_kernelIfLb0ELb0", True),
+                                    ("step_kernelIfLb1ELb1", False)):
+        m = re.search(r"^(_ZN\S*" + variant + r"\S*):", s, flags=re.M)
+        body = s[m.start():]
+        body = body[:body.index(".Lfunc_end")]
+        assert "scratch_" not in body and "buffer_store_dword" not in body, variant
+        desc = s[s.index(".amdhsa_kernel " + m.group(1)):]
+        desc = desc[:desc.index(".end_amdhsa_kernel")]
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", desc), variant
+        if not allow_readlane:
+            assert body.count("v_readlane_b32") < 16, (variant, body.count("v_readlane_b32"))
