@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uncertainty", type=float, default=0.0, help="crop-parameter noise scale (config 5: 0.2)")
+    ap.add_argument("--vecnorm", action="store_true", help="also run the on-device VecNormalize (obs + reward) each step")
     args = ap.parse_args()
 
     import numpy as np
@@ -98,6 +99,10 @@ def main():
     env = TomatoVecEnv(B, weather=weather, dtype="float64" if args.dtype == "f64" else "float32", n_sub=args.n_sub,
                        season_length=60, pred_horizon=0.5, device=f"cuda:{local}", seed=666 + rank,
                        start_rows=starts, uncertainty_scale=args.uncertainty, auto_reset=True)
+    vn = None
+    if args.vecnorm:
+        from gl_gym_amd.vec_normalize import VecNormalizeGPU
+        vn = VecNormalizeGPU(env, clip_obs=10.0, gamma=0.9631)
     env.reset_tensor()
     env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=dev,
                                         generator=torch.Generator(device=dev).manual_seed(1234 + rank)).to(env.tdtype))
@@ -119,6 +124,8 @@ def main():
         env.w_off_t.copy_(torch.where(m, rows, env.w_off_t))
         env.start_day_t.copy_(torch.where(m, days, env.start_day_t))
         env._launch_reset(env.done_t)
+        if vn is not None:
+            vn._call(env.obs_t, env.reward_t, env.done_t)
 
     for i in range(W):
         one_step(i)
@@ -161,6 +168,7 @@ def main():
                                    "weather year (KNMI Amsterdam files absent), random actions U(-1,1)",
                        "batch_per_gpu": B, "global_batch": B * world, "n_sub": args.n_sub, "dt_s": 900,
                        "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True,
+                       "vecnormalize": bool(args.vecnorm),
                        "uncertainty_scale": args.uncertainty, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE, n_sub=256 run"},
             "roofline": {"bound": "valu", "kernel": "step_kernel", "achieved": ach_tflops, "peak": PEAK_VALU_TFLOPS,

@@ -426,6 +426,113 @@ __global__ void crop_noise_kernel(T* crop_p, int B, int ld, const float* p0, flo
     for (int i = 0; i < NCROP; ++i) crop_p[(size_t)i * ld + b] = T(pn[i]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// VecNormalize on the device (HBM-bound: one read pass for the moments, one read + write pass to normalise)
+// ---------------------------------------------------------------------------------------------------
+// pass 1: per-feature sum and sum of squares over the batch.  Thread t owns columns t, t+256, ... (consecutive lanes ->
+// consecutive addresses of a row), walks a strip of rows in registers (fp64), then one atomic pair per column.
+__global__ __launch_bounds__(1024) void vecnorm_moments_kernel(const float* __restrict__ obs, int B, int dim,
+                                                               double* __restrict__ acc)
+{
+    const int rows_per_block = (B + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {       // blockDim >= dim in practice: one column per thread
+        double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {                            // two independent chains keep loads in flight
+            const double v0 = (double)obs[(size_t)r * dim + c], v1 = (double)obs[(size_t)(r + 1) * dim + c];
+            s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+        }
+        if (r < r1) { const double v = (double)obs[(size_t)r * dim + c]; s0 += v; q0 += v * v; }
+        if (r1 > r0) { atomicAdd(acc + c, s0 + s1); atomicAdd(acc + dim + c, q0 + q1); }
+    }
+}
+
+// discounted returns + their batch moments (wave reduction, one atomic pair per wave)
+template <class T>
+__global__ __launch_bounds__(256) void vecnorm_returns_kernel(const T* __restrict__ reward, double* __restrict__ returns,
+                                                              int B, double gamma, double* __restrict__ acc2)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0;
+    if (b < B) { v = returns[b] * gamma + (double)reward[b]; returns[b] = v; }
+    double s = v, q = v * v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, WAVE); q += __shfl_xor(q, o, WAVE); }
+    __shared__ double part[2][4];
+    const int wv = threadIdx.x / WAVE;
+    if ((threadIdx.x & (WAVE - 1)) == 0) { part[0][wv] = s; part[1][wv] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                   // one atomic pair per 256-env block
+        atomicAdd(acc2, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(acc2 + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+
+// RunningMeanStd.update_from_moments for every feature (and for the scalar return statistics)
+__global__ void vecnorm_merge_kernel(double* mean, double* var, double* count, const double* acc, int dim, int B,
+                                     double* ret_stats, const double* acc2, int do_obs, int do_ret)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const double n = (double)B;
+    if (do_obs && c < dim) {
+        const double bm = acc[c] / n, bv = fmax(acc[dim + c] / n - bm * bm, 0.0);
+        const double cnt = *count, tot = cnt + n, delta = bm - mean[c];
+        const double m2 = var[c] * cnt + bv * n + delta * delta * cnt * n / tot;
+        mean[c] += delta * n / tot;
+        var[c] = m2 / tot;
+    }
+    if (do_ret && c == 0) {
+        const double bm = acc2[0] / n, bv = fmax(acc2[1] / n - bm * bm, 0.0);
+        const double cnt = ret_stats[2], tot = cnt + n, delta = bm - ret_stats[0];
+        const double m2 = ret_stats[1] * cnt + bv * n + delta * delta * cnt * n / tot;
+        ret_stats[0] += delta * n / tot;
+        ret_stats[1] = m2 / tot;
+        ret_stats[2] = tot;
+    }
+}
+
+__global__ void vecnorm_count_kernel(double* count, int B) { *count += (double)B; }
+
+// per-column 1/sqrt(var + eps), once per call (fp64), so that pass 2 is two fp64 ops per element
+__global__ void vecnorm_scale_kernel(const double* __restrict__ var, double eps, int dim, double* __restrict__ scale)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < dim) scale[c] = 1.0 / sqrt(var[c] + eps);
+}
+
+// pass 2: clip((x - mean) * scale).  The subtraction stays in fp64 like SB3 (float32 obs - float64 mean): for
+// near-constant features a ~1e-8 difference is divided by sqrt(eps).  Lane i handles element i (coalesced).
+__global__ __launch_bounds__(1024) void vecnorm_apply_kernel(const float* __restrict__ obs, float* __restrict__ out,
+                                                            int B, int dim, const double* __restrict__ mean,
+                                                            const double* __restrict__ scale, float clip)
+{
+    const int rows_per_block = (B + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        const double mu = mean[c], sc = scale[c];
+        for (int r = r0; r < r1; ++r) {
+            const size_t i = (size_t)r * dim + c;
+            const float v = (float)(((double)obs[i] - mu) * sc);
+            out[i] = fminf(fmaxf(v, -clip), clip);
+        }
+    }
+}
+
+template <class T>
+__global__ void vecnorm_reward_kernel(const T* __restrict__ reward, float* __restrict__ out, double* __restrict__ returns,
+                                      const unsigned char* __restrict__ done, int B, const double* ret_stats, double eps,
+                                      float clip, int norm_reward)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float r = (float)reward[b];
+    if (norm_reward) r = fminf(fmaxf((float)((double)reward[b] / sqrt(ret_stats[1] + eps)), -clip), clip);
+    out[b] = r;
+    if (done && done[b]) returns[b] = 0.0;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -693,6 +800,66 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     int blocks = (a->B + 7) / 8;                 // 8 env rows per block-iteration
     if (blocks > 4096) blocks = 4096;            // grid-stride beyond that
     hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), 0, st, k);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+
+extern "C" int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* stream)
+{
+    if (!h || !a || a->B < 1 || a->dim < 1 || !a->obs || !a->obs_out || !a->obs_mean || !a->obs_var || !a->obs_count ||
+        !a->workspace || (a->reward && (!a->reward_out || !a->ret_stats || !a->returns))) {
+        g_err = "glgym_vecnorm: bad arguments";
+        return GLGYM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int B = a->B, dim = a->dim;
+    double* acc = a->workspace;
+    double* acc2 = a->workspace + 2 * dim;
+    HIPCHK(hipMemsetAsync(a->workspace, 0, (size_t)(2 * dim + 2) * sizeof(double), st));
+    const int do_obs = a->training && a->norm_obs, do_ret = a->training && a->reward != nullptr;
+    int col_threads = (dim + WAVE - 1) / WAVE * WAVE;       // one thread per observation column
+    if (col_threads > 1024) col_threads = 1024;
+    if (do_obs) {
+        int blocks = (B + 63) / 64;                 // 64-row strips: <= 1024 blocks x 2*dim fp64 atomics
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(vecnorm_moments_kernel, dim3(blocks), dim3(col_threads), 0, st, a->obs, B, dim, acc);
+    }
+    if (do_ret) {
+        if (h->dtype == GLGYM_F32)
+            hipLaunchKernelGGL((vecnorm_returns_kernel<float>), dim3((B + 255) / 256), dim3(256), 0, st,
+                               (const float*)a->reward, a->returns, B, a->gamma, acc2);
+        else
+            hipLaunchKernelGGL((vecnorm_returns_kernel<double>), dim3((B + 255) / 256), dim3(256), 0, st,
+                               (const double*)a->reward, a->returns, B, a->gamma, acc2);
+    }
+    if (do_obs || do_ret) {
+        hipLaunchKernelGGL(vecnorm_merge_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, a->obs_mean, a->obs_var,
+                           a->obs_count, acc, dim, B, a->ret_stats, acc2, do_obs, do_ret);
+        if (do_obs) hipLaunchKernelGGL(vecnorm_count_kernel, dim3(1), dim3(1), 0, st, a->obs_count, B);
+    }
+    const size_t total = (size_t)B * dim;
+    if (a->norm_obs) {
+        double* scale = acc;                       // the moment accumulators are dead after the merge
+        hipLaunchKernelGGL(vecnorm_scale_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, a->obs_var, a->epsilon, dim,
+                           scale);
+        int blocks = (B + 15) / 16;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(vecnorm_apply_kernel, dim3(blocks), dim3(col_threads), 0, st, a->obs, a->obs_out, B, dim,
+                           a->obs_mean, scale, a->clip_obs);
+    } else if (a->obs_out != a->obs) {
+        HIPCHK(hipMemcpyAsync(a->obs_out, a->obs, total * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (a->reward) {
+        if (h->dtype == GLGYM_F32)
+            hipLaunchKernelGGL((vecnorm_reward_kernel<float>), dim3((B + 255) / 256), dim3(256), 0, st,
+                               (const float*)a->reward, a->reward_out, a->returns, a->done, B, a->ret_stats, a->epsilon,
+                               a->clip_reward, a->norm_reward);
+        else
+            hipLaunchKernelGGL((vecnorm_reward_kernel<double>), dim3((B + 255) / 256), dim3(256), 0, st,
+                               (const double*)a->reward, a->reward_out, a->returns, a->done, B, a->ret_stats, a->epsilon,
+                               a->clip_reward, a->norm_reward);
+    }
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }

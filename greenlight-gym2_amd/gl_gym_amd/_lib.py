@@ -48,6 +48,15 @@ class ResetArgs(C.Structure):
                 ("timestep", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p)]
 
 
+class VecNormArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("dim", C.c_int32), ("obs", C.c_void_p), ("obs_out", C.c_void_p),
+                ("reward", C.c_void_p), ("reward_out", C.c_void_p), ("done", C.c_void_p), ("obs_mean", C.c_void_p),
+                ("obs_var", C.c_void_p), ("obs_count", C.c_void_p), ("ret_stats", C.c_void_p), ("returns", C.c_void_p),
+                ("workspace", C.c_void_p), ("gamma", C.c_double), ("epsilon", C.c_double), ("clip_obs", C.c_float),
+                ("clip_reward", C.c_float), ("training", C.c_int32), ("norm_obs", C.c_int32),
+                ("norm_reward", C.c_int32)]
+
+
 # every symbol include/glgym.h declares, with its prototype
 _DP = C.POINTER(C.c_double)
 PROTOTYPES = {
@@ -67,6 +76,7 @@ PROTOTYPES = {
     "glgym_reset": (C.c_int, [C.c_void_p, C.POINTER(ResetArgs), C.c_void_p]),
     "glgym_crop_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                                    C.c_void_p]),
+    "glgym_vecnorm": (C.c_int, [C.c_void_p, C.POINTER(VecNormArgs), C.c_void_p]),
     "glgym_timer_start": (C.c_int, [C.c_void_p, C.c_void_p]),
     "glgym_timer_stop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
 }

@@ -1,0 +1,122 @@
+"""On-device VecNormalize around a ``TomatoVecEnv``.
+
+Same statistics and call surface as ``stable_baselines3.common.vec_env.VecNormalize`` as the reference configures it
+(gl_gym/RL/experiment_manager.py:142-147: norm_obs, norm_reward, clip_obs=10, gamma; eval envs: training=False,
+norm_reward=False, gl_gym/RL/utils.py:62-66) -- but the running moments, the normalisation and the clipping run in HIP
+kernels on the observation block that already lives in HBM (libglgym.so: glgym_vecnorm), so a device-resident RL loop
+never copies the 263-float observations to the host.  ``obs_rms`` / ``ret_rms`` expose mean / var / count like SB3's
+RunningMeanStd (used by gl_gym/common/callbacks.py:295-296), ``unnormalize_obs`` serves gl_gym/common/evaluation.py:102.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib as L
+
+
+class VecNormalizeGPU:
+    def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
+                 gamma=0.99, epsilon=1e-8):
+        self.venv, self.torch = venv, venv.torch
+        t, dev = venv.torch, venv.device
+        self.num_envs, self.obs_dim = venv.num_envs, venv.obs_dim
+        self.observation_space, self.action_space = venv.observation_space, venv.action_space
+        self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
+        self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
+        f64 = dict(dtype=t.float64, device=dev)
+        self.obs_mean, self.obs_var = t.zeros(self.obs_dim, **f64), t.ones(self.obs_dim, **f64)
+        self.obs_count = t.full((1,), 1e-4, **f64)
+        self.ret_stats = t.tensor([0.0, 1.0, 1e-4], **f64)
+        self.returns = t.zeros(self.num_envs, **f64)
+        self._ws = t.zeros(2 * self.obs_dim + 2, **f64)
+        self.obs_norm_t = t.zeros(self.num_envs, self.obs_dim, dtype=t.float32, device=dev)
+        self.reward_norm_t = t.zeros(self.num_envs, dtype=t.float32, device=dev)
+        self.old_obs = self.old_reward = None
+
+    # ---- SB3-style views of the statistics -------------------------------------------------------
+    @property
+    def obs_rms(self):
+        return SimpleNamespace(mean=self.obs_mean.cpu().numpy(), var=self.obs_var.cpu().numpy(),
+                               count=float(self.obs_count))
+
+    @property
+    def ret_rms(self):
+        s = self.ret_stats.cpu().numpy()
+        return SimpleNamespace(mean=float(s[0]), var=float(s[1]), count=float(s[2]))
+
+    def _call(self, obs_t, reward_t, done_t):
+        v = self.venv
+        a = L.VecNormArgs(self.num_envs, self.obs_dim, obs_t.data_ptr(), self.obs_norm_t.data_ptr(),
+                          reward_t.data_ptr() if reward_t is not None else None, self.reward_norm_t.data_ptr(),
+                          done_t.data_ptr() if done_t is not None else None, self.obs_mean.data_ptr(),
+                          self.obs_var.data_ptr(), self.obs_count.data_ptr(), self.ret_stats.data_ptr(),
+                          self.returns.data_ptr(), self._ws.data_ptr(), self.gamma, self.epsilon, self.clip_obs,
+                          self.clip_reward, int(self.training), int(self.norm_obs), int(self.norm_reward))
+        L.check(v._lib.glgym_vecnorm(v._h, C.byref(a), v._stream()), "glgym_vecnorm")
+
+    # ---- tensor interface ----------------------------------------------------------------------------
+    def reset_tensor(self, seed=None):
+        obs = self.venv.reset_tensor(seed)
+        self.returns.zero_()
+        self._call(obs, None, None)
+        return self.obs_norm_t
+
+    def step_tensor(self, actions_t=None, controls_t=None):
+        obs, rew, done, info = self.venv.step_tensor(actions_t, controls_t)
+        self._call(obs, self.venv.reward_t, done)
+        return self.obs_norm_t, self.reward_norm_t, done, info
+
+    # ---- VecEnv calling convention ------------------------------------------------------------------------
+    def reset(self):
+        return self.reset_tensor().cpu().numpy()
+
+    def step(self, actions):
+        t = self.torch
+        obs_n, rew_n, done, info_T = self.step_tensor(t.as_tensor(np.asarray(actions, dtype=np.float32),
+                                                                  device=self.venv.device))
+        dones = done.cpu().numpy().astype(bool)
+        info = info_T.double().cpu().numpy()
+        infos = [{k: float(info[i, b]) for i, k in enumerate(L.INFO_KEYS)} for b in range(self.num_envs)]
+        if self.venv.auto_reset and dones.any():
+            term = self.normalize_obs(self.venv.term_obs_t.cpu().numpy())
+            for b in np.nonzero(dones)[0]:
+                infos[b]["terminal_observation"] = term[b]
+        return obs_n.cpu().numpy(), rew_n.cpu().numpy(), dones, infos
+
+    def normalize_obs(self, obs):
+        if not self.norm_obs:
+            return obs
+        r = self.obs_rms
+        return np.clip((obs - r.mean) / np.sqrt(r.var + self.epsilon), -self.clip_obs, self.clip_obs).astype(np.float32)
+
+    def unnormalize_obs(self, obs):
+        if not self.norm_obs:
+            return obs
+        r = self.obs_rms
+        return obs * np.sqrt(r.var + self.epsilon) + r.mean
+
+    def get_original_obs(self):
+        return self.venv.obs_t.cpu().numpy()
+
+    def get_original_reward(self):
+        return self.venv.reward_t[:self.num_envs].float().cpu().numpy()
+
+    def save(self, path):
+        with open(path, "wb") as f:
+            pickle.dump(dict(obs_mean=self.obs_mean.cpu(), obs_var=self.obs_var.cpu(), obs_count=self.obs_count.cpu(),
+                             ret_stats=self.ret_stats.cpu(), clip_obs=self.clip_obs, clip_reward=self.clip_reward,
+                             gamma=self.gamma, epsilon=self.epsilon, norm_obs=self.norm_obs,
+                             norm_reward=self.norm_reward), f)
+
+    def load_stats(self, path):
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        for k in ("obs_mean", "obs_var", "obs_count", "ret_stats"):
+            getattr(self, k).copy_(d[k])
+
+    def __getattr__(self, name):          # get_attr / env_method / metrics / close ... fall through to the wrapped env
+        return getattr(self.venv, name)

@@ -137,6 +137,32 @@ int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream);
 int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, uint64_t seed, uint64_t draw_index,
                      void* stream);
 
+/* ---- on-device VecNormalize ---------------------------------------------------------------------
+ * Replaces stable_baselines3.common.vec_env.VecNormalize (3rd party, pinned ==2.6.0 in the reference's requirements.txt)
+ * as the reference configures it: norm_obs, norm_reward, clip_obs = 10, gamma (gl_gym/RL/experiment_manager.py:142-147,
+ * gl_gym/RL/utils.py:62-66).  Algorithm: batch mean/var -> RunningMeanStd.update_from_moments -> clip((x-mean)/sqrt(var+eps));
+ * rewards: returns = returns*gamma + r; ret_rms.update(returns); clip(r/sqrt(ret_var+eps)); returns[done] = 0.
+ * All statistics are caller-owned device doubles so they can be saved / restored like VecNormalize.save(). */
+typedef struct {
+    int32_t B, dim;
+    const float* obs;          /* [B][dim] raw observations (glgym_obs output) */
+    float* obs_out;            /* [B][dim] normalised + clipped (may alias obs) */
+    const void* reward;        /* [B] T raw rewards, or NULL (reset: observations only) */
+    float* reward_out;         /* [B] f32 normalised + clipped */
+    const uint8_t* done;       /* [B] or NULL */
+    double* obs_mean;          /* [dim] running mean   (init 0) */
+    double* obs_var;           /* [dim] running var    (init 1) */
+    double* obs_count;         /* [1]   running count  (init 1e-4) */
+    double* ret_stats;         /* [3]   mean, var, count of the discounted returns (init 0, 1, 1e-4) */
+    double* returns;           /* [B]   discounted return accumulators (init 0) */
+    double* workspace;         /* [2*dim + 2] scratch, zeroed by the call */
+    double gamma, epsilon;     /* 0.99, 1e-8 in SB3 */
+    float clip_obs, clip_reward;
+    int32_t training, norm_obs, norm_reward;
+} glgym_vecnorm_args;
+
+int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* stream);
+
 /* Kernel timing on the stream the kernels are launched on (bench.py's roofline leg). */
 int glgym_timer_start(glgym_handle h, void* stream);
 int glgym_timer_stop(glgym_handle h, void* stream, float* elapsed_ms);   /* synchronises the stop event */

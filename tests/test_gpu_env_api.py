@@ -74,3 +74,44 @@ def test_greenlight_drop_in_signature(golden):
     with pytest.raises(GlgymError):
         GreenLight(27, 6, 10, 208, 900.0)
     m.close()
+
+
+def test_vecnormalize_on_device_matches_sb3_algorithm(golden):
+    """VecNormalizeGPU (glgym_vecnorm kernels) vs the numpy restatement of SB3 2.6.0's VecNormalize, driven by the same
+    raw observations / rewards / dones for 12 steps incl. an episode boundary (returns reset)."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.vec_normalize import VecNormalizeGPU
+    from oracle.vecnorm_oracle import VecNormalizeOracle
+    w = golden("rollout_10day")["weather"]
+    B = 512
+    env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=224, season_length=0.08, start_rows=[0, 30, 200], seed=9)
+    vn = VecNormalizeGPU(env, clip_obs=10.0, gamma=0.9631)                 # gamma of configs/agents/ppo.yml:8
+    orc = VecNormalizeOracle(B, env.obs_dim, clip_obs=10.0, gamma=0.9631)
+    obs_n = vn.reset()
+    ref_n = orc.reset(vn.get_original_obs().astype(np.float64))
+    np.testing.assert_allclose(obs_n, ref_n, rtol=1e-5, atol=2e-5)
+    rng = np.random.default_rng(0)
+    saw_done = False
+    for k in range(12):
+        obs_n, rew_n, dones, infos = vn.step(rng.uniform(-1, 1, (B, 6)).astype(np.float32))
+        raw_r = vn.get_original_reward().astype(np.float64)
+        # with auto-reset the raw obs of finished envs is the next episode's first obs, exactly what SB3 would see
+        ref_o, ref_r = orc.step(vn.get_original_obs().astype(np.float64), raw_r, dones)
+        np.testing.assert_allclose(obs_n, ref_o, rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(rew_n, ref_r, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(vn.obs_rms.mean, orc.obs_rms.mean, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(vn.obs_rms.var, orc.obs_rms.var, rtol=1e-7, atol=1e-9)
+        assert abs(vn.obs_rms.count - orc.obs_rms.count) < 1e-6
+        assert abs(vn.ret_rms.var - orc.ret_rms.var) < 1e-9 * max(1.0, orc.ret_rms.var)
+        np.testing.assert_allclose(vn.returns.cpu().numpy(), orc.returns, rtol=1e-9, atol=1e-12)
+        saw_done |= bool(dones.any())
+    assert saw_done and np.abs(obs_n).max() <= 10.0
+    x = rng.standard_normal((4, env.obs_dim))
+    np.testing.assert_allclose(vn.unnormalize_obs(x), orc.unnormalize_obs(x), rtol=1e-9)
+    # eval-mode wrapper (training=False, norm_reward=False) leaves the statistics untouched
+    vn.training, vn.norm_reward = False, False
+    m0 = vn.obs_rms.mean.copy()
+    _, rew_e, _, _ = vn.step(np.zeros((B, 6), np.float32))
+    assert np.array_equal(vn.obs_rms.mean, m0) and np.allclose(rew_e, vn.get_original_reward())
+    env.close()
