@@ -45,6 +45,7 @@ template <class T> struct Math;
 
 template <> struct Math<double> {
     static GL_HD double exp(double v) { return ::exp(v); }
+    static GL_HD double expk(double c, double v) { return ::exp(c * v); }      // exp(c*v)
     static GL_HD double log(double v) { return ::log(v); }
     static GL_HD double rcp(double v) { return 1.0 / v; }
     static GL_HD double sqrt(double v) { return ::sqrt(v); }
@@ -58,11 +59,14 @@ template <> struct Math<double> {
 template <> struct Math<float> {
 #if defined(__HIP_DEVICE_COMPILE__)
     static GL_HD float exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+    // exp(c*v): when c is a literal / compile-time constant, c*log2(e) folds and the call is one v_mul + v_exp
+    static GL_HD float expk(float c, float v) { return __builtin_amdgcn_exp2f((c * 1.44269504088896341f) * v); }
     static GL_HD float rcp(float v) { return __builtin_amdgcn_rcpf(v); }
     static GL_HD float sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
     static GL_HD float powa(float av, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(av)); }
 #else
     static GL_HD float exp(float v) { return ::expf(v); }
+    static GL_HD float expk(float c, float v) { return ::expf(c * v); }
     static GL_HD float rcp(float v) { return 1.0f / v; }
     static GL_HD float sqrt(float v) { return ::sqrtf(v); }
     static GL_HD float powa(float av, float e) { return ::powf(av, e); }
@@ -163,7 +167,7 @@ template <class T> struct ModelConst {
     T nk1Par, nk2Par, nkNir, nkFir;                          // -p32 -p33 -p34 -p35
     T oneMinusRhoCanPar, rhoFlrPar, oneMinusRhoFlrPar;       // 1-p10 p98 1-p98
     T rhoCanNir, oneMinusRhoCanNir, rhoFlrNir, oneMinusRhoFlrNir;   // p11 1-p11 p97 1-p97
-    // --- FIR: sigma folded into the Kelvin^4 scale, remaining factors per exchange pair.
+    // --- FIR: Stefan-Boltzmann sigma is folded into every coefficient below; the kernels work on raw Kelvin^4.
     T sigma;
     // p-only coefficients (suffix: a = times aCan, g = times canopy gap exp(-kFir*lai))
     T fCanFlr_a, fPipeFlr, fPipeCan_a, fCovESky, fLampFlr_g, fLampPipe_g, fLampCan_a, fGroPipeCan;
@@ -239,48 +243,48 @@ template <class T> inline void make_model_const(const double* p, ModelConst<T>& 
     m.sigma = S(sigma);
     const double aPipe = p[124], ePipe = p[104], eCan = p[3], eSky = p[4], eFlr = p[95], eTh = p[74], eBl = p[85];
     const double aLamp = p[181], eLampT = p[182], eLampB = p[183], tauLampFir = p[178], tauIntFir = p[199];
-    m.fCanFlr_a = S(eCan * eFlr * p[125]);
-    m.fPipeFlr = S(aPipe * ePipe * eFlr * 0.49);
-    m.fPipeCan_a = S(aPipe * ePipe * eCan * 0.49);
-    m.fCovESky = S(aCovFir * eSky);
-    m.fLampFlr_g = S(aLamp * eLampB * eFlr * tauIntFir * pipeShade);
-    m.fLampPipe_g = S(aLamp * eLampB * ePipe * tauIntFir * pipeCover);
-    m.fLampCan_a = S(aLamp * eLampB * eCan);
-    m.fGroPipeCan = S(p[169] * p[165] * eCan);
-    m.bCanCovIn = S(eCan * aCovFir * tauLampFir);
-    m.bCanSky = S(eCan * eSky * tauLampFir * tauCovFir);
-    m.bCanThScr = S(eCan * eTh * tauLampFir);
-    m.bPipeCovIn = S(aPipe * ePipe * aCovFir * tauIntFir * tauLampFir * 0.49);
-    m.bPipeSky = S(aPipe * ePipe * eSky * tauIntFir * tauLampFir * tauCovFir * 0.49);
-    m.bPipeThScr = S(aPipe * ePipe * eTh * tauIntFir * tauLampFir * 0.49);
-    m.bFlrCovIn = S(eFlr * aCovFir * tauIntFir * tauLampFir * pipeShade);
-    m.bFlrSky = S(eFlr * eSky * tauIntFir * tauLampFir * tauCovFir * pipeShade);
-    m.bFlrThScr = S(eFlr * eTh * tauIntFir * tauLampFir * pipeShade);
-    m.bThScrCovIn = S(eTh * aCovFir);
-    m.bThScrSky = S(eTh * eSky * tauCovFir);
-    m.bLampThScr = S(aLamp * eLampT * eTh);
-    m.bLampCovIn = S(aLamp * eLampT * aCovFir);
-    m.bLampSky = S(aLamp * eLampT * eSky * tauCovFir);
-    m.bFlrBlScr = S(eFlr * eBl * tauIntFir * tauLampFir * pipeShade);
-    m.bPipeBlScr = S(aPipe * ePipe * eBl * tauIntFir * tauLampFir * 0.49);
-    m.bCanBlScr = S(eCan * eBl * tauLampFir);
-    m.bBlScrThScr = S(eBl * eTh);
-    m.bBlScrCovIn = S(eBl * aCovFir);
-    m.bBlScrSky = S(eBl * eSky * tauCovFir);
-    m.bLampBlScr = S(aLamp * eLampT * eBl);
+    m.fCanFlr_a = S(sigma * (eCan * eFlr * p[125]));
+    m.fPipeFlr = S(sigma * (aPipe * ePipe * eFlr * 0.49));
+    m.fPipeCan_a = S(sigma * (aPipe * ePipe * eCan * 0.49));
+    m.fCovESky = S(sigma * (aCovFir * eSky));
+    m.fLampFlr_g = S(sigma * (aLamp * eLampB * eFlr * tauIntFir * pipeShade));
+    m.fLampPipe_g = S(sigma * (aLamp * eLampB * ePipe * tauIntFir * pipeCover));
+    m.fLampCan_a = S(sigma * (aLamp * eLampB * eCan));
+    m.fGroPipeCan = S(sigma * (p[169] * p[165] * eCan));
+    m.bCanCovIn = S(sigma * (eCan * aCovFir * tauLampFir));
+    m.bCanSky = S(sigma * (eCan * eSky * tauLampFir * tauCovFir));
+    m.bCanThScr = S(sigma * (eCan * eTh * tauLampFir));
+    m.bPipeCovIn = S(sigma * (aPipe * ePipe * aCovFir * tauIntFir * tauLampFir * 0.49));
+    m.bPipeSky = S(sigma * (aPipe * ePipe * eSky * tauIntFir * tauLampFir * tauCovFir * 0.49));
+    m.bPipeThScr = S(sigma * (aPipe * ePipe * eTh * tauIntFir * tauLampFir * 0.49));
+    m.bFlrCovIn = S(sigma * (eFlr * aCovFir * tauIntFir * tauLampFir * pipeShade));
+    m.bFlrSky = S(sigma * (eFlr * eSky * tauIntFir * tauLampFir * tauCovFir * pipeShade));
+    m.bFlrThScr = S(sigma * (eFlr * eTh * tauIntFir * tauLampFir * pipeShade));
+    m.bThScrCovIn = S(sigma * (eTh * aCovFir));
+    m.bThScrSky = S(sigma * (eTh * eSky * tauCovFir));
+    m.bLampThScr = S(sigma * (aLamp * eLampT * eTh));
+    m.bLampCovIn = S(sigma * (aLamp * eLampT * aCovFir));
+    m.bLampSky = S(sigma * (aLamp * eLampT * eSky * tauCovFir));
+    m.bFlrBlScr = S(sigma * (eFlr * eBl * tauIntFir * tauLampFir * pipeShade));
+    m.bPipeBlScr = S(sigma * (aPipe * ePipe * eBl * tauIntFir * tauLampFir * 0.49));
+    m.bCanBlScr = S(sigma * (eCan * eBl * tauLampFir));
+    m.bBlScrThScr = S(sigma * (eBl * eTh));
+    m.bBlScrCovIn = S(sigma * (eBl * aCovFir));
+    m.bBlScrSky = S(sigma * (eBl * eSky * tauCovFir));
+    m.bLampBlScr = S(sigma * (aLamp * eLampT * eBl));
 
     const double aInt = p[194], eInt = p[195];
     m.intLampActive = (aInt * eInt != 0.0 || p[198] != 0.0) ? 1 : 0;
     m.nkIntFirUp = S(-p[203] * (1.0 - p[189]));
     m.nkIntFirDown = S(-p[203] * p[189]);
-    m.iFlr = S(aInt * eInt * eFlr * pipeShade);
-    m.iPipe = S(aInt * eInt * ePipe * pipeCover);
-    m.iCan = S(aInt * eInt * eCan);
-    m.iLamp = S(aInt * eInt * eLampB * aLamp);
-    m.bIBlScr = S(aInt * eInt * eBl * tauLampFir);
-    m.bIThScr = S(aInt * eInt * eTh * tauLampFir);
-    m.bICovIn = S(aInt * eInt * aCovFir * tauLampFir);
-    m.bISky = S(aInt * eInt * eSky * tauCovFir * tauLampFir);
+    m.iFlr = S(sigma * (aInt * eInt * eFlr * pipeShade));
+    m.iPipe = S(sigma * (aInt * eInt * ePipe * pipeCover));
+    m.iCan = S(sigma * (aInt * eInt * eCan));
+    m.iLamp = S(sigma * (aInt * eInt * eLampB * aLamp));
+    m.bIBlScr = S(sigma * (aInt * eInt * eBl * tauLampFir));
+    m.bIThScr = S(sigma * (aInt * eInt * eTh * tauLampFir));
+    m.bICovIn = S(sigma * (aInt * eInt * aCovFir * tauLampFir));
+    m.bISky = S(sigma * (aInt * eInt * eSky * tauCovFir * tauLampFir));
     m.cIntLampAir = S(std::fabs(p[198]));
 
     m.aRoofOverFlr2 = S(p[55] * p[59] / (2.0 * p[46]));
@@ -348,7 +352,7 @@ template <class T> struct StepCoef {
     // stomata (depend on rCan = a45 only)
     T cEvap3, cEvap4, rSK;      // a169, a170, p42*a171
     // FIR (sigma lives in the K^4 values)
-    T qSky;                     // sigma*(tSky+C2K)^4
+    T qSky;                     // (tSky+C2K)^4  (sigma is folded into every FIR coefficient)
     T cCanCovIn, cCanSky, cCanThScr, cCanBlScr;                        // x aCan
     T cPipeCovIn, cPipeSky, cPipeThScr, cPipeBlScr;                    // x gap
     T cFlrCovIn, cFlrSky, cFlrThScr, cFlrBlScr;                        // x gap
@@ -430,7 +434,7 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
 
     // -- stomatal response to radiation above the canopy (aux_states.hpp:940-954); rCan has no LAI term
     const T rCan = oneMinusAir * iGlob * (m.etaGlobPar * tauCovPar + m.etaGlobNir * tauCovNir) + s.lampAirK;
-    const T sRs = M::rcp(one + M::exp(m.sRsSlope * (rCan - m.rCanSp)));
+    const T sRs = M::rcp(one + M::expk(m.sRsSlope, rCan - m.rCanSp));
     s.cEvap3 = m.cEvap3Night * (one - sRs) + m.cEvap3Day * sRs;
     s.cEvap4 = m.cEvap4Night * (one - sRs) + m.cEvap4Day * sRs;
     s.rSK = m.rSMin * (rCan + m.cEvap1) * M::rcp(rCan + m.cEvap2);
@@ -440,7 +444,7 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
     const T thbl = tauThF * tauBlF, uThBl = uTh * tauBlF;
     const T skyK = tSky + Kelvin<T>::c2k();
     const T sk2 = skyK * skyK;
-    s.qSky = m.sigma * sk2 * sk2;
+    s.qSky = sk2 * sk2;
     s.cCanCovIn = m.bCanCovIn * thbl;    s.cCanSky = m.bCanSky * thbl;
     s.cCanThScr = m.bCanThScr * uThBl;   s.cCanBlScr = m.bCanBlScr * uBl;
     s.cPipeCovIn = m.bPipeCovIn * thbl;  s.cPipeSky = m.bPipeSky * tauThF;      // :520 has no blackout factor
@@ -505,10 +509,10 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
 
     // ---- canopy geometry (aux_states.hpp:233, 299-484)
     const T lai = cr.sla * cLeaf;
-    const T e1Par = M::exp(m.nk1Par * lai);
-    const T e2Par = M::exp(m.nk2Par * lai);
-    const T eNir = M::exp(m.nkNir * lai);
-    const T gap = M::exp(m.nkFir * lai);          // FIR transmission of the canopy
+    const T e1Par = M::expk(m.nk1Par, lai);
+    const T e2Par = M::expk(m.nk2Par, lai);
+    const T eNir = M::expk(m.nkNir, lai);
+    const T gap = M::expk(m.nkFir, lai);          // FIR transmission of the canopy
     const T aCan = one - gap;
 
     // ---- short wave absorbed by canopy / floor / air (aux_states.hpp:299-470)
@@ -535,7 +539,7 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     const T rGlobSunAir = s.sunAirPar + s.sunAirNirK * (aCanNir + aFlrNir);
 
     // ---- long wave: sigma*T^4 per surface, then pairwise exchange (aux_states.hpp:493-632)
-    auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return m.sigma * k2 * k2; };
+    auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };   // sigma lives in the coefficients
     const T qCan = q4(tCan), qCovIn = q4(tCovIn), qCovE = q4(tCovE), qThScr = q4(tThScr), qFlr = q4(tFlr);
     const T qPipe = q4(tPipe), qLamp = q4(tLamp), qBlScr = q4(tBlScr), qGro = q4(tGroPipe), qSky = s.qSky;
 
@@ -576,7 +580,7 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     if (m.intLampActive) {
         const T tInt = x[18];
         const T qInt = q4(tInt);
-        const T eUp = M::exp(m.nkIntFirUp * lai), eDn = M::exp(m.nkIntFirDown * lai);
+        const T eUp = M::expk(m.nkIntFirUp, lai), eDn = M::expk(m.nkIntFirDown, lai);
         iToFlr = m.iFlr * eDn * (qInt - qFlr);
         iToPipe = m.iPipe * eDn * (qInt - qPipe);
         iToCan = m.iCan * ((one - eDn) + (one - eUp)) * (qInt - qCan);
@@ -639,7 +643,7 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     const T hLampAir = m.cLampAir * (tLamp - tAir);
 
     // ---- transpiration (aux_states.hpp:958-981)
-    auto satVp = [&](T t) { return T(610.78) * M::exp(T(17.2694) * t * M::rcp(t + T(238.3))); };
+    auto satVp = [&](T t) { return T(610.78) * M::expk(T(17.2694), t * M::rcp(t + T(238.3))); };
     const T vpd = satVp(tCan) - vpAir;
     const T co2Dev = m.etaMgPpm * co2Air - T(200);
     const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
@@ -650,7 +654,7 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     // ---- condensation and vapour carried by air (aux_states.hpp:999-1024)
     auto cond = [&](T hec, T vp1, T vp2) {
         const T dv = vp1 - vp2;
-        return hec * T(6.4e-9) * dv * M::rcp(one + M::exp(T(-0.1) * dv));
+        return hec * T(6.4e-9) * dv * M::rcp(one + M::expk(T(-0.1), dv));
     };
     const T mvAirThScr = cond(hecAirTh, vpAir, satVp(tThScr));
     const T mvAirBlScr = cond(hecAirBl, vpAir, satVp(tBlScr));
@@ -676,38 +680,39 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     const T co2Stom = cr.etaCo2Stom * co2Ppm;
     const T tCanK = tCan + c2k;
     const T iCanK = M::rcp(tCanK);
-    const T jPot = j25 * M::exp(cr.kJ1 * (tCan - cr.t25C) * iCanK) * cr.jDen25 *
+    const T jPot = j25 * M::expk(cr.kJ1, (tCan - cr.t25C) * iCanK) * cr.jDen25 *
                    M::rcp(one + M::exp(cr.kS - cr.kH * iCanK));
     const T aPar = cr.alpha * parCan;
     const T jSum = jPot + aPar;
     const T q = cr.fourTheta * jPot * aPar;
     const T jRate = cr.inv2Theta * (q - eps) * M::rcp(jSum + M::sqrt(jSum * jSum - q + eps));
-    const T photo = jRate * (co2Stom - gammaStar) * M::rcp(T(4) * (co2Stom + T(2) * gammaStar));
-    const T net = photo * (one - gammaStar * M::rcp(co2Stom));           // P - R
-    const T hAirBuf = M::rcp(one + M::exp(T(5e-4) * (cBuf - cr.cBufMax)));
+    // P = J (c - G) / (4 (c + 2G)),  R = P G / c   ->   P - R = J (c - G)^2 / (4 c (c + 2G)): one reciprocal
+    const T cmg = co2Stom - gammaStar;
+    const T net = jRate * cmg * cmg * M::rcp(T(4) * co2Stom * (co2Stom + T(2) * gammaStar));
+    const T hAirBuf = M::rcp(one + M::expk(T(5e-4), cBuf - cr.cBufMax));
     const T mcAirBuf = cr.mCh2o * hAirBuf * net;
 
     // ---- carbohydrate flows (aux_states.hpp:1103-1194)
     const T gT24 = T(0.047) * tCan24 + T(0.06);
-    const T hT24 = M::rcp((one + M::exp(T(-1.1587) * (tCan24 - cr.tCan24Min))) *
-                          (one + M::exp(T(1.3904) * (tCan24 - cr.tCan24Max))));
-    const T hTCan = M::rcp((one + M::exp(T(-0.869) * (tCan - cr.tCanMin))) *
-                           (one + M::exp(T(0.5793) * (tCan - cr.tCanMax))));
-    const T devA = tCanSum * m.tEndSumInv, devB = devA - one;
-    const T hTSum = T(0.5) * (devA + M::sqrt(devA * devA + T(1e-4))) - T(0.5) * (devB + M::sqrt(devB * devB + T(1e-4)));
-    const T hBufOrg = M::rcp(one + M::exp(T(-5e-3) * (cBuf - cr.cBufMin)));
+    const T hT24 = M::rcp((one + M::expk(T(-1.1587), tCan24 - cr.tCan24Min)) *
+                          (one + M::expk(T(1.3904), tCan24 - cr.tCan24Max)));
+    const T hTCan = M::rcp((one + M::expk(T(-0.869), tCan - cr.tCanMin)) *
+                           (one + M::expk(T(0.5793), tCan - cr.tCanMax)));
+    const T devA = tCanSum * m.tEndSumInv, devB = devA - one;      // devA - devB == 1
+    const T hTSum = T(0.5) * ((one + M::sqrt(devA * devA + T(1e-4))) - M::sqrt(devB * devB + T(1e-4)));
+    const T hBufOrg = M::rcp(one + M::expk(T(-5e-3), cBuf - cr.cBufMin));
     const T flow = hBufOrg * hT24 * gT24;
     const T mcBufLeaf = flow * cr.rgLeaf, mcBufStem = flow * cr.rgStem;
     const T mcBufFruit = flow * hTCan * hTSum * cr.rgFruit;
     const T mcBufAir = cr.cLeafG * mcBufLeaf + cr.cStemG * mcBufStem + cr.cFruitG * mcBufFruit;
-    const T maint = cr.maintBase * M::exp(cr.q10k * (tCan24 - T(25)));
+    const T maint = cr.maintBase * M::expk(cr.q10k, tCan24 - T(25));
     const T mcLeafAir = maint * cLeaf * cr.cLeafM, mcStemAir = maint * cStem * cr.cStemM;
     const T mcFruitAir = maint * cFruit * cr.cFruitM;
     T mcLeafHar = T(0), mcFruitHar = T(0);
     if (HARVEST_IN_RHS) {
         const T kHar = T(2.0 * 4.6052 / 1e4);
-        mcLeafHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cLeaf - cr.cLeafMax)));
-        mcFruitHar = T(5e4) * M::rcp(one + M::exp(-kHar * (cFruit - cr.cFruitMax)));
+        mcLeafHar = T(5e4) * M::rcp(one + M::expk(-kHar, cLeaf - cr.cLeafMax));
+        mcFruitHar = T(5e4) * M::rcp(one + M::expk(-kHar, cFruit - cr.cFruitMax));
     }
     const T mcAirCan = cr.co2PerCh2o * (mcAirBuf - mcBufAir - (mcLeafAir + mcStemAir + mcFruitAir));
 
@@ -851,24 +856,26 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
                      int n_sub, T* del)
 {
     const T h = dt / T(n_sub), h2 = T(0.5) * h, h6 = h / T(6);
-    T xs[NX], k[NX], acc[NX];
+    T y[NX], xs[NX], k[NX], acc[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
     for (int it = 0; it < n_sub; ++it) {
         // Strang splitting: half a step of the exact harvest flow, RK4 on everything else, half a step again
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, h2);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, h2);
+        // y = state at the start of the sub-step; stage inputs y + c*h*k are one FMA each (their rounding is at the
+        // state's magnitude either way; only the ACCUMULATION below has to stay in delta form)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xs[i] = x0[i] + del[i];
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+        rhs_stage(y, s, m, cr, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
         rhs_stage(xs, s, m, cr, k);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = x0[i] + (del[i] + h2 * k[i]); }
+        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
         rhs_stage(xs, s, m, cr, k);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = x0[i] + (del[i] + h2 * k[i]); }
-        rhs_stage(xs, s, m, cr, k);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = x0[i] + (del[i] + h * k[i]); }
+        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
         rhs_stage(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) del[i] += h6 * (acc[i] + k[i]);
