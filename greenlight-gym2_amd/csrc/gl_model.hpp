@@ -806,24 +806,6 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
     const T k = T(2.0 * 4.6052 / 1e4), one = T(1);
     const T z0 = k * (c - cMax);
     const T a = k * T(5e4) * t;
-#if defined(GL_HARVEST_SELECT)
-    // branch-free form (both regimes evaluated on clamped inputs, result selected)
-    const T zc = M::max(z0, T(-40));
-    const T E0 = M::exp(-zc);
-    T d1 = -a * M::rcp(one + E0);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const T em = M::expm1(-d1);
-        d1 -= (d1 - E0 * em + a) * M::rcp(one + E0 * (em + one));
-    }
-    const T D = E0 - zc + a;
-    T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
-#pragma unroll
-    for (int it = 0; it < 4; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
-    const T d2 = -M::log(w) - zc;
-    const T dz = (z0 < T(-6)) ? d1 : d2;
-    return (z0 < T(-40)) ? T(0) : dz * T(1e4 / (2.0 * 4.6052));
-#else
     if (z0 < T(-40)) return T(0);
     const T E0 = M::exp(-z0);
     T dz;
@@ -842,7 +824,6 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
         dz = -M::log(w) - z0;
     }
     return dz * T(1e4 / (2.0 * 4.6052));
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -22,11 +22,6 @@ def models():
     m64.close(); m32.close()
 
 
-def _reachable(X, P):
-    """tuples outside the harvest-switch zone (cLeaf within ~1e4 of cLeafMax is only reachable artificially)."""
-    return (X[:, 23] < P[:, 144] - 1.2e4) & (X[:, 25] < P[:, 145] - 1.2e4)
-
-
 def test_rhs_matches_reference_text_vectors(models, golden):
     g = golden("rhs_kat")
     X, U, D, P, DX = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["DX"]
