@@ -73,13 +73,49 @@ def _torch():
     return torch
 
 
+class LazyInfos:
+    """List-like view of the per-env info dicts (SB3: ``infos[i]``).  Dicts are built on first access and cached, so
+    wrappers that only touch finished envs (VecMonitor, VecNormalize) cost O(#done), not O(B), per step."""
+
+    def __init__(self, keys, info_rows, controls, dones, term_obs):
+        self._keys, self._rows, self._ctrl, self._dones, self._term = keys, info_rows, controls, dones, term_obs
+        self._cache = {}
+
+    def __len__(self):
+        return len(self._rows)
+
+    def _make(self, b):
+        d = dict(zip(self._keys, self._rows[b].tolist()))
+        d["controls"] = self._ctrl[b]
+        d["TimeLimit.truncated"] = False
+        if self._term is not None and self._dones[b]:
+            d["terminal_observation"] = self._term[b]
+        return d
+
+    def __getitem__(self, b):
+        if isinstance(b, slice):
+            return [self[i] for i in range(*b.indices(len(self)))]
+        b = int(b)
+        if b < 0:
+            b += len(self)
+        if b not in self._cache:
+            self._cache[b] = self._make(b)
+        return self._cache[b]
+
+    def __setitem__(self, b, value):
+        self._cache[int(b)] = value
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class TomatoVecEnv:
     def __init__(self, num_envs: int, weather: Optional[np.ndarray] = None, params: Optional[np.ndarray] = None,
                  dt: float = 900.0, season_length: float = 60, pred_horizon: float = 0.5, dtype: str = "float32",
                  n_sub: int = 256, device: str = "cuda:0", seed: int = 0, uncertainty_scale: float = 0.0,
                  start_rows: Optional[Sequence[int]] = None, start_days: Optional[Sequence[float]] = None,
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
-                 auto_reset: bool = True, collect_metrics: bool = True):
+                 auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise L.GlgymError("TomatoVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -102,6 +138,7 @@ class TomatoVecEnv:
         self.n_sub = int(n_sub)
         self.uncertainty_scale = float(uncertainty_scale)
         self.auto_reset = auto_reset
+        self.lazy_infos = (int(num_envs) > 4096) if lazy_infos is None else bool(lazy_infos)
         self.seed_value = int(seed)
 
         self.p = np.asarray(init_default_params(L.NP) if params is None else params, dtype=np.float32)
@@ -165,6 +202,19 @@ class TomatoVecEnv:
         self.action_space = _box(-1.0, 1.0, (L.NU,), np.float32)
         self._actions = None
         self.reset_infos: List[dict] = [{} for _ in range(self.B)]
+        # pinned host staging for the numpy (SB3) path: the 1 KB/env observation block dominates the D2H traffic
+        self._obs_host = [torch.empty(self.B, self.obs_dim, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._obs_flip = 0
+
+    def _obs_to_host(self, obs_t):
+        """D2H into one of two pinned buffers (alternating) and return a numpy VIEW of it: the array stays valid
+        until the call after next.  (A second host-side copy of the 1 KB/env block would cost more than the PCIe
+        transfer itself; consumers such as SB3's rollout buffer copy what they keep.)"""
+        buf = self._obs_host[self._obs_flip]
+        self._obs_flip ^= 1
+        buf.copy_(obs_t, non_blocking=True)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return buf.numpy()
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -240,7 +290,7 @@ class TomatoVecEnv:
 
     # ---- SB3 VecEnv calling convention ------------------------------------------------------------
     def reset(self):
-        return self.reset_tensor().cpu().numpy()
+        return self._obs_to_host(self.reset_tensor())
 
     def seed(self, seed: Optional[int] = None):
         if seed is not None:
@@ -253,19 +303,22 @@ class TomatoVecEnv:
     def step_wait(self):
         torch = self.torch
         obs_t, r_t, d_t, info_T = self.step_tensor(torch.as_tensor(self._actions, device=self.device))
-        obs, rew = obs_t.cpu().numpy(), r_t.float().cpu().numpy()
+        obs, rew = self._obs_to_host(obs_t), r_t.float().cpu().numpy()
         dones = d_t.cpu().numpy().astype(bool)
-        info = info_T.double().cpu().numpy()
+        # infos: SB3 wants a list of per-env dicts.  Built from two bulk D2H copies (info block, controls) with
+        # zip over Python lists -- the cheapest pure-Python construction (about 1 us per env per key).
+        rows = info_T.double().t().cpu().numpy()
         ctrl = self.u.double().cpu().numpy()
-        infos = []
         term = self.term_obs_t.cpu().numpy() if (self.auto_reset and dones.any()) else None
-        for b in range(self.B):
-            d = {k: float(info[i, b]) for i, k in enumerate(L.INFO_KEYS)}
-            d["controls"] = ctrl[b]
-            d["TimeLimit.truncated"] = False
-            if term is not None and dones[b]:
-                d["terminal_observation"] = term[b]
-            infos.append(d)
+        if self.lazy_infos:
+            infos = LazyInfos(L.INFO_KEYS, rows, ctrl, dones, term)
+        else:
+            infos = [dict(zip(L.INFO_KEYS, row), controls=c) for row, c in zip(rows.tolist(), ctrl)]
+            for d in infos:
+                d["TimeLimit.truncated"] = False
+            if term is not None:
+                for b in np.nonzero(dones)[0]:
+                    infos[b]["terminal_observation"] = term[b]
         return obs, rew, dones, infos
 
     def step(self, actions):
@@ -276,7 +329,7 @@ class TomatoVecEnv:
         torch = self.torch
         obs_t, r_t, d_t, info_T = self.step_tensor(controls_t=torch.as_tensor(np.asarray(controls), dtype=self.tdtype,
                                                                               device=self.device))
-        return obs_t.cpu().numpy(), r_t.float().cpu().numpy(), d_t.cpu().numpy().astype(bool), info_T.cpu().numpy()
+        return self._obs_to_host(obs_t), r_t.float().cpu().numpy(), d_t.cpu().numpy().astype(bool), info_T.cpu().numpy()
 
     def _indices(self, indices):
         if indices is None:

@@ -35,6 +35,19 @@ def test_vecenv_autoreset_and_terminal_observation(golden):
     m = env.metrics()
     assert m["n_done"] == B and m["n_env_steps"] == 5 * B
     env.close()
+    # large batches hand out a lazy list-like of the same dicts
+    env2 = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=224, season_length=0.05, start_rows=[0, 96], seed=1,
+                        lazy_infos=True)
+    env2.reset()
+    rng = np.random.default_rng(0)
+    for k in range(5):
+        obs2, rew2, dones2, infos2 = env2.step(rng.uniform(-1, 1, (B, 6)).astype(np.float32))
+    assert len(infos2) == B and np.array_equal(obs2, obs) and np.array_equal(rew2, rew)
+    for b in (0, B - 1):
+        assert set(infos2[b]) == set(infos[b]) and infos2[b]["EPI"] == infos[b]["EPI"]
+        assert np.array_equal(infos2[b]["terminal_observation"], infos[b]["terminal_observation"])
+    assert len(infos2[:3]) == 3 and sum(1 for _ in infos2) == B
+    env2.close()
 
 
 def test_single_env_wrapper_follows_reference_unit_tests(golden):
