@@ -38,8 +38,11 @@ PEAK_HBM_GBPS = 8000.0
 BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum, without the obs block
 
 
-def cpu_baseline(n_sub: int, budget_s: float = 12.0):
-    """Oracle (plain-C fp64 port, RK4 with the same n_sub) timed on ONE host core on a bounded sample."""
+def cpu_baseline(n_sub: int, budget_s: float = 10.0):
+    """Oracle (plain-C fp64 port of the same scheme, ODE step only) on a bounded sample: ONE host core (the contract's
+    `cpu_baseline`) and, beside it, all host cores (threads over env slices; ctypes releases the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
     import numpy as np
     from oracle import gl_oracle as O
     from gl_gym_amd.parameters import init_default_params
@@ -58,8 +61,23 @@ def cpu_baseline(n_sub: int, budget_s: float = 12.0):
         O.rk4_batch(X, U, D, p, 900.0, n_sub)
         done += n
     el = time.perf_counter() - t0
-    return {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
+    one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
+    cores = os.cpu_count() or 1
+    per = 32
+
+    def work(_):
+        O.rk4_batch(X[:per], U[:per], D[:per], p, 900.0, n_sub)
+        return per
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, range(cores)))                    # warm-up: library loaded in every thread
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 2:
+            done += sum(ex.map(work, range(cores)))
+        el = time.perf_counter() - t0
+    allc = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{done} env-steps on {cores} threads in {el:.1f} s"}
+    return one, allc
 
 
 def main():
@@ -185,7 +203,7 @@ def main():
             "episodes_finished": agg["episodes_finished"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.n_sub)
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.n_sub)
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:
