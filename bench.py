@@ -63,8 +63,14 @@ def cpu_baseline(n_sub: int, budget_s: float = 10.0):
     el = time.perf_counter() - t0
     one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
-    cores = os.cpu_count() or 1
-    per = 32
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:        # a container may be granted fewer CPUs than it can see (cgroup v2 quota)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    per = 64
 
     def work(_):
         O.rk4_batch(X[:per], U[:per], D[:per], p, 900.0, n_sub)
@@ -73,10 +79,10 @@ def cpu_baseline(n_sub: int, budget_s: float = 10.0):
         list(ex.map(work, range(cores)))                    # warm-up: library loaded in every thread
         done, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget_s / 2:
-            done += sum(ex.map(work, range(cores)))
+            done += sum(ex.map(work, range(2 * cores)))
         el = time.perf_counter() - t0
     allc = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{done} env-steps on {cores} threads in {el:.1f} s"}
+            "sample": f"{done} env-steps on {cores} threads (= CPUs granted to this container) in {el:.1f} s"}
     return one, allc
 
 
