@@ -866,4 +866,37 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
     del[NX - 1] = dt * T(1.0 / 86400.0);     // x27 = time [days]: dx = 1/86400 exactly, nothing depends on it
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Stability guard.  Classical RK4 is stable for h*lambda <= 2.785; lambda_max is ~0.67 1/s nominally (h = 3.5 s at
+// n_sub = 256 leaves 16 % margin) but the top-compartment exchange rate grows with wind * vent opening, and in
+// storms (18-20 m/s, vents and screens open) the state moves past the limit DURING the step and the sub-stepper
+// overflows (about 1.3e-6 of random-action env-steps on synthetic weather).  The reference's implicit solver has no
+// such limit, so instead of reporting a failed integration the step is redone from x0 with 2x, then 4x sub-steps;
+// only a step that still overflows is flagged.  Returns the number of extra attempts used (0 in the common case).
+// ---------------------------------------------------------------------------------------------------
+template <class T> GL_HD bool all_finite(const T* v)
+{
+    T chk = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) chk += v[i] * T(0);      // 0 unless some v[i] is inf / NaN
+    return chk == T(0);
+}
+
+template <class T>
+GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
+                            int n_sub, T* del, bool* failed)
+{
+    int n = n_sub, extra = 0;
+    bool ok = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rk4_delta(x0, s, m, cr, dt, n, del);
+        ok = all_finite(del);
+        if (ok) break;
+        n *= 2;
+        ++extra;
+    }
+    *failed = !ok;
+    return ok ? extra : 2;
+}
+
 }  // namespace glm

@@ -179,16 +179,20 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
     StepCoef<T> s;
     precompute(u, d, m, cr, s);
     T del[NX];
-    rk4_delta(x0, s, m, cr, a.dt, a.n_sub, del);
+    bool bad;
+    const int retries = rk4_delta_guarded(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
 
-    // ---- failure check (tomato_env.py:119-123: on an integrator error the state is left unchanged)
-    T chk = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) chk += del[i] * T(0);
-    const bool bad = !(chk == T(0));
+    // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x1[i] = bad ? x0[i] : x0[i] + del[i];
+    {   // x27 = time [days since reset]: exact from the step counter when the episode started at 0 (it always does in
+        // the reference), so that fp32 storage does not random-walk over a 5 761-step season
+        const double per_step = (double)a.dt / 86400.0;
+        double t_start = (double)x0[NX - 1] - (double)ts * per_step;
+        if (fabs(t_start) < 5e-4) t_start = 0.0;
+        if (!bad) x1[NX - 1] = T(t_start + ((double)ts + 1.0) * per_step);
+    }
 
     // ---- reward epilogue (rewards.py:156-231); indoor obs conversions (observations.py:70-77)
     const T co2ppm = rw.kPpm * (x1[2] + T(273.15)) * x1[0];
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
         const float w = live ? 1.f : 0.f;
         float mv[GLGYM_NMETRIC] = {w * (float)reward, w * (float)profit, (live && term) ? 1.f : 0.f,
                                    (live && bad) ? 1.f : 0.f, w * (float)viol[0], w * (float)viol[1],
-                                   w * (float)viol[2], w};
+                                   w * (float)viol[2], w, w * (float)retries};
 #pragma unroll
         for (int i = 0; i < GLGYM_NMETRIC; ++i) {
             const float sum = wave_sum(mv[i]);
@@ -264,7 +268,8 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
         return;
     }
     T del[NX];
-    rk4_delta(x0, s, m, cr, dt, n_sub, del);
+    bool failed;
+    rk4_delta_guarded(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
     for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
 }
 

@@ -9,14 +9,14 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
 
-NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 8
+NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 9
 F32, F64 = 0, 1
 OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
              "temp_violation", "co2_violation", "rh_violation", "lamp_violation")      # tomato_env.py:208-222
 METRIC_KEYS = ("sum_reward", "sum_EPI", "n_done", "n_ode_fail", "sum_co2_violation", "sum_temp_violation",
-               "sum_rh_violation", "n_env_steps")
+               "sum_rh_violation", "n_env_steps", "n_substep_retries")
 
 
 class GlgymError(RuntimeError):

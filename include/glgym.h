@@ -43,7 +43,8 @@ extern "C" {
 #define GLGYM_NCROP 34      /* p[128..161], the block noise.py perturbs */
 #define GLGYM_NINFO 11      /* EPI, revenue, variable_costs, fixed_costs, co2_cost, heat_cost, elec_cost,
                                temp_violation, co2_violation, rh_violation, lamp_violation (tomato_env.py:208-222) */
-#define GLGYM_NMETRIC 8     /* sum reward, sum EPI, n done, n ODE failures, sum co2/temp/rh violation, n env-steps */
+#define GLGYM_NMETRIC 9     /* sum reward, sum EPI, n done, n ODE failures, sum co2/temp/rh violation, n env-steps,
+                               n sub-step retries (stability guard: env-steps redone with 2x / 4x sub-steps) */
 
 typedef struct glgym_handle_s* glgym_handle;
 
@@ -82,7 +83,7 @@ typedef struct {
     void* reward;              /* [ld] T out */
     void* info;                /* SoA [11][ld] T out, order of GLGYM_NINFO */
     uint8_t* done;             /* [B] out: terminated (season end, or ODE failure -> state left unchanged) */
-    float* metrics;            /* [8] f32 accumulators (atomicAdd, GLGYM_NMETRIC order) or NULL */
+    float* metrics;            /* [9] f32 accumulators (atomicAdd, GLGYM_NMETRIC order) or NULL */
 } glgym_step_args;
 
 /* Device-pointer arguments of observation assembly (row-major output, what SB3 / Gymnasium consume). */

@@ -144,7 +144,7 @@ class OracleTomatoEnv:
     def _evalF(self, x, u, d, p):
         p = np.asarray(p, dtype=np.float64)
         if self.integrator == "rk4":            # the kernels' scheme: Strang-split exact harvest flow + RK4
-            return O.rk4_split(x, u, d, p, self.dt, self.n_sub)
+            return O.rk4_guarded(x, u, d, p, self.dt, self.n_sub)[0]
         if self.integrator == "rk4_plain":      # classical RK4 of the complete RHS
             return O.rk4(x, u, d, p, self.dt, self.n_sub)
         if self.integrator == "stiff":

@@ -581,6 +581,21 @@ void gl_oracle_rk4_split(const double *x0, const double *u, const double *d, con
     memcpy(x1, x, sizeof x);
 }
 
+/* Stability guard of the kernels: redo the env-step from x0 with 2x, then 4x sub-steps while the result is not finite.
+ * Returns the number of extra attempts (0 normally; 2 with a non-finite result = failed integration). */
+int gl_oracle_rk4_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                          double *x1)
+{
+    int n = n_sub;
+    for (int attempt = 0; attempt < 3; ++attempt, n *= 2) {
+        gl_oracle_rk4_split(x0, u, d, p, dt, n, x1);
+        int ok = 1;
+        for (int i = 0; i < GL_NX; ++i) ok &= isfinite(x1[i]) ? 1 : 0;
+        if (ok) return attempt;
+    }
+    return 2;
+}
+
 /* Batched RK4 over independent environments (row-major [B,*]; p is [B,np] if p_per_env
  * else [np]).  Used for parity at batch sizes and as the "port" CPU baseline. */
 void gl_oracle_rk4_batch(const double *x0, const double *u, const double *d, const double *p, int p_per_env,

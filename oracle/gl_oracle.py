@@ -41,6 +41,8 @@ def lib():
         L.gl_oracle_rhs.argtypes = [_dp] * 6
         L.gl_oracle_rk4.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_split.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk4_guarded.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk4_guarded.restype = ctypes.c_int
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_stiff.argtypes = [_dp] * 4 + [ctypes.c_double] * 3 + [_dp, ctypes.POINTER(ctypes.c_long)]
         L.gl_oracle_stiff.restype = ctypes.c_long
@@ -80,6 +82,14 @@ def rk4_split(x, u, d, p, dt=900.0, n_sub=256):
     out = np.empty(NX)
     lib().gl_oracle_rk4_split(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
     return out
+
+
+def rk4_guarded(x, u, d, p, dt=900.0, n_sub=256):
+    """rk4_split with the kernels' stability guard (retry with 2x / 4x sub-steps).  Returns (x_next, retries)."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    r = lib().gl_oracle_rk4_guarded(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
+    return out, int(r)
 
 
 def rk4_batch(X, U, D, P, dt=900.0, n_sub=256):

@@ -1,0 +1,35 @@
+"""60-day season (5 761 steps, the reference's default episode): fp32 vs fp64 kernels on identical random actions, and
+an ODE-failure / physical-range census over a large fp32 batch.  Evidence for DESIGN.md; not a timed benchmark."""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "greenlight-gym2_amd")
+import numpy as np, torch
+from gl_gym_amd.tomato_env import TomatoVecEnv
+from gl_gym_amd.utils import synthetic_weather
+w = synthetic_weather(n_rows=35040)
+N = 5761
+e32 = TomatoVecEnv(64, weather=w, dtype="float32", season_length=60, start_rows=[96 * 100], auto_reset=False)
+e64 = TomatoVecEnv(64, weather=w, dtype="float64", season_length=60, start_rows=[96 * 100], auto_reset=False)
+big = TomatoVecEnv(16384, weather=w, dtype="float32", season_length=60, start_rows=list(range(0, 25000, 96)), seed=3,
+                   auto_reset=False)
+for e in (e32, e64, big): e.reset_tensor()
+g = torch.Generator(device=e32.device); g.manual_seed(42)
+gb = torch.Generator(device=e32.device); gb.manual_seed(43)
+xmax = torch.zeros(28, dtype=torch.float64, device=e32.device)
+worst = torch.zeros(28, dtype=torch.float64, device=e32.device)
+t0 = time.time()
+for k in range(N):
+    a = (torch.rand(1, 6, generator=g, device=e32.device) * 2 - 1).repeat(64, 1)
+    e32.step_tensor(a, want_obs=False); e64.step_tensor(a, want_obs=False)
+    big.step_tensor(torch.rand(16384, 6, generator=gb, device=e32.device) * 2 - 1, want_obs=False)
+    x64 = e64.x[0].double(); x32 = e32.x[0].double()
+    xmax = torch.maximum(xmax, x64.abs())
+    if k % 480 == 479 or k == N - 1:
+        sc = torch.maximum(x64.abs(), 1e-3 * xmax); sc[sc == 0] = 1
+        err = ((x32 - x64).abs() / sc)
+        worst = torch.maximum(worst, err)
+        print(f"day {(k+1)/96:5.1f}: fp32 vs fp64 max scaled err {float(err.max()):.2e} (state {int(err.argmax())}); "
+              f"big batch: ode_fail {big.metrics()['n_ode_fail']:.0f}, done {int(big.done_t.sum())}, "
+              f"cLeaf [{float(big.x[:,23].min()):.0f}, {float(big.x[:,23].max()):.0f}] cFruit max {float(big.x[:,25].max()):.0f} "
+              f"tAir [{float(big.x[:,2].min()):.1f}, {float(big.x[:,2].max()):.1f}]  ({time.time()-t0:.0f}s)", flush=True)
+print("season worst fp32-vs-fp64 scaled err per state:", np.array2string(worst.cpu().numpy(), precision=1))
+assert torch.isfinite(big.x).all()
