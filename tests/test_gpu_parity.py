@@ -304,3 +304,40 @@ def test_stability_guard_in_storm(golden, oracle):
     assert plain_failed, "the scenario no longer leaves RK4-256's stability region; pick a harsher one"
     assert m["n_ode_fail"] == 0 and m["n_substep_retries"] >= B
     env.close()
+
+
+def test_run_time_configuration_dt300_no_forecast(golden):
+    """The reference's own timing harness (gl_gym/experiments/run_time.py:19-27) runs dt = 300 s, pred_horizon = 0,
+    season 10 days, raw controls.  Same sequencing / reward scaling / observation layout (Np = 0 -> 23 floats) against the
+    env oracle, with n_sub = 86 (h = 3.49 s)."""
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from oracle.gl_env_oracle import OracleTomatoEnv, INFO_KEYS
+    w900 = golden("rollout_10day")["weather"]
+    w = np.repeat(w900, 3, axis=0)[:3000]                  # a 300-s grid (zero-order hold of the 900-s fixture rows)
+    B = 32
+    env = TomatoVecEnv(B, weather=w, dtype="float64", dt=300.0, n_sub=86, season_length=0.02, pred_horizon=0,
+                       start_rows=[0, 12], start_days=[0.0, 12 * 300 / 86400], seed=3, auto_reset=False)
+    assert env.N == 5 and env.Np == 0 and env.obs_dim == 23
+    obs0 = env.reset()
+    w_off = env.w_off_t.cpu().numpy(); sd = env.start_day_t.cpu().numpy()
+    assert abs(env.fixed_costs - (15 + 0.015 + 0.07 * 116 + 2) / 365 / (86400 // 300)) < 1e-15     # rewards.py:149-155
+    rng = np.random.default_rng(2)
+    orcs = []
+    for b in range(0, B, 5):
+        o = OracleTomatoEnv(weather=w[w_off[b]:], p=env.p, season_length=0.02, dt=300.0, pred_horizon=0,
+                            integrator="rk4", n_sub=86, train_years=[0], train_days=[float(sd[b])], seed=0)
+        ob = o.reset()
+        assert ob.shape == (23,) and np.allclose(ob, obs0[b], rtol=2e-6, atol=1e-6)
+        orcs.append((b, o))
+    for k in range(6):
+        ctrl = rng.uniform(0, 1, (B, 6))
+        obs, rew, dones, info = env.step_raw_control(ctrl)
+        for b, o in orcs:
+            ob, r, term, inf = o.step_raw_control(ctrl[b])
+            assert scaled_err(env.x[b].cpu().numpy(), o.x) < 1e-8
+            assert abs(r - rew[b]) < 1e-6 and term == bool(dones[b])
+            assert np.allclose(ob, obs[b], rtol=2e-6, atol=2e-5)
+            for j, key in enumerate(INFO_KEYS):
+                assert abs(inf[key] - info[j, b]) < 1e-6 * max(1.0, abs(inf[key])), key
+    assert dones.all()
+    env.close()
