@@ -36,6 +36,10 @@ PEAK_VALU_TFLOPS = 157.3 / 2      # fp32 vector peak counts FMA = 2; the path's 
 PEAK_SPECIAL_TOPS = 157.3 / 2 / 4  # quarter rate
 PEAK_HBM_GBPS = 8000.0
 BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum, without the obs block
+# HBM bytes per step_kernel launch from rocprofv3 PMC passes on the DEFAULT workload (B = 65 536, fp32):
+# FETCH_SIZE 5 785 KB (x2: gfx950 reports half of the fetched bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 12 352 KB;
+# profiles/r01_v4_pmc_summary.csv.  bench.py cannot collect counters itself, so this is a recorded measurement.
+PMC_TRAFFIC_DEFAULT = (2 * 5785.32 + 12352.0) * 1024
 
 
 def cpu_baseline(n_sub: int, budget_s: float = 10.0):
@@ -196,7 +200,11 @@ def main():
                        "uncertainty_scale": args.uncertainty, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE, n_sub=256 run"},
             "roofline": {"bound": "valu", "kernel": "step_kernel", "achieved": ach_tflops, "peak": PEAK_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": frac, "traffic": None,
+                         "unit": "TFLOP/s", "frac": frac,
+                         "traffic": PMC_TRAFFIC_DEFAULT if (B == 65536 and args.dtype == "f32" and not args.uncertainty)
+                         else None,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
+                                         "WRITE_SIZE, recorded in profiles/r01_v4_pmc_summary.csv (default workload only)",
                          "note": "path is VALU/transcendental-bound, not HBM/MFMA (SURVEY 8d): achieved = algorithmic "
                                  "add/mul flops (4*n_sub*1502 per env-step) / mean step_kernel time; frac adds the "
                                  "quarter-rate special-op term (4*n_sub*219 per env-step)",
