@@ -1,3 +1,4 @@
+// Issue-rate microbenchmarks for gfx950 (each launch runs several ms after a same-length warm-up)
 // Issue-rate microbenchmarks for gfx950 (what limits a VALU/transcendental-bound, one-lane-per-env kernel).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/microbench.hip -o tools/microbench ; run on the GPU box.
 #include <hip/hip_runtime.h>
@@ -6,7 +7,7 @@
 
 #define CHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 1; } } while (0)
 
-constexpr int ITER = 4096;
+constexpr int ITER = 50000;      // x8 unrolled body     // >= 5 ms per launch: shorter kernels measure the DVFS clock ramp, not the issue rate
 
 template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const float* in, int n)
 {
@@ -18,6 +19,8 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pc = {c, c}, pd = {d, d};
     for (int i = 0; i < n; ++i) {
+#pragma unroll
+      for (int rep = 0; rep < 8; ++rep) {      // 64+ instructions per loop trip: the taken branch costs a lone wave ~40 cycles
         if (KIND == 0) {          // 8 independent v_fma_f32
             a0 = fmaf(a0, c, d); a1 = fmaf(a1, c, d); a2 = fmaf(a2, c, d); a3 = fmaf(a3, c, d);
             a4 = fmaf(a4, c, d); a5 = fmaf(a5, c, d); a6 = fmaf(a6, c, d); a7 = fmaf(a7, c, d);
@@ -54,6 +57,7 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
             a0 *= c; a1 *= c; a2 *= c; a3 *= c; a4 *= c; a5 *= c; a6 *= c; a7 *= c;
         }
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+      }
     }
     out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
@@ -63,19 +67,19 @@ template <int KIND> int run(const char* name, float* out, float* in, int ops_per
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     int n_cu = 256;
-    for (int wps : {1, 2, 4, 8}) {            // waves per SIMD
+    for (int wps : {1, 2, 4}) {               // waves per SIMD
         const int blocks = n_cu * 4 * wps;
-        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, in, 64);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, in, ITER);     // warm-up at full length
         CHK(hipDeviceSynchronize());
         CHK(hipEventRecord(e0));
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, in, ITER);
         CHK(hipEventRecord(e1));
         CHK(hipEventSynchronize(e1));
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-        const double wave_instr = (double)ITER * ops_per_iter;              // per wave
+        const double wave_instr = (double)ITER * 8 * ops_per_iter;          // per wave
         const double ns_per_instr_per_simd = ms * 1e6 / (wave_instr * wps);  // time per wave-instruction on one SIMD
-        printf("%-34s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz)\n", name, wps, ms,
-               ns_per_instr_per_simd, ns_per_instr_per_simd * 2.4);
+        printf("%-34s waves/SIMD=%d  %8.3f ms  -> %.3f ns per wave-instr per SIMD (%.2f cycles @2.27GHz)\n", name, wps, ms,
+               ns_per_instr_per_simd, ns_per_instr_per_simd * 2.27);
     }
     return 0;
 }
