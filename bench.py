@@ -138,6 +138,8 @@ def main():
     acts = [torch.rand(B, 6, generator=gen, device=dev) * 2 - 1 for _ in range(min(K + W, 32))]
 
     def one_step(i, ev=None):
+        # the full SB3-semantics step: control update + fused ODE step kernel + observation block + auto-reset of
+        # finished envs (new episode start drawn in-kernel, terminal observation kept, their obs rows recomputed)
         env.action_t.copy_(acts[i % len(acts)])
         if ev is not None:
             ev[0].record()
@@ -146,12 +148,9 @@ def main():
             ev[1].record()
         if not args.no_obs:
             env._launch_obs(env.obs_t)
-        # SB3 auto-reset semantics: finished envs restart from init_state at a new weather offset
-        rows, days = env._sample_starts()
-        m = env.done_t.bool()
-        env.w_off_t.copy_(torch.where(m, rows, env.w_off_t))
-        env.start_day_t.copy_(torch.where(m, days, env.start_day_t))
         env._launch_reset(env.done_t)
+        if not args.no_obs:
+            env._launch_obs(env.obs_t, env.done_t, env.term_obs_t)
         if vn is not None:
             vn._call(env.obs_t, env.reward_t, env.done_t)
 

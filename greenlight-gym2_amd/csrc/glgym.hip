@@ -282,6 +282,7 @@ template <class T> struct ObsArgsT {
     const T* x; const T* u; const T* weather; int weather_rows;
     const int* w_off; const int* timestep; const float* start_day;
     int Np; float* obs; double doy_inc, hod_inc;     // (dt/86400) mod 365 [days], dt/3600 [h] per env-step
+    const unsigned char* mask; float* term_obs;
 };
 
 // 8 consecutive env rows = one contiguous span of the row-major output.  Phase 1: 8 x 23 lanes convert the
@@ -298,6 +299,11 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
     const float kPpm = (float)(8.3144598 / (101325.0 * 44.01e-3));
     for (int rb = blockIdx.x * ROWS; rb < a.B; rb += gridDim.x * ROWS) {
         const int nrows = min(ROWS, a.B - rb);
+        if (a.mask) {                                 // masked mode: skip strips without a finished env
+            int any = 0;
+            for (int r = 0; r < nrows; ++r) any |= a.mask[rb + r];
+            if (!any) continue;                       // block-uniform
+        }
         if (tid < ROWS * NCORE) {
             const int r = tid / NCORE, j = tid - r * NCORE, b = rb + r;
             if (r < nrows) {
@@ -346,6 +352,10 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
         float* out = a.obs + (size_t)rb * dim;
         for (int e = tid; e < total; e += 256) {
             const int r = e / dim, j = e - r * dim;
+            if (a.mask) {
+                if (!a.mask[rb + r]) continue;
+                if (a.term_obs) a.term_obs[(size_t)rb * dim + e] = out[e];      // SB3 terminal_observation
+            }
             float v;
             if (j < NCORE) v = core[r][j];
             else {                                           // raw forecast rows, no unit conversion (:175-182)
@@ -360,15 +370,41 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
     }
 }
 
+// counter-based generator shared by the reset (episode start draw) and crop-noise kernels
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned* out)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // masked reset: init_state (utils.py:13-46)
 // ---------------------------------------------------------------------------------------------------
 template <class T>
 __global__ void reset_kernel(int B, int ld, const unsigned char* mask, T* x, T* u, int* timestep, const T* weather,
-                             int weather_rows, const int* w_off)
+                             int weather_rows, int* w_off, const int* start_rows, const float* start_days, int n_starts,
+                             float* start_day, int* episode, unsigned long long seed)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || (mask && !mask[b])) return;
+    if (start_rows && n_starts > 0) {            // draw this episode's start (tomato_env.py:236-244)
+        const int ep = episode ? episode[b] : 0;
+        unsigned rnd[4];
+        philox4x32_10((unsigned)b, (unsigned)ep, 0x5eedu, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
+        const int j = (int)(rnd[0] % (unsigned)n_starts);
+        w_off[b] = start_rows[j];
+        if (start_day && start_days) start_day[b] = start_days[j];
+        if (episode) episode[b] = ep + 1;
+    }
     int r = w_off[b];
     r = r < 0 ? 0 : (r >= weather_rows ? weather_rows - 1 : r);
     const double co2Out = (double)weather[(size_t)r * ND + 3], tSoOut = (double)weather[(size_t)r * ND + 6];
@@ -393,20 +429,6 @@ __global__ void reset_kernel(int B, int ld, const unsigned char* mask, T* x, T* 
 // ---------------------------------------------------------------------------------------------------
 // crop-parameter noise (noise.py:3-23) with a counter-based generator: Philox4x32-10
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                                              unsigned k1, unsigned* out)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 template <class T>
 __global__ void crop_noise_kernel(T* crop_p, int B, int ld, const float* p0, float scale, unsigned long long seed,
                                   unsigned long long draw)
@@ -801,7 +823,7 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     ObsArgsT<T> k;
     k.B = a->B; k.ld = a->ld; k.x = (const T*)a->x; k.u = (const T*)a->u; k.weather = (const T*)a->weather;
     k.weather_rows = a->weather_rows; k.w_off = a->w_off; k.timestep = a->timestep; k.start_day = a->start_day;
-    k.Np = a->Np; k.obs = a->obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0;
+    k.Np = a->Np; k.obs = a->obs; k.mask = a->mask; k.term_obs = a->term_obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0;
     int blocks = (a->B + 7) / 8;                 // 8 env rows per block-iteration
     if (blocks > 4096) blocks = 4096;            // grid-stride beyond that
     hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), 0, st, k);
@@ -892,10 +914,13 @@ int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
     const dim3 grid((a->B + 255) / 256), block(256);
     if (h->dtype == GLGYM_F32)
         hipLaunchKernelGGL((reset_kernel<float>), grid, block, 0, st, a->B, a->ld, a->mask, (float*)a->x, (float*)a->u,
-                           a->timestep, (const float*)a->weather, a->weather_rows, a->w_off);
+                           a->timestep, (const float*)a->weather, a->weather_rows, a->w_off, a->start_rows, a->start_days,
+                           a->n_starts, a->start_day, a->episode, (unsigned long long)a->seed);
     else
         hipLaunchKernelGGL((reset_kernel<double>), grid, block, 0, st, a->B, a->ld, a->mask, (double*)a->x,
-                           (double*)a->u, a->timestep, (const double*)a->weather, a->weather_rows, a->w_off);
+                           (double*)a->u, a->timestep, (const double*)a->weather, a->weather_rows, a->w_off,
+                           a->start_rows, a->start_days, a->n_starts, a->start_day, a->episode,
+                           (unsigned long long)a->seed);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }

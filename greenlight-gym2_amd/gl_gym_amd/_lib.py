@@ -40,12 +40,14 @@ class StepArgs(C.Structure):
 class ObsArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("u", C.c_void_p), ("weather", C.c_void_p),
                 ("weather_rows", C.c_int32), ("w_off", C.c_void_p), ("timestep", C.c_void_p), ("start_day", C.c_void_p),
-                ("Np", C.c_int32), ("obs", C.c_void_p)]
+                ("Np", C.c_int32), ("obs", C.c_void_p), ("mask", C.c_void_p), ("term_obs", C.c_void_p)]
 
 
 class ResetArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("mask", C.c_void_p), ("x", C.c_void_p), ("u", C.c_void_p),
-                ("timestep", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p)]
+                ("timestep", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p),
+                ("start_rows", C.c_void_p), ("start_days", C.c_void_p), ("n_starts", C.c_int32),
+                ("start_day", C.c_void_p), ("episode", C.c_void_p), ("seed", C.c_uint64)]
 
 
 class VecNormArgs(C.Structure):

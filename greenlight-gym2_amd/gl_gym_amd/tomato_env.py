@@ -193,8 +193,7 @@ class TomatoVecEnv:
         self.crop_T = z(L.NCROP, self.ld) if self.uncertainty_scale > 0 else None
         self._start_rows_t = torch.as_tensor(self.start_rows, dtype=torch.int32, device=dev)
         self._start_days_t = torch.as_tensor(self.start_days, dtype=torch.float32, device=dev)
-        self._gen = torch.Generator(device=dev)
-        self._gen.manual_seed(self.seed_value)
+        self.episode_t = z(self.B, dtype=torch.int32)           # episodes started per env (keys the start draw)
         self._draw = 0
         self.x, self.u = self.x_T[:, :self.B].t(), self.u_T[:, :self.B].t()      # [B,28] / [B,6] views
 
@@ -220,21 +219,20 @@ class TomatoVecEnv:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _sample_starts(self, n=None):
-        torch = self.torch
-        idx = torch.randint(0, len(self.start_rows), (self.B,), generator=self._gen, device=self.device)
-        return self._start_rows_t[idx], self._start_days_t[idx]
-
     def _launch_reset(self, mask_t):
+        """Masked reset; the kernel draws each new episode's start from the start table (Philox on (seed, env, episode))."""
         a = L.ResetArgs(self.B, self.ld, mask_t.data_ptr() if mask_t is not None else None, self.x_T.data_ptr(),
                         self.u_T.data_ptr(), self.timestep_t.data_ptr(), self.weather_t.data_ptr(), self.weather_rows,
-                        self.w_off_t.data_ptr())
+                        self.w_off_t.data_ptr(), self._start_rows_t.data_ptr(), self._start_days_t.data_ptr(),
+                        len(self.start_rows), self.start_day_t.data_ptr(), self.episode_t.data_ptr(), self.seed_value)
         L.check(self._lib.glgym_reset(self._h, C.byref(a), self._stream()), "glgym_reset")
 
-    def _launch_obs(self, out_t):
+    def _launch_obs(self, out_t, mask_t=None, term_t=None):
         a = L.ObsArgs(self.B, self.ld, self.x_T.data_ptr(), self.u_T.data_ptr(), self.weather_t.data_ptr(),
                       self.weather_rows, self.w_off_t.data_ptr(), self.timestep_t.data_ptr(),
-                      self.start_day_t.data_ptr(), self.Np, out_t.data_ptr())
+                      self.start_day_t.data_ptr(), self.Np, out_t.data_ptr(),
+                      mask_t.data_ptr() if mask_t is not None else None,
+                      term_t.data_ptr() if term_t is not None else None)
         L.check(self._lib.glgym_obs(self._h, C.byref(a), self._stream()), "glgym_obs")
 
     def _launch_step(self, raw_control: bool):
@@ -255,10 +253,8 @@ class TomatoVecEnv:
     # ---- tensor interface (no host synchronisation) ---------------------------------------------
     def reset_tensor(self, seed: Optional[int] = None):
         if seed is not None:
-            self._gen.manual_seed(int(seed))
-        rows, days = self._sample_starts()
-        self.w_off_t.copy_(rows)
-        self.start_day_t.copy_(days)
+            self.seed_value = int(seed)
+            self.episode_t.zero_()
         self._launch_reset(None)
         self._launch_obs(self.obs_t)
         return self.obs_t
@@ -276,16 +272,10 @@ class TomatoVecEnv:
         self._launch_step(raw_control=controls_t is not None)
         if want_obs:
             self._launch_obs(self.obs_t)
-        if self.auto_reset:
-            if want_obs:
-                self.term_obs_t.copy_(self.obs_t)
-            rows, days = self._sample_starts()
-            m = self.done_t.bool()
-            self.w_off_t.copy_(self.torch.where(m, rows, self.w_off_t))
-            self.start_day_t.copy_(self.torch.where(m, days, self.start_day_t))
+        if self.auto_reset:      # SB3 semantics: finished envs restart; their last obs goes to term_obs_t
             self._launch_reset(self.done_t)
             if want_obs:
-                self._launch_obs(self.obs_t)
+                self._launch_obs(self.obs_t, self.done_t, self.term_obs_t)
         return self.obs_t, self.reward_t[:self.B], self.done_t, self.info_T[:, :self.B]
 
     # ---- SB3 VecEnv calling convention ------------------------------------------------------------
@@ -294,7 +284,7 @@ class TomatoVecEnv:
 
     def seed(self, seed: Optional[int] = None):
         if seed is not None:
-            self._gen.manual_seed(int(seed))
+            self.seed_value = int(seed)
         return [seed] * self.B
 
     def step_async(self, actions):

@@ -98,6 +98,9 @@ typedef struct {
     const float* start_day;    /* [B] day of year at reset */
     int32_t Np;                /* forecast rows (int(pred_horizon*86400/dt)); obs_dim = 23 + 5*Np */
     float* obs;                /* [B][23 + 5*Np] row-major f32 out */
+    const uint8_t* mask;       /* NULL: every row.  Else only rows with mask[b] != 0 are recomputed ...            */
+    float* term_obs;           /* ... after their CURRENT content was saved here ([B][dim], SB3 "terminal_observation");
+                                  may be NULL */
 } glgym_obs_args;
 
 /* Device-pointer arguments of a masked reset. */
@@ -109,7 +112,16 @@ typedef struct {
     int32_t* timestep;         /* [B] out: 0 */
     const void* weather;
     int32_t weather_rows;
-    const int32_t* w_off;      /* [B] (already holding the NEW offsets of the envs being reset) */
+    int32_t* w_off;            /* [B] in/out: first weather row of the episode.  With a start table (below) the kernel
+                                  draws the new episode's start itself, otherwise it uses the value found here */
+    /* optional start table (TomatoEnv.reset picks (growth_year, start_day) at random, tomato_env.py:236-244):
+       entry j = Philox4x32-10(key = seed, counter = (env, episode[b])) mod n_starts; episode[b] is then incremented */
+    const int32_t* start_rows; /* [n_starts] or NULL */
+    const float* start_days;   /* [n_starts] day of year of each start row */
+    int32_t n_starts;
+    float* start_day;          /* [B] out: day of year of the drawn start */
+    int32_t* episode;          /* [B] in/out: episodes started so far per env */
+    uint64_t seed;
 } glgym_reset_args;
 
 const char* glgym_version(void);

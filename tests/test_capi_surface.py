@@ -33,8 +33,8 @@ def test_struct_layouts_match_header_sizes(lib):
     # 4-byte ints followed by 8-byte pointers: ctypes applies the same natural alignment as the C compiler
     assert C.sizeof(lib.RewardCfg) == 16 * 8
     assert C.sizeof(lib.StepArgs) == 8 + 8 * 5 + 8 + 8 * 3 + 8 + 8 * 4
-    assert C.sizeof(lib.ObsArgs) == 8 + 8 * 3 + 8 + 8 * 3 + 8 + 8
-    assert C.sizeof(lib.ResetArgs) == 8 + 8 * 5 + 8 + 8
+    assert C.sizeof(lib.ObsArgs) == 8 + 8 * 3 + 8 + 8 * 3 + 8 + 8 + 8 + 8
+    assert C.sizeof(lib.ResetArgs) == 8 + 8 * 5 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
 
 def test_no_cpu_fallback(lib):
