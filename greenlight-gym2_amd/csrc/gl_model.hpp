@@ -797,8 +797,9 @@ GL_HD void rhs_stage<double>(const double* x, const StepCoef<double>& s, const M
 // It is a scalar autonomous ODE with a closed-form flow: with z = k (c - cMax),  z - exp(-z) = z0 - exp(-z0) - k M t,
 // i.e. w = exp(-z) solves w + ln w = D (Wright omega).  harvest_flow returns the INCREMENT of c over time t.
 //   * z0 < -40: the rate is below 2e-13 mg/s -> 0.
-//   * z0 < -6 : increment form (Newton on dz, expm1) so that the tiny nominal change is not lost in fp32.
-//   * else    : Newton on w + ln w = D from the asymptotic initial guess (monotone, no overflow).
+//   * first Newton step |dz| < 0.03 (always on nominal trajectories): increment form (Newton on dz with expm1), so
+//     that the tiny change is not lost in fp32;
+//   * else: Newton on w + ln w = D from the asymptotic initial guess (monotone, no overflow).
 // ---------------------------------------------------------------------------------------------------
 template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
 {
@@ -808,9 +809,9 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
     const T a = k * T(5e4) * t;
     if (z0 < T(-40)) return T(0);
     const T E0 = M::exp(-z0);
-    T dz;
-    if (z0 < T(-6)) {
-        dz = -a * M::rcp(one + E0);                                   // first Newton step from dz = 0
+    T dz = -a * M::rcp(one + E0);                                     // first Newton step from dz = 0
+    if (dz > T(-0.03)) {
+        // small change (always the case on nominal trajectories): two more Newton steps converge to < 1e-12 relative
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const T em = M::expm1(-dz);
@@ -820,7 +821,7 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
         const T D = E0 - z0 + a;                                      // w + ln w = D,  w = exp(-z1)
         T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
 #pragma unroll
-        for (int it = 0; it < 4; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
+        for (int it = 0; it < 5; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
         dz = -M::log(w) - z0;
     }
     return dz * T(1e4 / (2.0 * 4.6052));

@@ -48,7 +48,14 @@ def hostmath():
     def P(a):
         return a.ctypes.data_as(dp)
 
+    lib.hostmath_harvest_flow.restype = ctypes.c_double
+    lib.hostmath_harvest_flow.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+
     class H:
+        @staticmethod
+        def harvest_flow(c, cmax, t, f32=False):
+            return lib.hostmath_harvest_flow(float(c), float(cmax), float(t), int(f32))
+
         @staticmethod
         def rhs(x, u, d_, p, f32=False, per_env_crop=False):
             out = np.empty(28)

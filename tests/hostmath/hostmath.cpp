@@ -36,6 +36,10 @@ static void run(const double* x, const double* u, const double* d, const double*
 }
 
 extern "C" {
+double hostmath_harvest_flow(double c, double cmax, double t, int f32)
+{
+    return f32 ? (double)harvest_flow<float>((float)c, (float)cmax, (float)t) : harvest_flow<double>(c, cmax, t);
+}
 void hostmath_rhs(const double* x, const double* u, const double* d, const double* p, int f32, int per_env_crop,
                   double* dx)
 {

@@ -43,3 +43,64 @@ def test_fp32_10day_rollout_meets_1e_4(hostmath, golden):
                               np.float32(w[k]) if f32 else w[k], p, f32)
             X.append(x)
         assert scaled_err(np.array(X), XR) < tol
+
+
+def test_harvest_flow_properties(hostmath):
+    """harvest_flow() = exact flow of dc/dt = -5e4 / (1 + exp(-k (c - cMax))) (aux_states.hpp:75-79).  Checked against
+    a tight numerical solve over every regime (rate from 1e-13 to 5e4 mg/s), plus the semigroup property
+    Phi(t1 + t2) = Phi(t2) o Phi(t1), monotonicity, and fp32 resolution of the tiny nominal increment."""
+    from scipy.integrate import solve_ivp
+    k, M, cmax = 2 * 4.6052 / 1e4, 5e4, 1.1278e5
+    rng = np.random.default_rng(0)
+    for z0 in (-45.0, -39.9, -30.0, -16.1, -8.01, -7.99, -6.0, -2.0, 0.0, 3.0, 18.0, 60.0):
+        c0 = cmax + z0 / k
+        for t in (0.2, 1.7578125, 30.0):
+            d64 = hostmath.harvest_flow(c0, cmax, t)
+            sol = solve_ivp(lambda _, c: -M / (1 + np.exp(-k * (c - cmax))), (0, t), [c0], method="Radau", rtol=1e-13,
+                            atol=1e-10)
+            ref = sol.y[0, -1] - c0
+            assert d64 <= 0.0
+            assert abs(d64 - ref) <= 2e-9 * max(1.0, abs(ref)) + 1e-9, (z0, t, d64, ref)
+            # semigroup
+            t1 = t * rng.uniform(0.2, 0.8)
+            d1 = hostmath.harvest_flow(c0, cmax, t1)
+            d2 = hostmath.harvest_flow(c0 + d1, cmax, t - t1)
+            assert abs((d1 + d2) - d64) <= 1e-9 * max(1.0, abs(d64)) + 1e-9
+            # fp32: relative to the increment itself wherever the rate is resolvable at all
+            d32 = hostmath.harvest_flow(c0, cmax, t, f32=True)
+            if z0 >= -39.0:
+                assert abs(d32 - d64) <= 2e-4 * abs(d64) + 1e-7 * abs(c0 - cmax) * 1e-3 + 1e-12, (z0, t, d32, d64)
+    # nominal operating point (cLeaf ~ 14 400 mg below cLeafMax): 0.1 mg per half sub-step, resolved to < 1e-5 in fp32
+    c0 = cmax - 14400.0
+    d64, d32 = hostmath.harvest_flow(c0, cmax, 1.7578125), hostmath.harvest_flow(c0, cmax, 1.7578125, f32=True)
+    assert -0.2 < d64 < -0.05 and abs(d32 - d64) < 1e-5 * abs(d64)
+
+
+def test_rhs_with_random_parameter_blocks_against_oracle(hostmath, oracle, golden):
+    """All 208 parameters perturbed (+-10 %), plus the switches the default block never exercises: FIR-transparent
+    cover (sky terms), grow-pipe emissivity, interlight geometry, etaRoofThr > 1 (the 'else' ventilation branch).
+    The product's three-tier RHS must agree with the literal oracle for every block."""
+    g = golden("rhs_kat")
+    X, U, D = g["X"], g["U"], g["D"]
+    p0 = golden("params_default")["p"].astype(np.float64)
+    rng = np.random.default_rng(123)
+    worst64 = worst32 = 0.0
+    for trial in range(40):
+        p = p0 * (1 + 0.1 * rng.uniform(-1, 1, 208))
+        if trial % 2:
+            p[70], p[67] = rng.uniform(0.02, 0.2), rng.uniform(0.05, 0.2)
+        if trial % 3 == 0:
+            p[165] = rng.uniform(0.1, 0.9)
+        if trial % 4 == 0:
+            p[194], p[195], p[198] = rng.uniform(0.01, 0.05), rng.uniform(0.5, 0.95), rng.uniform(0.5, 3.0)
+        if trial % 5 == 0:
+            p[8] = 1.2
+        p = p.astype(np.float32).astype(np.float64)
+        for i in rng.integers(0, 256, 6):
+            ref = oracle.rhs(X[i], U[i], D[i], p)
+            sc = np.maximum(np.abs(ref), 1e-3 * np.abs(g["DX"]).max(axis=0))
+            for per_env in (False, True):
+                worst64 = max(worst64, float(np.max(np.abs(hostmath.rhs(X[i], U[i], D[i], p, False, per_env) - ref) / sc)))
+                worst32 = max(worst32, float(np.max(np.abs(hostmath.rhs(X[i], U[i], D[i], p, True, per_env) - ref) / sc)))
+    assert worst64 < 1e-9, worst64
+    assert worst32 < 5e-3, worst32
