@@ -112,9 +112,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or (os.environ.get("GLGYM_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    # Test hook for 1-GPU boxes: GLGYM_BENCH_SHARE_GPU=1 maps every rank to cuda:0 and uses gloo for the (tiny) metric
+    # gather, so the N > 1 control flow can be exercised end to end.  Never set by the driver.
+    share_gpu = os.environ.get("GLGYM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
@@ -175,7 +183,7 @@ def main():
     # final metric gather: the only collective on this path (RCCL all_gather of 6 doubles per rank)
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
-                           m.get("n_done", 0.0), kern_ms], device=dev)
+                           m.get("n_done", 0.0), kern_ms], device=None if share_gpu else dev)
     if rank == 0:
         agg = aggregate(rows)
         t_max, value, kern_ms_max = agg["t_max"], agg["value"], agg["kernel_ms_max"]
