@@ -76,10 +76,12 @@ def gym_rng(seed):                  # gymnasium.utils.seeding.np_random
 class OracleReward:
     """rewards.py:47-231 restated (profit scaling + state-constraint violations)."""
 
-    def __init__(self, env, **kw):
+    def __init__(self, env, constraints_low=None, constraints_high=None, **kw):
         k = dict(REWARD_DEFAULTS, **kw)
         self.env = env
         self.k = k
+        self.low = CONSTRAINTS_LOW if constraints_low is None else np.asarray(constraints_low, dtype=np.float64)
+        self.high = CONSTRAINTS_HIGH if constraints_high is None else np.asarray(constraints_high, dtype=np.float64)
         yearly = k["fixed_greenhouse_cost"] + k["fixed_co2_cost"] + k["fixed_lamp_cost"] * 116 + k["fixed_screen_cost"]
         self.fixed_costs = yearly / 365 / (86400 // env.dt)                       # :149-155
         p, dt = env.p, env.dt
@@ -102,7 +104,7 @@ class OracleReward:
         self.gains = (e.x[25] - e.x_prev[25]) * 1e-6 / k["dmfm"] * k["fruit_price"]          # :173-184
         self.profit = self.gains - self.variable_costs                                     # :221
         o = np.asarray(e.obs[:3], dtype=np.float64)
-        viol = np.maximum(CONSTRAINTS_LOW - o, 0.0) + np.maximum(o - CONSTRAINTS_HIGH, 0.0)  # :186-199
+        viol = np.maximum(self.low - o, 0.0) + np.maximum(o - self.high, 0.0)                # :186-199
         self.co2_violation, self.temp_violation, self.rh_violation = viol
         self.lamp_violation = 0                                                            # :203-212 (always 0)
         scaled_profit = (self.profit - self.min_profit) / (self.max_profit - self.min_profit)
@@ -121,7 +123,7 @@ class OracleTomatoEnv:
 
     def __init__(self, weather, p, season_length=60, start_day=59, growth_year=2010, dt=900.0,
                  pred_horizon=0.5, uncertainty_scale=0.0, integrator="rk4", n_sub=256, seed=None,
-                 train_years=(2010,), train_days=(59,)):
+                 train_years=(2010,), train_days=(59,), reward_params=None, constraints=None):
         self.c = 86400
         self.nx, self.nu, self.nd, self.num_params = 28, 6, 10, 208
         self.dt = dt
@@ -138,7 +140,11 @@ class OracleTomatoEnv:
         self.train_years, self.train_days = list(train_years), list(train_days)
         self.start_day, self.growth_year = start_day, growth_year
         self.seed = seed
-        self.reward = OracleReward(self)
+        c = constraints or {}
+        lo = [c.get("co2_min", 300.0), c.get("temp_min", 15.0), c.get("rh_min", 50.0)]
+        hi = [c.get("co2_max", 1600.0), c.get("temp_max", 34.0), c.get("rh_max", 85.0)]
+        self.constraints_low, self.constraints_high = np.array(lo), np.array(hi)
+        self.reward = OracleReward(self, constraints_low=lo, constraints_high=hi, **(reward_params or {}))
 
     # greenlight_model.cpp:96-120 semantic
     def _evalF(self, x, u, d, p):

@@ -341,3 +341,34 @@ def test_run_time_configuration_dt300_no_forecast(golden):
                 assert abs(inf[key] - info[j, b]) < 1e-6 * max(1.0, abs(inf[key])), key
     assert dones.all()
     env.close()
+
+
+def test_custom_reward_prices_and_constraints(golden):
+    """Prices, dmfm and the constraint box come from configs/envs/TomatoEnv.yml in the reference; non-default values must
+    flow through glgym_set_reward into the kernel epilogue exactly like rewards.py uses them."""
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from oracle.gl_env_oracle import OracleTomatoEnv, INFO_KEYS
+    w = golden("rollout_10day")["weather"]
+    rp = dict(elec_price=0.21, heating_price=0.05, co2_price=0.12, fruit_price=2.4, dmfm=0.0627)
+    cs = dict(co2_min=500., co2_max=1000., temp_min=17., temp_max=20., rh_min=60., rh_max=75.)
+    env = TomatoVecEnv(16, weather=w, dtype="float64", n_sub=256, season_length=1, reward_params=rp, constraints=cs,
+                       auto_reset=False)
+    env.reset()
+    orc = OracleTomatoEnv(weather=w, p=env.p, season_length=1, integrator="rk4", n_sub=256, train_years=[0],
+                          train_days=[0.0], seed=0, reward_params=rp, constraints=cs)
+    orc.reset()
+    # (the reference computes these from float32 parameter scalars: float32 under NumPy >= 2, float64 under its pinned 1.26)
+    assert abs(env.max_profit / float(orc.reward.max_profit) - 1) < 2e-7
+    assert abs(env.min_profit / float(orc.reward.min_profit) - 1) < 2e-7
+    rng = np.random.default_rng(8)
+    seen_violation = False
+    for k in range(8):
+        a = rng.uniform(-1, 1, 6).astype(np.float32)
+        obs, rew, dones, infos = env.step(np.tile(a, (16, 1)))
+        ob, r, term, info = orc.step(a)
+        assert abs(r - rew[0]) < 1e-6
+        for key in INFO_KEYS:
+            assert abs(info[key] - infos[0][key]) < 1e-6 * max(1.0, abs(info[key])), key
+        seen_violation |= info["temp_violation"] > 0 or info["rh_violation"] > 0
+    assert seen_violation                  # the tightened box is actually violated, so the penalty path is exercised
+    env.close()
