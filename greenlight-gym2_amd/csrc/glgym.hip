@@ -176,8 +176,20 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
         make_crop_const<T, T>(pc, a.gasR, a.tCanMin, crLocal);
     }
     const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
+#if defined(GL_COEF_IN_LDS)
+    // experiment: tier-2 coefficients of each lane staged in LDS instead of VGPRs
+    __shared__ StepCoef<T> s_lds[WAVE];
+    {
+        StepCoef<T> tmp;
+        precompute(u, d, m, cr, tmp);
+        s_lds[lane] = tmp;
+    }
+    __syncthreads();
+    const StepCoef<T>& s = s_lds[lane];
+#else
     StepCoef<T> s;
     precompute(u, d, m, cr, s);
+#endif
     T del[NX];
     bool bad;
     const int retries = rk4_delta_guarded(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
