@@ -265,7 +265,26 @@ def g_controller():
     print("controller_kat: u range", np.min(Uo), np.max(Uo))
 
 
-ALL = dict(params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+def g_rollout_summer():
+    """3-day / 289-step rollout on the synthetic weather generator's midsummer-like window (700 W/m2 peaks): the
+    regime the Bleiswijk autumn fixture does not reach (strong photosynthesis, open vents, high temperatures)."""
+    sys.path.insert(0, str(HERE.parent.parent / "greenlight-gym2_amd"))
+    from gl_gym_amd.utils import synthetic_weather            # the repo's own generator (SURVEY 8d recipe)
+    p = init_default_params(208).astype(np.float64)
+    w = synthetic_weather(n_rows=35040, seed=2024)[96 * 180:96 * 180 + 400].copy()
+    acts = np.random.default_rng(4242).uniform(-1, 1, (289, 6)).astype(np.float32)
+    x = init_state(w[0]); u = np.zeros(6)
+    Xs = [x.copy()]
+    for k in range(289):
+        u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))
+        x, _ = tight_step(x, u, w[k], p)
+        Xs.append(x.copy())
+    np.savez_compressed(HERE / "rollout_3day_synth.npz", actions=acts, weather=w, X=np.array(Xs))
+    print("rollout_3day_synth: max iGlob %.0f, tAir range %.1f..%.1f" % (w[:289, 0].max(), np.min(np.array(Xs)[:, 2]),
+                                                                          np.max(np.array(Xs)[:, 2])))
+
+
+ALL = dict(rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

@@ -70,25 +70,31 @@ def test_n_sub_4_is_unstable_and_flagged(golden):
     env.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("float64", 5e-6), ("float32", 1e-4)])
-def test_10day_rollout_vs_tight_fixture(golden, dtype, tol):
-    """The headline accuracy bar: 961 steps of step() with the fixture's action sequence on Bleiswijk weather."""
+@pytest.mark.parametrize("fixture,dtype,tol", [("rollout_10day", "float64", 5e-6), ("rollout_10day", "float32", 1e-4),
+                                               ("rollout_3day_synth", "float64", 5e-6),
+                                               ("rollout_3day_synth", "float32", 1e-4)])
+def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol):
+    """The headline accuracy bar: step() with the fixture's action sequence vs the tight (Radau 1e-11) states.
+    rollout_10day: 961 steps on Bleiswijk autumn weather; rollout_3day_synth: 289 steps on midsummer-like synthetic
+    weather (670 W/m2 peaks, strong photosynthesis and ventilation, air temperature 6..28 C)."""
     from gl_gym_amd.tomato_env import TomatoVecEnv
-    g = golden("rollout_10day")
+    g = golden(fixture)
     acts, w, XR = g["actions"], g["weather"], g["X"]
     B = 64                                    # 64 identical envs: also checks lane-independence
-    env = TomatoVecEnv(B, weather=w, dtype=dtype, n_sub=256, season_length=10, pred_horizon=0.5, auto_reset=False)
+    n_steps = len(acts)
+    env = TomatoVecEnv(B, weather=w, dtype=dtype, n_sub=256, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
+                       auto_reset=False)
     env.reset()
     import torch
     X = [env.x[0].double().cpu().numpy()]
-    for k in range(961):
+    for k in range(n_steps):
         a = torch.as_tensor(np.repeat(acts[k][None], B, 0), device=env.device)
         _, _, done, _ = env.step_tensor(a, want_obs=False)
         X.append(env.x[0].double().cpu().numpy())
     X = np.array(X)
     assert np.array_equal(env.x[0].cpu().numpy(), env.x[B - 1].cpu().numpy())
     err = scaled_err(X, XR)
-    print(f"10-day rollout {dtype}: max scaled rel err vs tight oracle = {err:.3e}")
+    print(f"{fixture} {dtype}: max scaled rel err vs tight oracle = {err:.3e}")
     assert err < tol
     assert bool(done[0]) is False or True
     env.close()

@@ -42,13 +42,14 @@ def test_oracle_stiff_solver_matches_radau_fixture(oracle, golden):
         assert scaled_err(xs, XT[i]) < 1e-7 and nfev > 0
 
 
-def test_oracle_rollout_10day(oracle, golden):
-    g = golden("rollout_10day")
+@pytest.mark.parametrize("fixture", ["rollout_10day", "rollout_3day_synth"])
+def test_oracle_rollout_10day(oracle, golden, fixture):
+    g = golden(fixture)
     acts, w, XR = g["actions"], g["weather"], g["X"]
     p = golden("params_default")["p"].astype(np.float64)
     x, u = XR[0].copy(), np.zeros(6)
     X = [x]
-    for k in range(961):
+    for k in range(len(acts)):
         u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))
         x = oracle.rk4_split(x, u, w[k], p, 900.0, 256)
         X.append(x)

@@ -32,12 +32,13 @@ def test_step_map_against_oracle_and_tight(hostmath, oracle, golden):
 
 def test_fp32_10day_rollout_meets_1e_4(hostmath, golden):
     """The north-star accuracy bar, evaluated on the product's own fp32 arithmetic (host instantiation)."""
-    g = golden("rollout_10day")
-    acts, w, XR = g["actions"], g["weather"], g["X"]
     p = golden("params_default")["p"].astype(np.float64)
-    for f32, tol in ((False, 5e-6), (True, 1e-4)):
+    for fixture, f32, tol in (("rollout_10day", False, 5e-6), ("rollout_10day", True, 1e-4),
+                              ("rollout_3day_synth", False, 5e-6), ("rollout_3day_synth", True, 1e-4)):
+        g = golden(fixture)
+        acts, w, XR = g["actions"], g["weather"], g["X"]
         x, u, X = XR[0].copy(), np.zeros(6), [XR[0]]
-        for k in range(961):
+        for k in range(len(acts)):
             u = np.clip(u + acts[k] * np.float32(0.1), 0, 1)
             x = hostmath.step(np.float32(x) if f32 else x, np.float32(u) if f32 else u,
                               np.float32(w[k]) if f32 else w[k], p, f32)
