@@ -54,8 +54,7 @@ def main():
     obs = env.reset_tensor()
     t0 = time.time()
     for k in range(N1):
-        u = env.rule_based_controls(ctrl)
-        obs, rew, done, info = env.step_tensor(controls_t=u.to(env.tdtype))
+        obs, rew, done, info = env.step_tensor(controller=ctrl)     # glgym_rule_based + glgym_step, no host round trip
         rec0[k, :23] = obs[0, :23].cpu().numpy()
         rec0[k, 23] = float(rew[0])
         rec0[k, 24:] = info[idx, 0].cpu().numpy()

@@ -382,6 +382,69 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// rule-based controller (baseline.py:68-227), one thread per env, fp64 throughout
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void rule_based_kernel(glgym_rule_cfg c, int B, int ld, const T* __restrict__ x,
+                                                         const T* __restrict__ weather, int weather_rows,
+                                                         const int* __restrict__ w_off, const int* __restrict__ timestep,
+                                                         const float* __restrict__ start_day, const double* hour,
+                                                         const double* doy_in, double doy_inc, double hod_inc,
+                                                         T* __restrict__ control)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int ts = timestep[b];
+    int row = w_off[b] + ts;
+    row = row >= weather_rows ? weather_rows - 1 : (row < 0 ? 0 : row);
+    const T* w = weather + (size_t)row * ND;
+    const double iGlob = (double)w[0], tOut = (double)w[1], dli = (double)w[7], isDay = (double)w[8],
+                 isDaySmooth = (double)w[9];
+    const double co2Air = (double)x[b], tAir = (double)x[(size_t)2 * ld + b], vpAir = (double)x[(size_t)15 * ld + b];
+    const double hod = hour ? hour[b] : fmod((double)ts * hod_inc, 24.0);
+    const double doy = doy_in ? doy_in[b] : (double)start_day[b] + (double)ts * doy_inc;
+    // proportional band: lo + (hi-lo) / (1 + exp(-2/pBand * ln(100) * (v - setPt - pBand/2)))   (:226-227)
+    auto pband = [](double v, double sp, double band, double lo, double hi) {
+        return lo + (hi - lo) * (1.0 / (1.0 + exp(-2.0 / band * 4.605170185988092 * (v - sp - band * 0.5))));
+    };
+    const double tod = c.lamps_on <= c.lamps_off ? (double)(c.lamps_on < hod && hod < c.lamps_off)
+                                                 : (double)(c.lamps_on < hod || hod < c.lamps_off);              // :76-77
+    const double doy_ok = c.lamps_day_start <= c.lamps_day_stop
+                              ? (double)(c.lamps_day_start < doy && doy < c.lamps_day_stop)
+                              : (double)(c.lamps_day_start < doy || doy < c.lamps_day_stop);                   // :85-86
+    const double below_dli = (double)(dli < c.lamp_rad_sum_limit);
+    const double lamp_no_cons = (double)(iGlob < c.lamps_off_sun) * below_dli * tod * doy_ok;                   // :98
+    const double sw_on = fmax(0.0, fmin(1.0, hod - c.lamps_on + 1.0));                                          // :107
+    const double sw_off = fmax(0.0, fmin(1.0, c.lamps_off - hod + 1.0));                                        // :113
+    const double both = c.lamps_on == c.lamps_off ? 0.0
+                        : (c.lamps_on < c.lamps_off ? fmin(sw_on, sw_off) : fmax(sw_on, sw_off));               // :119-120
+    const double smooth_lamp = both * below_dli * doy_ok;                                                       // :128
+    const double day_inside = fmax(smooth_lamp, isDay);                                                         // :133
+    const double heat_sp = day_inside * c.temp_setpoint_day + (1.0 - day_inside) * c.temp_setpoint_night +
+                           c.heat_correction * lamp_no_cons;                                                    // :136
+    const double heat_max = heat_sp + c.heat_deadzone;
+    const double co2_sp = day_inside * c.co2_day;
+    const double co2_ppm = 1e6 * 8.3144598 * (tAir + 273.15) * (1e-6 * co2Air) / (101325.0 * 44.01e-3);         // :145
+    const double rh_in = 100.0 * vpAir / (610.78 * exp(17.2694 * tAir / (tAir + 238.3)));                       // :151
+    const double vent_heat = pband(tAir, heat_max, c.vent_heat_Pband, 0, 1);
+    const double vent_rh = pband(rh_in, c.rh_max + 0.0 * c.mech_dehumid_Pband, c.vent_rh_Pband, 0, 1);
+    const double vent_cold = pband(tAir, heat_sp - c.t_vent_off, c.vent_cold_Pband, 1, 0);
+    const double th_sp = isDay * c.thScrSpDay + (1.0 - isDay) * c.thScrSpNight;
+    const double th_cold = pband(tOut, th_sp, c.thScrPband, 0, 1);
+    const double th_heat = pband(tAir, heat_sp + c.thScrDeadZone, -c.thScrPband, 1, 0);
+    const double th_rh = fmax(pband(rh_in, c.rhMax + c.thScrRh, c.thScrRhPband, 1, 0), 1.0 - vent_cold);
+    const double lamp_on = lamp_no_cons * pband(tAir, heat_max + c.lampExtraHeat, -0.5, 0, 1) *
+                           (isDaySmooth + (1.0 - isDaySmooth)) *
+                           fmax(pband(rh_in, c.rhMax + c.blScrExtraRh, -0.5, 0, 1), 1.0 - vent_cold);           // :189-191
+    control[b] = (T)pband(tAir, heat_sp, c.tHeatBand, 0, 1);
+    control[(size_t)1 * ld + b] = (T)pband(co2_ppm, co2_sp, c.co2Band, 0, 1);
+    control[(size_t)2 * ld + b] = (T)fmin(th_cold, fmax(th_heat, th_rh));
+    control[(size_t)3 * ld + b] = (T)fmin(vent_cold, fmax(vent_heat, vent_rh));
+    control[(size_t)4 * ld + b] = (T)lamp_on;
+    control[(size_t)5 * ld + b] = (T)(c.useBlScr * (1.0 - isDaySmooth) * lamp_on);
+}
+
 // counter-based generator shared by the reset (episode start draw) and crop-noise kernels
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
                                               unsigned k1, unsigned* out)
@@ -949,6 +1012,30 @@ int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, 
     else
         hipLaunchKernelGGL((crop_noise_kernel<double>), grid, block, 0, st, (double*)crop_p, B, ld, h->p0_crop_dev,
                            (float)scale, (unsigned long long)seed, (unsigned long long)draw_index);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
+
+int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule_args* a, void* stream)
+{
+    if (!h || !cfg || !a || a->B < 1 || a->ld < a->B || !a->x || !a->weather || !a->w_off || !a->timestep || !a->control ||
+        a->weather_rows < 1 || (!a->start_day && !a->doy) || cfg->vent_heat_Pband == 0 || cfg->vent_rh_Pband == 0 ||
+        cfg->vent_cold_Pband == 0 || cfg->thScrPband == 0 || cfg->thScrRhPband == 0 || cfg->tHeatBand == 0 ||
+        cfg->co2Band == 0) {
+        g_err = "glgym_rule_based: bad arguments (null pointer, ld < B, or a zero proportional band)";
+        return GLGYM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((a->B + 255) / 256), block(256);
+    const double doy_inc = std::fmod(h->dt / 86400.0, 365.0), hod_inc = h->dt / 3600.0;
+    if (h->dtype == GLGYM_F32)
+        hipLaunchKernelGGL((rule_based_kernel<float>), grid, block, 0, st, *cfg, a->B, a->ld, (const float*)a->x,
+                           (const float*)a->weather, a->weather_rows, a->w_off, a->timestep, a->start_day, a->hour, a->doy,
+                           doy_inc, hod_inc, (float*)a->control);
+    else
+        hipLaunchKernelGGL((rule_based_kernel<double>), grid, block, 0, st, *cfg, a->B, a->ld, (const double*)a->x,
+                           (const double*)a->weather, a->weather_rows, a->w_off, a->timestep, a->start_day, a->hour,
+                           a->doy, doy_inc, hod_inc, (double*)a->control);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }

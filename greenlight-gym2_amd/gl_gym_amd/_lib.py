@@ -59,6 +59,23 @@ class VecNormArgs(C.Structure):
                 ("norm_reward", C.c_int32)]
 
 
+RULE_FIELDS = ("lamps_on", "lamps_off", "lamps_day_start", "lamps_day_stop", "lamps_off_sun", "lamp_rad_sum_limit",
+               "temp_setpoint_day", "temp_setpoint_night", "heat_correction", "heat_deadzone", "co2_day",
+               "vent_heat_Pband", "rh_max", "mech_dehumid_Pband", "vent_rh_Pband", "t_vent_off", "vent_cold_Pband",
+               "thScrSpDay", "thScrSpNight", "thScrPband", "thScrDeadZone", "thScrRh", "thScrRhPband", "lampExtraHeat",
+               "blScrExtraRh", "rhMax", "tHeatBand", "co2Band", "useBlScr")
+
+
+class RuleCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in RULE_FIELDS]
+
+
+class RuleArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("weather", C.c_void_p),
+                ("weather_rows", C.c_int32), ("w_off", C.c_void_p), ("timestep", C.c_void_p), ("start_day", C.c_void_p),
+                ("hour", C.c_void_p), ("doy", C.c_void_p), ("control", C.c_void_p)]
+
+
 # every symbol include/glgym.h declares, with its prototype
 _DP = C.POINTER(C.c_double)
 PROTOTYPES = {
@@ -78,6 +95,7 @@ PROTOTYPES = {
     "glgym_reset": (C.c_int, [C.c_void_p, C.POINTER(ResetArgs), C.c_void_p]),
     "glgym_crop_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                                    C.c_void_p]),
+    "glgym_rule_based": (C.c_int, [C.c_void_p, C.POINTER(RuleCfg), C.POINTER(RuleArgs), C.c_void_p]),
     "glgym_vecnorm": (C.c_int, [C.c_void_p, C.POINTER(VecNormArgs), C.c_void_p]),
     "glgym_timer_start": (C.c_int, [C.c_void_p, C.c_void_p]),
     "glgym_timer_stop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

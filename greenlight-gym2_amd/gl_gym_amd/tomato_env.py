@@ -259,17 +259,29 @@ class TomatoVecEnv:
         self._launch_obs(self.obs_t)
         return self.obs_t
 
-    def step_tensor(self, actions_t=None, controls_t=None, want_obs: bool = True):
-        """actions_t [B,6] f32 in [-1,1] (step) or controls_t [B,6] (step_raw_control).  Returns
+    def _launch_rule_based(self, controller, hour_t=None, doy_t=None):
+        """glgym_rule_based: controller.predict for every env, written to the SoA control buffer of step_raw_control."""
+        cfg = L.RuleCfg(*[float(getattr(controller, n)) for n in L.RULE_FIELDS])
+        a = L.RuleArgs(self.B, self.ld, self.x_T.data_ptr(), self.weather_t.data_ptr(), self.weather_rows,
+                       self.w_off_t.data_ptr(), self.timestep_t.data_ptr(), self.start_day_t.data_ptr(),
+                       hour_t.data_ptr() if hour_t is not None else None,
+                       doy_t.data_ptr() if doy_t is not None else None, self.ctrl_T.data_ptr())
+        L.check(self._lib.glgym_rule_based(self._h, C.byref(cfg), C.byref(a), self._stream()), "glgym_rule_based")
+
+    def step_tensor(self, actions_t=None, controls_t=None, want_obs: bool = True, controller=None):
+        """actions_t [B,6] f32 in [-1,1] (step), controls_t [B,6] (step_raw_control) or controller (a
+        RuleBasedController evaluated on the device, then step_raw_control).  Returns
         (obs [B,dim] f32, reward [B], done [B] uint8, info [11,B]) as device tensors; with auto_reset the
         finished envs are re-initialised and ``term_obs_t`` keeps their last observation."""
-        if (actions_t is None) == (controls_t is None):
-            raise ValueError("give exactly one of actions_t / controls_t")
+        if (actions_t is not None) + (controls_t is not None) + (controller is not None) != 1:
+            raise ValueError("give exactly one of actions_t / controls_t / controller")
         if actions_t is not None:
             self.action_t.copy_(actions_t.reshape(self.B, L.NU))
-        else:
+        elif controls_t is not None:
             self.ctrl_T[:, :self.B].copy_(controls_t.reshape(self.B, L.NU).t())
-        self._launch_step(raw_control=controls_t is not None)
+        else:
+            self._launch_rule_based(controller)
+        self._launch_step(raw_control=actions_t is None)
         if want_obs:
             self._launch_obs(self.obs_t)
         if self.auto_reset:      # SB3 semantics: finished envs restart; their last obs goes to term_obs_t
@@ -291,8 +303,11 @@ class TomatoVecEnv:
         self._actions = np.asarray(actions, dtype=np.float32)
 
     def step_wait(self):
-        torch = self.torch
-        obs_t, r_t, d_t, info_T = self.step_tensor(torch.as_tensor(self._actions, device=self.device))
+        return self._host_result(self.step_tensor(self.torch.as_tensor(self._actions, device=self.device)))
+
+    def _host_result(self, out):
+        """(obs, rewards, dones, infos) as SB3 consumes them, from step_tensor's device tensors."""
+        obs_t, r_t, d_t, info_T = out
         obs, rew = self._obs_to_host(obs_t), r_t.float().cpu().numpy()
         dones = d_t.cpu().numpy().astype(bool)
         # infos: SB3 wants a list of per-env dicts.  Built from two bulk D2H copies (info block, controls) with
@@ -360,9 +375,14 @@ class TomatoVecEnv:
         return self.start_day_t.double() + self.timestep_t.double() * ((self.dt / self.c) % 365)   # :126
 
     def rule_based_controls(self, controller):
-        """u[B,6] of a gl_gym_amd.baseline.RuleBasedController for the current state (experiments/evaluate_baseline.py:22)."""
-        return controller.predict(self.x.double(), self.current_weather().double(), self.hour_of_day(),
-                                  self.day_of_year())
+        """u[B,6] of a gl_gym_amd.baseline.RuleBasedController for the current state (experiments/evaluate_baseline.py:22),
+        computed by the glgym_rule_based kernel."""
+        self._launch_rule_based(controller)
+        return self.ctrl_T[:, :self.B].t().clone()
+
+    def step_rule_based(self, controller):
+        """One env-step under the rule-based controller, everything on the device (config 1, batched)."""
+        return self._host_result(self.step_tensor(controller=controller))
 
     def metrics(self) -> Dict[str, float]:
         if self.metrics_t is None:

@@ -21,6 +21,8 @@
  *   glgym_reset    <- TomatoEnv.reset (state part)               gl_gym/environments/tomato_env.py:262-266,
  *                     init_state                                  gl_gym/environments/utils.py:13-46
  *   glgym_crop_noise <- parametric_crop_uncertainty               gl_gym/environments/noise.py:3-23
+ *   glgym_rule_based <- RuleBasedController.predict              gl_gym/environments/baseline.py:68-227
+ *                     (constants gl_gym/configs/agents/rule_based.yml; caller experiments/evaluate_baseline.py:22)
  *   glgym_rhs      <- ODE(x,u,d,p) (test hook; no reference binding) gl_gym/environments/models/ode.hpp:6-124
  *
  * Layouts.  "SoA [n][ld]" = n planes of ld elements, element (i, b) at base[i*ld + b]; lane b of a
@@ -149,6 +151,34 @@ int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream);
  * (seed, stream_id), counter (env index, draw_index).  crop_p: SoA [34][ld] T. */
 int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, uint64_t seed, uint64_t draw_index,
                      void* stream);
+
+/* ---- rule-based controller (BASELINE config 1 "fixed rule-based actions") ------------------------------
+ * u[6] = RuleBasedController.predict(x, weather[w_off + timestep], env clocks) for every env of the shard, written in the
+ * SoA layout glgym_step consumes as `control` (step_raw_control).  Constants: the constructor arguments of
+ * baseline.py:22-66 in declaration order.  Computed in fp64 for either handle dtype (12 exp per env-step: free). */
+typedef struct {
+    double lamps_on, lamps_off, lamps_day_start, lamps_day_stop, lamps_off_sun, lamp_rad_sum_limit;
+    double temp_setpoint_day, temp_setpoint_night, heat_correction, heat_deadzone, co2_day;
+    double vent_heat_Pband, rh_max, mech_dehumid_Pband, vent_rh_Pband, t_vent_off, vent_cold_Pband;
+    double thScrSpDay, thScrSpNight, thScrPband, thScrDeadZone, thScrRh, thScrRhPband, lampExtraHeat;
+    double blScrExtraRh, rhMax, tHeatBand, co2Band, useBlScr;
+} glgym_rule_cfg;
+
+typedef struct {
+    int32_t B, ld;
+    const void* x;             /* SoA [28][ld] T */
+    const void* weather;       /* [weather_rows][10] T; row used = w_off[b] + timestep[b] (the row about to be integrated) */
+    int32_t weather_rows;
+    const int32_t* w_off;      /* [B] */
+    const int32_t* timestep;   /* [B] */
+    const float* start_day;    /* [B] day of year at reset: day_of_year = start_day + timestep*((dt/86400) mod 365),
+                                  hour_of_day = (timestep*dt/3600) mod 24   (tomato_env.py:126-128) */
+    const double* hour;        /* optional [B] explicit clocks (known-answer tests); NULL = derive as above */
+    const double* doy;
+    void* control;             /* SoA [6][ld] T out */
+} glgym_rule_args;
+
+int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule_args* a, void* stream);
 
 /* ---- on-device VecNormalize ---------------------------------------------------------------------
  * Replaces stable_baselines3.common.vec_env.VecNormalize (3rd party, pinned ==2.6.0 in the reference's requirements.txt)
