@@ -375,6 +375,9 @@ template <class T> struct StepCoef {
     T uTh, uBl, oneMinusUTh, oneMinusUBl, kTh, kBl, hTh, hBl;   // u2 u5 1-u2 1-u5 u2*p84 u5*p94 1.7u2 1.7u5
     // actuators
     T hBoilPipe, mcExtAir;
+    // ODE_pipe variant only (ode.hpp:184-189): track the measured pipe temperature d10 unless d10 < 1 or d12 > 0.
+    // Set by the caller after precompute(); dead (and removed by the compiler) in the default ODE instantiations.
+    T pipeTrack, tPipeSet;
 };
 
 // C-to-K offsets: the reference uses 273.15 everywhere except airMv(), whose offset is a C `float`
@@ -488,6 +491,8 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
     s.kTh = uTh * m.kThScr;  s.kBl = uBl * m.kBlScr;  s.hTh = T(1.7) * uTh;  s.hBl = T(1.7) * uBl;
     s.hBoilPipe = uBoil * m.boilPerFlr;
     s.mcExtAir = uCo2 * m.co2PerFlr;
+    s.pipeTrack = T(0);
+    s.tPipeSet = T(0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -495,7 +500,8 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
 // ---------------------------------------------------------------------------------------------------
 // HARVEST_IN_RHS = true gives the reference's complete right-hand side (test hook).  The integrator uses false:
 // the two harvest terms are advanced by their exact flow instead (harvest_flow below).
-template <class T, bool HARVEST_IN_RHS = true>
+// PIPE = true: the reference's ODE_pipe (ode.hpp:126-263) -- dxdt(9) follows the measured pipe temperature, dxdt(19) = 0.
+template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false>
 GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
 {
     using M = Math<T>;
@@ -751,6 +757,10 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
                            rLampFlr - rLampCan + iToLamp);
     dx[18] = m.iCapIntLamp * (-hIntLampAir - iToSky - iToCovIn - iToThScr - iToPipe - iToBlScr - iToFlr - iToCan - iToLamp);
     dx[19] = m.iCapGroPipe * (-rGroPipeCan - hGroPipeAir);
+    if (PIPE) {
+        dx[9] = (s.pipeTrack != T(0)) ? (s.tPipeSet - x[9]) : dx[9];      // ode.hpp:184-189
+        dx[19] = T(0);                                                    // ode.hpp:240
+    }
     dx[20] = m.iCapBlScr * (hAirBlScr + L * mvAirBlScr + rCanBlScr + rFlrBlScr + rPipeBlScr - hBlScrTop - rBlScrCovIn -
                             rBlScrSky - rBlScrThScr + rLampBlScr + iToBlScr);
     const T perDay = T(1.0 / 86400.0);
@@ -770,25 +780,33 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
 // optimisation level (fp32 and the host build were unaffected).  Out of line, each function fits its register budget.
 // ---------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
+template <bool PIPE>
 __device__ __noinline__ inline void rhs_stage_f64(const double* x, const StepCoef<double>* s, const ModelConst<double>* m,
                                                   const CropConst<double>* cr, double* dx)
 {
-    rhs<double, false>(x, *s, *m, *cr, dx);
+    rhs<double, false, PIPE>(x, *s, *m, *cr, dx);
 }
 #endif
-template <class T>
+template <class T, bool PIPE> struct RhsStage {
+    static GL_HD void run(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
+    {
+        rhs<T, false, PIPE>(x, s, m, cr, dx);
+    }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <bool PIPE> struct RhsStage<double, PIPE> {
+    static GL_HD void run(const double* x, const StepCoef<double>& s, const ModelConst<double>& m,
+                          const CropConst<double>& cr, double* dx)
+    {
+        rhs_stage_f64<PIPE>(x, &s, &m, &cr, dx);
+    }
+};
+#endif
+template <class T, bool PIPE = false>
 GL_HD void rhs_stage(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
 {
-    rhs<T, false>(x, s, m, cr, dx);
+    RhsStage<T, PIPE>::run(x, s, m, cr, dx);
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-template <>
-GL_HD void rhs_stage<double>(const double* x, const StepCoef<double>& s, const ModelConst<double>& m,
-                             const CropConst<double>& cr, double* dx)
-{
-    rhs_stage_f64(x, &s, &m, &cr, dx);
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Harvest switch (aux_states.hpp:75-79, 1184-1188):  dc/dt = -M / (1 + exp(-k (c - cMax))),  M = 5e4, k = 2*4.6052/1e4.
@@ -797,6 +815,7 @@ GL_HD void rhs_stage<double>(const double* x, const StepCoef<double>& s, const M
 // It is a scalar autonomous ODE with a closed-form flow: with z = k (c - cMax),  z - exp(-z) = z0 - exp(-z0) - k M t,
 // i.e. w = exp(-z) solves w + ln w = D (Wright omega).  harvest_flow returns the INCREMENT of c over time t.
 //   * z0 < -40: the rate is below 2e-13 mg/s -> 0.
+//   * z0 - k M t > 40: the rate stays saturated at M (to 4e-18) over the whole interval -> -M t (and w would underflow).
 //   * first Newton step |dz| < 0.03 (always on nominal trajectories): increment form (Newton on dz with expm1), so
 //     that the tiny change is not lost in fp32;
 //   * else: Newton on w + ln w = D from the asymptotic initial guess (monotone, no overflow).
@@ -808,6 +827,7 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
     const T z0 = k * (c - cMax);
     const T a = k * T(5e4) * t;
     if (z0 < T(-40)) return T(0);
+    if (z0 - a > T(40)) return T(-5e4) * t;
     const T E0 = M::exp(-z0);
     T dz = -a * M::rcp(one + E0);                                     // first Newton step from dz = 0
     if (dz > T(-0.03)) {
@@ -833,7 +853,7 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
 // Each sub-step is Strang-split: exact harvest flow (h/2) -> classical RK4 of the remaining RHS (h) -> harvest (h/2).
 // Returns del (x(dt) - x0); the caller adds it once.
 // ---------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, bool PIPE = false>
 GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                      int n_sub, T* del)
 {
@@ -849,16 +869,16 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
         // state's magnitude either way; only the ACCUMULATION below has to stay in delta form)
 #pragma unroll
         for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-        rhs_stage(y, s, m, cr, k);
+        rhs_stage<T, PIPE>(y, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
-        rhs_stage(xs, s, m, cr, k);
+        rhs_stage<T, PIPE>(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
-        rhs_stage(xs, s, m, cr, k);
+        rhs_stage<T, PIPE>(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
-        rhs_stage(xs, s, m, cr, k);
+        rhs_stage<T, PIPE>(xs, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) del[i] += h6 * (acc[i] + k[i]);
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, h2);
@@ -883,14 +903,14 @@ template <class T> GL_HD bool all_finite(const T* v)
     return chk == T(0);
 }
 
-template <class T>
+template <class T, bool PIPE = false>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                             int n_sub, T* del, bool* failed)
 {
     int n = n_sub, extra = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        rk4_delta(x0, s, m, cr, dt, n, del);
+        rk4_delta<T, PIPE>(x0, s, m, cr, dt, n, del);
         ok = all_finite(del);
         if (ok) break;
         n *= 2;

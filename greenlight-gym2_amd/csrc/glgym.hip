@@ -105,6 +105,7 @@ template <class T> struct StepArgsT {
     T* reward; T* info; unsigned char* done; float* metrics;
     T dt; int n_sub;
     T gasR, tCanMin;
+    int nd;                     // weather row stride (10, or 14 with the measured-pipe columns of ODE_pipe)
 };
 
 template <class T> __device__ __forceinline__ T wave_sum(T v)
@@ -127,7 +128,8 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #ifndef GL_STEP_WAVES_PER_SIMD
 #define GL_STEP_WAVES_PER_SIMD 1
 #endif
-template <class T, bool PER_ENV_CROP, bool DEFAULT_P>
+// PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
+template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false>
 __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
     row = row < 0 ? 0 : (row >= a.weather_rows ? a.weather_rows - 1 : row);
     T d[7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) d[j] = a.weather[(size_t)row * ND + j];
+    for (int j = 0; j < 7; ++j) d[j] = a.weather[(size_t)row * a.nd + j];
 
     // ---- tier 2, then the sub-stepped RK4
     CropConst<T> crLocal;
@@ -189,10 +191,15 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
 #else
     StepCoef<T> s;
     precompute(u, d, m, cr, s);
+    if (PIPE) {                                                           // ode.hpp:184-189
+        const T tPipe = a.weather[(size_t)row * a.nd + 10], swOff = a.weather[(size_t)row * a.nd + 12];
+        s.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
+        s.tPipeSet = tPipe;
+    }
 #endif
     T del[NX];
     bool bad;
-    const int retries = rk4_delta_guarded(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
+    const int retries = rk4_delta_guarded<T, PIPE>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -253,17 +260,17 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
 // ---------------------------------------------------------------------------------------------------
 // reference-compatible step map / RHS with row-major double I/O (B small; B = 1 for the drop-in evalF)
 // ---------------------------------------------------------------------------------------------------
-template <class T, bool PER_ENV_CROP>
+template <class T, bool PER_ENV_CROP, bool PIPE = false>
 __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
                                                      const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
-                                                     ModelConst<T> m, double* x_next, int rhs_only)
+                                                     ModelConst<T> m, double* x_next, int rhs_only, int nd)
 {
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= B) return;
     T x0[NX], uu[NU], dd[7];
     for (int i = 0; i < NX; ++i) x0[i] = T(x[(size_t)b * NX + i]);
     for (int i = 0; i < NU; ++i) uu[i] = T(u[(size_t)b * NU + i]);
-    for (int i = 0; i < 7; ++i) dd[i] = T(d[(size_t)b * ND + i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[(size_t)b * nd + i]);
     CropConst<T> crLocal;
     if (PER_ENV_CROP) {
         T pc[NCROP];
@@ -273,15 +280,20 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
     StepCoef<T> s;
     precompute(uu, dd, m, cr, s);
+    if (PIPE) {
+        const T tPipe = T(d[(size_t)b * nd + 10]), swOff = T(d[(size_t)b * nd + 12]);
+        s.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
+        s.tPipeSet = tPipe;
+    }
     if (rhs_only) {
         T k[NX];
-        rhs(x0, s, m, cr, k);
+        rhs<T, true, PIPE>(x0, s, m, cr, k);
         for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)k[i];
         return;
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
+    rk4_delta_guarded<T, PIPE>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
     for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
 }
 
@@ -295,6 +307,7 @@ template <class T> struct ObsArgsT {
     const int* w_off; const int* timestep; const float* start_day;
     int Np; float* obs; double doy_inc, hod_inc;     // (dt/86400) mod 365 [days], dt/3600 [h] per env-step
     const unsigned char* mask; float* term_obs;
+    int nd;                                          // weather row stride
 };
 
 // 8 consecutive env rows = one contiguous span of the row-major output.  Phase 1: 8 x 23 lanes convert the
@@ -339,7 +352,7 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
                 } else if (j < 13) {                         // controls (:108-112)
                     v = (float)a.u[(size_t)(j - 7) * a.ld + b];
                 } else if (j < 18) {                         // current weather (:129-136)
-                    const T* w = a.weather + (size_t)base * ND;
+                    const T* w = a.weather + (size_t)base * a.nd;
                     const float tOut = (float)w[1];
                     const int c = j - 13;
                     if (c == 2) v = fminf(fmaxf(100.0f * (float)w[2] * __builtin_amdgcn_rcpf(sat_vp(tOut)), 0.0f), 100.0f);
@@ -374,7 +387,7 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
                 const int q = j - NCORE, i = q / 5, c = q - i * 5;
                 int row = base_s[r] + i + 1;
                 row = row >= a.weather_rows ? a.weather_rows - 1 : (row < 0 ? 0 : row);
-                v = (float)a.weather[(size_t)row * ND + c];
+                v = (float)a.weather[(size_t)row * a.nd + c];
             }
             out[e] = v;
         }
@@ -391,14 +404,14 @@ __global__ __launch_bounds__(256) void rule_based_kernel(glgym_rule_cfg c, int B
                                                          const int* __restrict__ w_off, const int* __restrict__ timestep,
                                                          const float* __restrict__ start_day, const double* hour,
                                                          const double* doy_in, double doy_inc, double hod_inc,
-                                                         T* __restrict__ control)
+                                                         T* __restrict__ control, int nd)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int ts = timestep[b];
     int row = w_off[b] + ts;
     row = row >= weather_rows ? weather_rows - 1 : (row < 0 ? 0 : row);
-    const T* w = weather + (size_t)row * ND;
+    const T* w = weather + (size_t)row * nd;
     const double iGlob = (double)w[0], tOut = (double)w[1], dli = (double)w[7], isDay = (double)w[8],
                  isDaySmooth = (double)w[9];
     const double co2Air = (double)x[b], tAir = (double)x[(size_t)2 * ld + b], vpAir = (double)x[(size_t)15 * ld + b];
@@ -467,7 +480,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 template <class T>
 __global__ void reset_kernel(int B, int ld, const unsigned char* mask, T* x, T* u, int* timestep, const T* weather,
                              int weather_rows, int* w_off, const int* start_rows, const float* start_days, int n_starts,
-                             float* start_day, int* episode, unsigned long long seed)
+                             float* start_day, int* episode, unsigned long long seed, int nd)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || (mask && !mask[b])) return;
@@ -482,7 +495,7 @@ __global__ void reset_kernel(int B, int ld, const unsigned char* mask, T* x, T* 
     }
     int r = w_off[b];
     r = r < 0 ? 0 : (r >= weather_rows ? weather_rows - 1 : r);
-    const double co2Out = (double)weather[(size_t)r * ND + 3], tSoOut = (double)weather[(size_t)r * ND + 6];
+    const double co2Out = (double)weather[(size_t)r * nd + 3], tSoOut = (double)weather[(size_t)r * nd + 6];
     const double tAir = 16.5;
     double xi[NX];
     xi[0] = xi[1] = co2Out;
@@ -653,6 +666,8 @@ struct glgym_handle_s {
     RewardConst<double> rd;
     double max_profit = 0, min_profit = 0, fixed_costs = 0;
     float* p0_crop_dev = nullptr;       // shared p[128..161] as f32 (noise kernel input)
+    int nd = ND;                        // weather / disturbance row stride: 10, or up to 16 (ODE_pipe reads columns 10, 12)
+    int variant = GLGYM_ODE;            // GLGYM_ODE | GLGYM_ODE_PIPE
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-pointer entry points
@@ -690,9 +705,9 @@ const char* glgym_last_error(void) { return g_err.c_str(); }
 int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int dtype, int n_sub, int device,
                  glgym_handle* out)
 {
-    if (!out || !p || nx != NX || nu != NU || nd != ND || np != NP || !(dt > 0) || n_sub < 1 ||
+    if (!out || !p || nx != NX || nu != NU || nd < ND || nd > 16 || np != NP || !(dt > 0) || n_sub < 1 ||
         (dtype != GLGYM_F32 && dtype != GLGYM_F64)) {
-        g_err = "glgym_create: expected nx=28 nu=6 nd=10 np=208, dt>0, n_sub>=1, dtype in {F32,F64}";
+        g_err = "glgym_create: expected nx=28 nu=6 nd=10..16 np=208, dt>0, n_sub>=1, dtype in {F32,F64}";
         return GLGYM_EINVAL;
     }
     int n_dev = 0;
@@ -703,7 +718,7 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     HIPCHK(hipSetDevice(device));
     glgym_handle h = new (std::nothrow) glgym_handle_s();
     if (!h) return GLGYM_ENOMEM;
-    h->device = device; h->dtype = dtype; h->n_sub = n_sub; h->dt = dt;
+    h->device = device; h->dtype = dtype; h->n_sub = n_sub; h->dt = dt; h->nd = nd;
     std::memcpy(h->p, p, sizeof h->p);
     default_reward(h->rcfg);
     if (const char* e = std::getenv("GLGYM_GENERIC")) h->use_specialised = (e[0] == '1') ? 0 : 1;
@@ -733,6 +748,16 @@ int glgym_set_params(glgym_handle h, const double* p)
     if (!h || !p) return GLGYM_EINVAL;
     std::memcpy(h->p, p, sizeof h->p);
     return refresh(h);
+}
+
+int glgym_set_model_variant(glgym_handle h, int variant)
+{
+    if (!h || (variant != GLGYM_ODE && variant != GLGYM_ODE_PIPE) || (variant == GLGYM_ODE_PIPE && h->nd < 14)) {
+        g_err = "glgym_set_model_variant: GLGYM_ODE or GLGYM_ODE_PIPE (the latter needs a handle created with nd >= 14)";
+        return GLGYM_EINVAL;
+    }
+    h->variant = variant;
+    return GLGYM_OK;
 }
 
 int glgym_set_n_sub(glgym_handle h, int n_sub)
@@ -776,12 +801,19 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
                      const double* dd, const double* dcrop, int B, double* dout, int rhs_only)
 {
     const dim3 grid((B + WAVE - 1) / WAVE), block(WAVE);
-    if (dcrop)
+    if (h->variant == GLGYM_ODE_PIPE) {
+        if (dcrop) {
+            g_err = "glgym_evalF: per-row parameter blocks are not supported with GLGYM_ODE_PIPE";
+            return GLGYM_EINVAL;
+        }
+        hipLaunchKernelGGL((evalf_kernel<T, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+    } else if (dcrop)
         hipLaunchKernelGGL((evalf_kernel<T, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only);
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
     else
         hipLaunchKernelGGL((evalf_kernel<T, false>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only);
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }
@@ -803,22 +835,22 @@ static int evalf_impl(glgym_handle h, const double* x, const double* u, const do
             for (int i = 0; i < NP; ++i)
                 if ((i < CROP0 || i >= CROP0 + NCROP) && p[(size_t)b * NP + i] != p[i]) {
                     for (int r = 0; r < B; ++r) {
-                        const int rc = evalf_impl(h, x + (size_t)r * NX, u + (size_t)r * NU, d + (size_t)r * ND,
+                        const int rc = evalf_impl(h, x + (size_t)r * NX, u + (size_t)r * NU, d + (size_t)r * h->nd,
                                                   p + (size_t)r * NP, 1, 1, out + (size_t)r * NX, rhs_only);
                         if (rc != GLGYM_OK) return rc;
                     }
                     return GLGYM_OK;
                 }
     }
-    const size_t n_in = (size_t)B * (NX + NU + ND + (per_row ? NCROP : 0));
+    const size_t n_in = (size_t)B * (NX + NU + h->nd + (per_row ? NCROP : 0));
     int rc = ensure_scratch(h, n_in + (size_t)B * NX);
     if (rc != GLGYM_OK) return rc;
     double* dx = h->scratch; double* du = dx + (size_t)B * NX; double* dd = du + (size_t)B * NU;
-    double* dcrop = per_row ? dd + (size_t)B * ND : nullptr;
+    double* dcrop = per_row ? dd + (size_t)B * h->nd : nullptr;
     double* dout = h->scratch + n_in;
     HIPCHK(hipMemcpy(dx, x, (size_t)B * NX * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(du, u, (size_t)B * NU * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dd, d, (size_t)B * ND * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dd, d, (size_t)B * h->nd * sizeof(double), hipMemcpyHostToDevice));
     if (per_row) {
         std::vector<double> crop((size_t)B * NCROP);
         for (int b = 0; b < B; ++b)
@@ -865,8 +897,17 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     k.weather = (const T*)a->weather; k.weather_rows = a->weather_rows;
     k.w_off = a->w_off; k.timestep = a->timestep; k.crop_p = (const T*)a->crop_p; k.N = a->N;
     k.reward = (T*)a->reward; k.info = (T*)a->info; k.done = a->done; k.metrics = a->metrics;
-    k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]);
+    k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]); k.nd = h->nd;
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
+    if (h->variant == GLGYM_ODE_PIPE) {
+        if (a->crop_p) {
+            g_err = "glgym_step: per-env crop parameters are not supported with GLGYM_ODE_PIPE";
+            return GLGYM_EINVAL;
+        }
+        hipLaunchKernelGGL((step_kernel<T, false, false, true>), grid, block, 0, st, k, m, rw);
+        HIPCHK(hipGetLastError());
+        return GLGYM_OK;
+    }
     // fp64 (parity configuration) always takes the generic kernel: its RHS is an out-of-line call that receives the
     // constant block by address, and only the kernarg copy has a usable one.
     const bool def = h->use_specialised && sizeof(T) == 4 && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
@@ -898,7 +939,7 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     ObsArgsT<T> k;
     k.B = a->B; k.ld = a->ld; k.x = (const T*)a->x; k.u = (const T*)a->u; k.weather = (const T*)a->weather;
     k.weather_rows = a->weather_rows; k.w_off = a->w_off; k.timestep = a->timestep; k.start_day = a->start_day;
-    k.Np = a->Np; k.obs = a->obs; k.mask = a->mask; k.term_obs = a->term_obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0;
+    k.Np = a->Np; k.obs = a->obs; k.mask = a->mask; k.term_obs = a->term_obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0; k.nd = h->nd;
     int blocks = (a->B + 7) / 8;                 // 8 env rows per block-iteration
     if (blocks > 4096) blocks = 4096;            // grid-stride beyond that
     hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), 0, st, k);
@@ -990,12 +1031,12 @@ int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
     if (h->dtype == GLGYM_F32)
         hipLaunchKernelGGL((reset_kernel<float>), grid, block, 0, st, a->B, a->ld, a->mask, (float*)a->x, (float*)a->u,
                            a->timestep, (const float*)a->weather, a->weather_rows, a->w_off, a->start_rows, a->start_days,
-                           a->n_starts, a->start_day, a->episode, (unsigned long long)a->seed);
+                           a->n_starts, a->start_day, a->episode, (unsigned long long)a->seed, h->nd);
     else
         hipLaunchKernelGGL((reset_kernel<double>), grid, block, 0, st, a->B, a->ld, a->mask, (double*)a->x,
                            (double*)a->u, a->timestep, (const double*)a->weather, a->weather_rows, a->w_off,
                            a->start_rows, a->start_days, a->n_starts, a->start_day, a->episode,
-                           (unsigned long long)a->seed);
+                           (unsigned long long)a->seed, h->nd);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }
@@ -1031,11 +1072,11 @@ int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule
     if (h->dtype == GLGYM_F32)
         hipLaunchKernelGGL((rule_based_kernel<float>), grid, block, 0, st, *cfg, a->B, a->ld, (const float*)a->x,
                            (const float*)a->weather, a->weather_rows, a->w_off, a->timestep, a->start_day, a->hour, a->doy,
-                           doy_inc, hod_inc, (float*)a->control);
+                           doy_inc, hod_inc, (float*)a->control, h->nd);
     else
         hipLaunchKernelGGL((rule_based_kernel<double>), grid, block, 0, st, *cfg, a->B, a->ld, (const double*)a->x,
                            (const double*)a->weather, a->weather_rows, a->w_off, a->timestep, a->start_day, a->hour,
-                           a->doy, doy_inc, hod_inc, (double*)a->control);
+                           a->doy, doy_inc, hod_inc, (double*)a->control, h->nd);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }

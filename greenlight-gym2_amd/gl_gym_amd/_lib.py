@@ -11,6 +11,7 @@ LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
 
 NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 9
 F32, F64 = 0, 1
+ODE, ODE_PIPE = 0, 1
 OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "glgym_destroy": (C.c_int, [C.c_void_p]),
     "glgym_set_params": (C.c_int, [C.c_void_p, _DP]),
     "glgym_set_n_sub": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_model_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_reward": (C.c_int, [C.c_void_p, C.POINTER(RewardCfg)]),
     "glgym_get_reward_scale": (C.c_int, [C.c_void_p, _DP, _DP, _DP]),
     "glgym_evalF": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),

@@ -18,7 +18,9 @@ from .parameters import init_default_params
 
 
 class GreenLight:
-    def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=256, device=0):
+    def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=256, device=0, variant="ode"):
+        """nd = 10, or 14 as in experiments/gl_predefined_controls.py:95 (rows carry the measured pipe columns).
+        variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         self._lib = L.load()
         self.nx, self.nu, self.nd, self.np = int(nx), int(nu), int(nd), int(np_)
         self.dt = float(dt)
@@ -28,6 +30,10 @@ class GreenLight:
                                     L.F64 if str(dtype) in ("float64", "f64", "double") else L.F32, int(n_sub),
                                     int(device), C.byref(self._h))
         L.check(rc, "glgym_create")
+        if variant not in ("ode", "ode_pipe"):
+            raise ValueError("variant must be 'ode' or 'ode_pipe'")
+        if variant == "ode_pipe":
+            L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
 
     @property
     def handle(self):
@@ -47,10 +53,10 @@ class GreenLight:
         return self.evalF_batch(x, u, d, p)[0].tolist()
 
     def evalF_batch(self, x, u, d, p=None):
-        """Row-major batch version: x[B,28], u[B,6], d[B,10], p[208] or p[B,208] -> ndarray [B,28]."""
+        """Row-major batch version: x[B,28], u[B,6], d[B,nd], p[208] or p[B,208] -> ndarray [B,28]."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         B = 1 if x.ndim == 1 else x.shape[0]
-        x, u, d = self._as(x, L.NX, B), self._as(u, L.NU, B), self._as(d, L.ND, B)
+        x, u, d = self._as(x, L.NX, B), self._as(u, L.NU, B), self._as(d, self.nd, B)
         out = np.empty((B, L.NX))
         if p is None:
             pp, rows = None, 1
@@ -70,7 +76,7 @@ class GreenLight:
         """dx/dt with the handle's parameter block (test hook)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         B = 1 if x.ndim == 1 else x.shape[0]
-        x, u, d = self._as(x, L.NX, B), self._as(u, L.NU, B), self._as(d, L.ND, B)
+        x, u, d = self._as(x, L.NX, B), self._as(u, L.NU, B), self._as(d, self.nd, B)
         out = np.empty((B, L.NX))
         L.check(self._lib.glgym_rhs(self._h, x.ctypes.data_as(L._DP), u.ctypes.data_as(L._DP),
                                     d.ctypes.data_as(L._DP), B, out.ctypes.data_as(L._DP)), "glgym_rhs")

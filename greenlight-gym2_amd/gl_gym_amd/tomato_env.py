@@ -115,7 +115,10 @@ class TomatoVecEnv:
                  n_sub: int = 256, device: str = "cuda:0", seed: int = 0, uncertainty_scale: float = 0.0,
                  start_rows: Optional[Sequence[int]] = None, start_days: Optional[Sequence[float]] = None,
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
-                 auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None):
+                 auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None,
+                 model_variant: str = "ode"):
+        """weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
+        (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise L.GlgymError("TomatoVecEnv needs a HIP device (torch.cuda.is_available() is False); "
@@ -128,7 +131,11 @@ class TomatoVecEnv:
         self.ld = (self.B + 63) // 64 * 64
         self.dt = float(dt)
         self.c = 86400
-        self.nx, self.nu, self.nd, self.num_params = L.NX, L.NU, L.ND, L.NP
+        self.nx, self.nu, self.num_params = L.NX, L.NU, L.NP
+        self.nd = L.ND if weather is None else int(np.asarray(weather).shape[1])
+        if model_variant not in ("ode", "ode_pipe"):
+            raise ValueError("model_variant must be 'ode' or 'ode_pipe'")
+        self.model_variant = model_variant
         self.season_length = season_length
         self.N = int(season_length * self.c / self.dt)                     # base_env.py:88
         self.Np = int(pred_horizon * self.c / self.dt)                     # base_env.py:80
@@ -144,9 +151,11 @@ class TomatoVecEnv:
         self.p = np.asarray(init_default_params(L.NP) if params is None else params, dtype=np.float32)
         self._h = C.c_void_p()
         p64 = np.ascontiguousarray(self.p, dtype=np.float64)
-        L.check(self._lib.glgym_create(L.NX, L.NU, L.ND, L.NP, self.dt, p64.ctypes.data_as(L._DP),
+        L.check(self._lib.glgym_create(L.NX, L.NU, self.nd, L.NP, self.dt, p64.ctypes.data_as(L._DP),
                                        L.F64 if self.f64 else L.F32, self.n_sub, self.device.index or 0,
                                        C.byref(self._h)), "glgym_create")
+        if model_variant == "ode_pipe":
+            L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         rp = dict(DEFAULT_REWARD, **(reward_params or {}))
         cs = dict(DEFAULT_CONSTRAINTS, **(constraints or {}))
         self.reward_params, self.constraints = rp, cs
@@ -336,6 +345,13 @@ class TomatoVecEnv:
                                                                               device=self.device))
         return self._obs_to_host(obs_t), r_t.float().cpu().numpy(), d_t.cpu().numpy().astype(bool), info_T.cpu().numpy()
 
+    def step_raw_control_pipeinput(self, controls):
+        """tomato_env.py:175-191: controls applied directly, no noise / observation / info; returns (x [B,28], terminated [B])."""
+        torch = self.torch
+        _, _, d_t, _ = self.step_tensor(controls_t=torch.as_tensor(np.asarray(controls), dtype=self.tdtype,
+                                                                   device=self.device), want_obs=False)
+        return self.x.double().cpu().numpy(), d_t.cpu().numpy().astype(bool)
+
     def _indices(self, indices):
         if indices is None:
             return list(range(self.B))
@@ -420,8 +436,8 @@ class TomatoEnv:
 
     def __init__(self, weather=None, params=None, dt=900.0, season_length=60, pred_horizon=0.5, dtype="float64",
                  n_sub=256, device="cuda:0", uncertainty_scale=0.0, start_day=0.0, growth_year=2010,
-                 reward_params=None, constraints=None, location="synthetic", training=True):
-        self.vec = TomatoVecEnv(1, weather=weather, params=params, dt=dt, season_length=season_length,
+                 reward_params=None, constraints=None, location="synthetic", training=True, model_variant="ode"):
+        self.vec = TomatoVecEnv(1, model_variant=model_variant, weather=weather, params=params, dt=dt, season_length=season_length,
                                 pred_horizon=pred_horizon, dtype=dtype, n_sub=n_sub, device=device,
                                 uncertainty_scale=uncertainty_scale, start_rows=[0], start_days=[start_day],
                                 reward_params=reward_params, constraints=constraints, auto_reset=False)
@@ -465,6 +481,11 @@ class TomatoEnv:
         t = self.vec.torch
         return self._finish(self.vec.step_tensor(controls_t=t.as_tensor(np.asarray(control).reshape(1, 6),
                                                                         dtype=self.vec.tdtype, device=self.vec.device)))
+
+    def step_raw_control_pipeinput(self, control):
+        x, term = self.vec.step_raw_control_pipeinput(np.asarray(control).reshape(1, 6))
+        self.terminated = bool(term[0])
+        return x[0], self.terminated
 
     def set_crop_state(self, cBuf, cLeaf, cStem, cFruit, tCanSum):
         for i, v in zip((22, 23, 24, 25, 26), (cBuf, cLeaf, cStem, cFruit, tCanSum)):

@@ -40,7 +40,7 @@ extern "C" {
 
 #define GLGYM_NX 28
 #define GLGYM_NU 6
-#define GLGYM_ND 10
+#define GLGYM_ND 10        /* columns the model reads; glgym_create accepts nd = 10..16 = row stride of weather / d */
 #define GLGYM_NP 208
 #define GLGYM_NCROP 34      /* p[128..161], the block noise.py perturbs */
 #define GLGYM_NINFO 11      /* EPI, revenue, variable_costs, fixed_costs, co2_cost, heat_cost, elec_cost,
@@ -51,6 +51,13 @@ extern "C" {
 typedef struct glgym_handle_s* glgym_handle;
 
 typedef enum { GLGYM_F32 = 0, GLGYM_F64 = 1 } glgym_dtype;
+
+/* Right-hand side variants of gl_gym/environments/models/ode.hpp.  GLGYM_ODE = ODE (:6-124), what the reference's
+ * compiled module integrates.  GLGYM_ODE_PIPE = ODE_pipe (:126-263): columns 10..13 of each weather / d row are
+ * (tPipe, tGroPipe, pipeSwitchOff, groPipeSwitchOff); dxdt(9) = d10 - x9 unless d10 < 1 or d12 > 0, dxdt(19) = 0.
+ * Its tracking term has rate 1 1/s: keep dt / n_sub below 2.7 s (dt = 300, n_sub = 256 in
+ * experiments/gl_predefined_controls.py's setting). */
+typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
 
 typedef enum {
     GLGYM_OK = 0,
@@ -76,7 +83,7 @@ typedef struct {
     void* u;                   /* SoA [6][ld]  T, in/out: previous control in, applied control out */
     const float* action;       /* [B][6] row-major f32 in [-1,1]: u <- clip(u + 0.1f*a, 0, 1)   (step)            */
     const void* control;       /* SoA [6][ld] T: u <- control                                    (step_raw_control) */
-    const void* weather;       /* [weather_rows][10] row-major T, shared by all envs            */
+    const void* weather;       /* [weather_rows][nd] row-major T (nd of glgym_create), shared by all envs */
     int32_t weather_rows;
     const int32_t* w_off;      /* [B] first weather row of each env's episode                    */
     int32_t* timestep;         /* [B] in/out; row integrated over = w_off[b] + timestep[b]; then ++ */
@@ -135,6 +142,7 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
 int glgym_destroy(glgym_handle h);
 int glgym_set_params(glgym_handle h, const double* p);
 int glgym_set_n_sub(glgym_handle h, int n_sub);
+int glgym_set_model_variant(glgym_handle h, int variant);   /* GLGYM_ODE_PIPE needs a handle created with nd >= 14 */
 int glgym_set_reward(glgym_handle h, const glgym_reward_cfg* cfg);
 int glgym_get_reward_scale(glgym_handle h, double* max_profit, double* min_profit, double* fixed_costs);
 

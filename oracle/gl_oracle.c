@@ -550,16 +550,47 @@ static double harvest_flow_ref(double c, double cmax, double t)
     return cmax + 0.5 * (lo + hi) / k;
 }
 
-static void rhs_no_harvest(const double *x, const double *u, const double *d, const double *p, double *dx)
+/* ODE_pipe (ode.hpp:126-263): the variant that tracks MEASURED pipe temperatures.  d has 14 entries: 10 tPipe,
+ * 11 tGroPipe, 12 pipeSwitchOff, 13 groPipeSwitchOff.  update() is the same (reads d[0..6]); only two balances differ:
+ *   dxdt(9)  = if_else(d(10) < 1 || d(12) > 0, tPipeOff, tPipeOn)   (:184-189; tPipeOff is ODE's dxdt(9) expression)
+ *   dxdt(19) = 0                                                     (:236-240) */
+void gl_oracle_rhs_pipe(const double *x, const double *u, const double *d, const double *p, double *dx,
+                        double *aux_out)
+{
+    gl_oracle_rhs(x, u, d, p, dx, aux_out);
+    const double tPipeOn = d[10] - x[9];
+    const double tPipeOff = dx[9];
+    dx[9] = ((d[10] < 1.0) || (d[12] > 0.0)) ? tPipeOff : tPipeOn;
+    dx[19] = 0.0;
+}
+
+static void rhs_no_harvest(const double *x, const double *u, const double *d, const double *p, double *dx, int pipe)
 {
     double a[GL_NAUX];
-    gl_oracle_rhs(x, u, d, p, dx, a);
+    if (pipe) gl_oracle_rhs_pipe(x, u, d, p, dx, a);
+    else gl_oracle_rhs(x, u, d, p, dx, a);
     dx[23] += a[214];
     dx[25] += a[215];
 }
 
+static void rk4_split_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                           double *x1, int pipe);
+
 void gl_oracle_rk4_split(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                          double *x1)
+{
+    rk4_split_impl(x0, u, d, p, dt, n_sub, x1, 0);
+}
+
+/* the same scheme on ODE_pipe (d: 14 entries) */
+void gl_oracle_rk4_split_pipe(const double *x0, const double *u, const double *d, const double *p, double dt,
+                              int n_sub, double *x1)
+{
+    rk4_split_impl(x0, u, d, p, dt, n_sub, x1, 1);
+}
+
+static void rk4_split_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                           double *x1, int pipe)
 {
     double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX];
     const double h = dt / (double)n_sub;
@@ -567,13 +598,13 @@ void gl_oracle_rk4_split(const double *x0, const double *u, const double *d, con
     for (int s = 0; s < n_sub; ++s) {
         x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
         x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
-        rhs_no_harvest(x, u, d, p, k1);
+        rhs_no_harvest(x, u, d, p, k1, pipe);
         for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
-        rhs_no_harvest(xs, u, d, p, k2);
+        rhs_no_harvest(xs, u, d, p, k2, pipe);
         for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
-        rhs_no_harvest(xs, u, d, p, k3);
+        rhs_no_harvest(xs, u, d, p, k3, pipe);
         for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
-        rhs_no_harvest(xs, u, d, p, k4);
+        rhs_no_harvest(xs, u, d, p, k4, pipe);
         for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
         x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
         x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);

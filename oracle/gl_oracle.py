@@ -41,6 +41,8 @@ def lib():
         L.gl_oracle_rhs.argtypes = [_dp] * 6
         L.gl_oracle_rk4.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_split.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rhs_pipe.argtypes = [_dp] * 6
+        L.gl_oracle_rk4_split_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.restype = ctypes.c_int
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
@@ -81,6 +83,22 @@ def rk4_split(x, u, d, p, dt=900.0, n_sub=256):
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
     out = np.empty(NX)
     lib().gl_oracle_rk4_split(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
+    return out
+
+
+def rhs_pipe(x, u, d14, p):
+    """ODE_pipe (ode.hpp:126-263); d14 = the 10 disturbances + tPipe, tGroPipe, pipeSwitchOff, groPipeSwitchOff."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d14, 14), _c(p, NP)
+    dx = np.empty(NX)
+    aux = np.empty(NAUX)
+    lib().gl_oracle_rhs_pipe(_p(x), _p(u), _p(d), _p(p), _p(dx), _p(aux))
+    return dx
+
+
+def rk4_split_pipe(x, u, d14, p, dt=300.0, n_sub=256):
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d14, 14), _c(p, NP)
+    out = np.empty(NX)
+    lib().gl_oracle_rk4_split_pipe(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
     return out
 
 

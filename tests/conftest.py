@@ -70,6 +70,18 @@ def hostmath():
             lib.hostmath_step(P(x), P(u), P(d_), P(p), int(f32), int(per_env_crop), ctypes.c_double(dt), int(n_sub),
                               P(out))
             return out
+    def _rhs_pipe(x, u, d14, p, f32=False):
+        out = np.empty(28)
+        x, u, d14, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d14, p)]
+        lib.hostmath_rhs_pipe(P(x), P(u), P(d14), P(p), int(f32), P(out))
+        return out
+
+    def _step_pipe(x, u, d14, p, f32=False, dt=300.0, n_sub=256):
+        out = np.empty(28)
+        x, u, d14, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d14, p)]
+        lib.hostmath_step_pipe(P(x), P(u), P(d14), P(p), int(f32), ctypes.c_double(dt), int(n_sub), P(out))
+        return out
+    H.rhs_pipe, H.step_pipe = staticmethod(_rhs_pipe), staticmethod(_step_pipe)
     return H
 
 

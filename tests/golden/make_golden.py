@@ -284,7 +284,41 @@ def g_rollout_summer():
                                                                           np.max(np.array(Xs)[:, 2])))
 
 
-ALL = dict(rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+def g_pipe():
+    """ODE_pipe (ode.hpp:126-263; nd = 14, driven by experiments/gl_predefined_controls.py at dt = 300 s).
+    (a) 64 RHS known answers from the reference's ODE_pipe statement text; (b) 24 tight one-step maps over 300 s
+    (Radau 1e-11 on the oracle's ODE_pipe, which (a) pins to the reference text); half of the tuples carry that
+    experiment's parameter overrides (set_matlab_params, gl_predefined_controls.py:70-77)."""
+    X, U, D, P = _input_tuples(64, 999)
+    rng = np.random.default_rng(31)
+    D14 = np.zeros((64, 14)); D14[:, :10] = D
+    P = P.astype(np.float64)
+    for i in range(64):
+        D14[i, 10] = 0.0 if i % 4 == 0 else rng.uniform(30, 70)            # measured pipe temperature (0 = no data)
+        D14[i, 11] = 0.0 if i % 3 == 0 else rng.uniform(25, 45)            # grow-pipe temperature (ignored by the code)
+        D14[i, 12] = 1.0 if i % 5 == 2 else 0.0                            # pipeSwitchOff
+        D14[i, 13] = 1.0 if i % 7 == 2 else 0.0
+        if i % 2:
+            q = P[i]
+            q[79] = 0.6; q[108] = 44. * q[46]; q[109] = 720.; q[165] = 0.88; q[170] = 44. * q[46]; q[145] = 300_000
+    DX = np.empty((64, 28)); worst = 0.0
+    for i in range(64):
+        DX[i], _ = R.ref_rhs_pipe(X[i], U[i], D14[i], P[i])
+        o = O.rhs_pipe(X[i], U[i], D14[i], P[i])
+        e = np.abs(DX[i] - o) / np.maximum(np.abs(DX[i]), 1e-300); e[DX[i] == o] = 0
+        worst = max(worst, e.max())
+    XT = np.empty((24, 28))
+    for i in range(24):
+        s = solve_ivp(lambda t, y: O.rhs_pipe(y, U[i], D14[i], P[i]), (0.0, 300.0), X[i], method="Radau", rtol=1e-11,
+                      atol=1e-11)
+        assert s.success
+        XT[i] = s.y[:, -1]
+    print("pipe_kat: oracle vs reference-text worst rel diff = %.3e; tracking tuples %d" %
+          (worst, int(np.sum((D14[:, 10] >= 1) & (D14[:, 12] <= 0)))))
+    np.savez_compressed(HERE / "pipe_kat.npz", X=X, U=U, D14=D14, P=P, DX=DX, X_tight300=XT)
+
+
+ALL = dict(pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

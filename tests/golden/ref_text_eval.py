@@ -104,6 +104,24 @@ def build():
     assert n_dx == 28, n_dx
     py.append("    return dxdt, a\n")
 
+    # ODE_pipe (ode.hpp:126-263): same statement rewriting; its four `SX name = ...` locals become plain assignments
+    pipe = _body(ode_src, r"SX\s+ODE_pipe\s*\(.*?\)\s*\{", r"return\s+dxdt\s*;")
+    py.append("def ODE_pipe(x, u, d, p):\n    a = update(x, u, d, p)\n    dxdt = [0.0] * 28")
+    n_dx = 0
+    for st in pipe.split(";"):
+        st = " ".join(st.replace("\\", " ").split())
+        if not st or st.startswith("SX a =") or st.startswith("SX dxdt"):
+            continue
+        if st.startswith("SX "):
+            st = st[3:]
+            assert re.match(r"t\w*Pipe(On|Off)\s*=", st), st
+        else:
+            assert re.match(r"dxdt\(\d+\)\s*=", st), st
+            n_dx += 1
+        py.append("    " + _expr(st))
+    assert n_dx == 28, n_dx
+    py.append("    return dxdt, a\n")
+
     code = "\n".join(py)
     ns: dict = {}
     exec(compile(code, "<reference-text>", "exec"), ns)
@@ -123,6 +141,15 @@ def ref_rhs(x, u, d, p):
     d = [float(v) for v in d]
     p = [float(v) for v in p]
     dx, a = _NS["ODE"](x, u, d, p)
+    return np.array(dx, dtype=np.float64), np.array(a, dtype=np.float64)
+
+
+def ref_rhs_pipe(x, u, d, p):
+    """(dx[28], aux[239]) of ODE_pipe (d has 14 entries: 10 tPipe, 11 tGroPipe, 12 pipeSwitchOff, 13 groPipeSwitchOff)."""
+    global _NS
+    if _NS is None:
+        _NS = build()
+    dx, a = _NS["ODE_pipe"]([float(v) for v in x], [float(v) for v in u], [float(v) for v in d], [float(v) for v in p])
     return np.array(dx, dtype=np.float64), np.array(a, dtype=np.float64)
 
 

@@ -5,7 +5,7 @@
 
 using namespace glm;
 
-template <class T>
+template <class T, bool PIPE = false>
 static void run(const double* x, const double* u, const double* d, const double* p, int per_env_crop, double dt,
                 int n_sub, double* out, int rhs_only)
 {
@@ -24,14 +24,19 @@ static void run(const double* x, const double* u, const double* d, const double*
     const CropConst<T>& cr = per_env_crop ? crLocal : m.crop;
     StepCoef<T> s;
     precompute(uu, dd, m, cr, s);
+    if (PIPE) {                                   // same two lines as step_kernel / evalf_kernel (d has 14 entries)
+        const T tPipe = T(d[10]), swOff = T(d[12]);
+        s.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
+        s.tPipeSet = tPipe;
+    }
     if (rhs_only) {
         T k[NX];
-        rhs(x0, s, m, cr, k);
+        rhs<T, true, PIPE>(x0, s, m, cr, k);
         for (int i = 0; i < NX; ++i) out[i] = (double)k[i];
         return;
     }
     T del[NX];
-    rk4_delta(x0, s, m, cr, T(dt), n_sub, del);
+    rk4_delta<T, PIPE>(x0, s, m, cr, T(dt), n_sub, del);
     for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
 }
 
@@ -45,6 +50,17 @@ void hostmath_rhs(const double* x, const double* u, const double* d, const doubl
 {
     if (f32) run<float>(x, u, d, p, per_env_crop, 0, 0, dx, 1);
     else run<double>(x, u, d, p, per_env_crop, 0, 0, dx, 1);
+}
+void hostmath_rhs_pipe(const double* x, const double* u, const double* d14, const double* p, int f32, double* dx)
+{
+    if (f32) run<float, true>(x, u, d14, p, 0, 0, 0, dx, 1);
+    else run<double, true>(x, u, d14, p, 0, 0, 0, dx, 1);
+}
+void hostmath_step_pipe(const double* x, const double* u, const double* d14, const double* p, int f32, double dt,
+                        int n_sub, double* x_next)
+{
+    if (f32) run<float, true>(x, u, d14, p, 0, dt, n_sub, x_next, 0);
+    else run<double, true>(x, u, d14, p, 0, dt, n_sub, x_next, 0);
 }
 void hostmath_step(const double* x, const double* u, const double* d, const double* p, int f32, int per_env_crop,
                    double dt, int n_sub, double* x_next)

@@ -378,3 +378,61 @@ def test_custom_reward_prices_and_constraints(golden):
         seen_violation |= info["temp_violation"] > 0 or info["rh_violation"] > 0
     assert seen_violation                  # the tightened box is actually violated, so the penalty path is exercised
     env.close()
+
+
+@pytest.mark.gpu
+def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
+    """SURVEY 8(f-4).  (1) GLGYM_ODE_PIPE against the reference-text vectors of ODE_pipe (ode.hpp:126-263) and the tight
+    300 s step maps; (2) nd = 14 rows with the default ODE variant behave exactly like their first 10 columns (what the
+    reference's compiled module does in experiments/gl_predefined_controls.py: it integrates ODE, the extra columns
+    ride along); (3) the batched env on 14-column weather, step_raw_control_pipeinput, against the oracle's scheme."""
+    import torch
+    from gl_gym_amd import GreenLight
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = golden("pipe_kat")
+    X, U, D, P, DX, XT = g["X"], g["U"], g["D14"], g["P"], g["DX"], g["X_tight300"]
+    n = len(XT)
+    for dtype, tol_rhs, tol_step in (("float64", 1e-11, 1.3e-5), ("float32", 2e-4, 3e-5)):
+        m = GreenLight(28, 6, 14, 208, 300.0, dtype=dtype, variant="ode_pipe")
+        for grp in (0, 1):                                    # even tuples: default p; odd: the MATLAB-comparison overrides
+            idx = np.arange(grp, len(X), 2)
+            if not np.array_equal(P[idx[0]], P[idx[-1]]):     # crop-noise tuples differ: one row at a time
+                idx = idx[[np.array_equal(P[i], P[idx[-1]]) for i in idx]]
+            m.set_params(P[idx[-1]])
+            dx = m.rhs(X[idx], U[idx], D[idx])
+            sc = np.maximum(np.abs(DX).max(axis=0), 1e-30)       # same scaling as test_rhs_matches_reference_text_vectors
+            assert np.max(np.abs(dx - DX[idx]) / sc) < tol_rhs, (dtype, grp)
+            assert np.all(dx[:, 19] == 0.0)
+        got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(n)])
+        err = scaled_err(got, XT)
+        print(f"ODE_pipe {dtype}: one-step (300 s) err vs tight {err:.2e}")
+        assert err < tol_step
+        m.close()
+    # (2) default variant, 14-column rows
+    a = GreenLight(28, 6, 14, 208, 300.0)
+    b = GreenLight(28, 6, 10, 208, 300.0)
+    np.testing.assert_array_equal(a.evalF_batch(X[:8], U[:8], D[:8]), b.evalF_batch(X[:8], U[:8], D[:8, :10]))
+    with pytest.raises(Exception):
+        GreenLight(28, 6, 10, 208, 300.0, variant="ode_pipe")          # needs the measured-pipe columns
+    a.close(); b.close()
+    # (3) env: 14-column weather table, controls held, pipe tracking on most rows
+    w10 = golden("rollout_10day")["weather"][:200]
+    rng = np.random.default_rng(5)
+    w14 = np.concatenate([w10, np.column_stack([rng.uniform(35, 65, 200), rng.uniform(25, 45, 200),
+                                                (np.arange(200) % 9 == 4) * 1.0, np.zeros(200)])], axis=1)
+    w14[::13, 10] = 0.0
+    p = P[1]
+    env = TomatoVecEnv(4, weather=w14, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
+                       model_variant="ode_pipe", auto_reset=False)
+    ref_env = TomatoVecEnv(4, weather=w10, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
+                           auto_reset=False)
+    np.testing.assert_array_equal(env.reset(), ref_env.reset())           # obs / reset read the 14-wide rows correctly
+    x = env.x[0].double().cpu().numpy()
+    p64 = np.asarray(env.p, dtype=np.float64)
+    for k in range(env.N + 1):
+        u = rng.uniform(0, 1, 6)
+        xs, term = env.step_raw_control_pipeinput(np.repeat(u[None], 4, 0))
+        x = oracle.rk4_split_pipe(x, u, w14[k], p64, 300.0, 256)
+        assert scaled_err(xs[0], x) < 1e-9 and np.array_equal(xs[0], xs[3])
+        assert bool(term[0]) == (k == env.N)
+    env.close(); ref_env.close()

@@ -145,3 +145,22 @@ def test_weather_loader_and_helpers(golden):
         np.testing.assert_allclose(v, h[name], rtol=1e-14, err_msg=name)
     w = U.synthetic_weather(n_rows=960)
     assert w.shape == (960, 10) and np.all(np.isfinite(w)) and w[:, 0].min() == 0 and w[:, 0].max() > 300
+
+
+def test_oracle_ode_pipe_bitwise_and_tight(oracle, golden):
+    """ODE_pipe (ode.hpp:126-263): the oracle against the reference's statement text (bit for bit) and its split RK4
+    over 300 s (experiments/gl_predefined_controls.py:96) against the tight solve."""
+    g = golden("pipe_kat")
+    X, U, D, P, DX, XT = g["X"], g["U"], g["D14"], g["P"], g["DX"], g["X_tight300"]
+    tracking = (D[:, 10] >= 1) & (D[:, 12] <= 0)
+    assert 20 < tracking.sum() < 50
+    for i in range(len(X)):
+        dx = oracle.rhs_pipe(X[i], U[i], D[i], P[i])
+        assert np.array_equal(dx, DX[i])
+        assert dx[19] == 0.0
+        if tracking[i]:
+            assert dx[9] == D[i, 10] - X[i, 9]
+        else:
+            assert dx[9] == oracle.rhs(X[i], U[i], D[i, :10], P[i])[9]
+    got = np.array([oracle.rk4_split_pipe(X[i], U[i], D[i], P[i], 300.0, 256) for i in range(len(XT))])
+    assert scaled_err(got, XT) < 1.3e-5      # same band as the 900 s one-step fixture (perturbed, harvest-active tuples)

@@ -53,7 +53,7 @@ def test_harvest_flow_properties(hostmath):
     from scipy.integrate import solve_ivp
     k, M, cmax = 2 * 4.6052 / 1e4, 5e4, 1.1278e5
     rng = np.random.default_rng(0)
-    for z0 in (-45.0, -39.9, -30.0, -16.1, -8.01, -7.99, -6.0, -2.0, 0.0, 3.0, 18.0, 60.0):
+    for z0 in (-45.0, -39.9, -30.0, -16.1, -8.01, -7.99, -6.0, -2.0, 0.0, 3.0, 18.0, 60.0, 100.0, 800.0, 2500.0):
         c0 = cmax + z0 / k
         for t in (0.2, 1.7578125, 30.0):
             d64 = hostmath.harvest_flow(c0, cmax, t)
@@ -105,3 +105,20 @@ def test_rhs_with_random_parameter_blocks_against_oracle(hostmath, oracle, golde
                 worst32 = max(worst32, float(np.max(np.abs(hostmath.rhs(X[i], U[i], D[i], p, True, per_env) - ref) / sc)))
     assert worst64 < 1e-9, worst64
     assert worst32 < 5e-3, worst32
+
+
+def test_ode_pipe_variant_host(hostmath, oracle, golden):
+    """The product's PIPE instantiation (rhs<T, ., true>, rk4_delta<T, true>) against the reference-text vectors, the
+    oracle's scheme and the tight 300 s solve."""
+    g = golden("pipe_kat")
+    X, U, D, P, DX, XT = g["X"], g["U"], g["D14"], g["P"], g["DX"], g["X_tight300"]
+    for i in range(len(X)):
+        sc = np.maximum(np.maximum(np.abs(DX[i]), 1e-6 * np.abs(DX).max(axis=0)), 1e-30)     # dx[19] is identically 0
+        assert np.max(np.abs(hostmath.rhs_pipe(X[i], U[i], D[i], P[i]) - DX[i]) / sc) < 1e-9
+    ok = np.ones(len(XT), bool)
+    g64 = np.array([hostmath.step_pipe(X[i], U[i], D[i], P[i], False) for i in range(len(XT))])
+    g32 = np.array([hostmath.step_pipe(X[i], U[i], D[i], P[i], True) for i in range(len(XT))])
+    ref = np.array([oracle.rk4_split_pipe(X[i], U[i], D[i], P[i], 300.0, 256) for i in range(len(XT))])
+    assert scaled_err(g64[ok], ref[ok]) < 1e-9
+    assert scaled_err(g64[ok], XT[ok]) < 1.3e-5
+    assert scaled_err(g32[ok], XT[ok]) < 3e-5
