@@ -310,14 +310,18 @@ template <class T> struct ObsArgsT {
     int nd;                                          // weather row stride
 };
 
-// 8 consecutive env rows = one contiguous span of the row-major output.  Phase 1: 8 x 23 lanes convert the
-// state / current-weather / clock features into LDS (the only divergent, transcendental work).  Phase 2: all 256
-// lanes stream the span: lane t writes elements t, t+256, ... (fully coalesced), taking the 23 leading floats of a
-// row from LDS and the 5*Np forecast floats straight from the L2-resident weather table.
+// 8 consecutive env rows = one contiguous, 32-byte aligned span of the row-major output (8 * dim floats).  The span is
+// assembled in LDS -- phase 1: 8 x 23 lanes convert the state / current-weather / clock features (the only divergent,
+// transcendental work) while the other lanes start on phase 2: the 5*Np raw forecast floats per row, gathered from the
+// L2-resident weather table with (row, column) loops, no per-element division -- and then streamed out with 16-byte
+// stores, lane t writing float4 t, t+256, ... (fully coalesced).  Masked mode (auto-reset) copies only the finished
+// rows, after saving their previous content as SB3's terminal_observation.
+constexpr int OBS_ROWS = 8, OBS_NCORE = 23, OBS_MAX_NP = 288;     // LDS span = 8 rows * (23 + 5 Np) floats <= 46.8 KB
 template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T> a)
 {
-    constexpr int ROWS = 8, NCORE = 23;
-    __shared__ float core[ROWS][NCORE + 1];
+    constexpr int ROWS = OBS_ROWS, NCORE = OBS_NCORE;
+    extern __shared__ float4 span4[];               // ROWS * dim floats (dynamic: 8.4 KB at Np = 48), 16-byte aligned
+    float* span = reinterpret_cast<float*>(span4);
     __shared__ int base_s[ROWS];
     const int tid = threadIdx.x;
     const int dim = NCORE + 5 * a.Np;
@@ -329,13 +333,18 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
             for (int r = 0; r < nrows; ++r) any |= a.mask[rb + r];
             if (!any) continue;                       // block-uniform
         }
+        if (tid < ROWS) {
+            const int b = rb + (tid < nrows ? tid : 0);
+            const int ts = a.timestep[b];
+            base_s[tid] = a.w_off[b] + (ts > 0 ? ts - 1 : 0);   // row / "timestep" the reference shows (pre-increment)
+        }
+        __syncthreads();
         if (tid < ROWS * NCORE) {
             const int r = tid / NCORE, j = tid - r * NCORE, b = rb + r;
             if (r < nrows) {
                 const int ts = a.timestep[b];
-                const int k = ts > 0 ? ts - 1 : 0;       // row / "timestep" the reference shows (pre-increment)
-                int base = a.w_off[b] + k;
-                if (j == 0) base_s[r] = base;
+                const int k = ts > 0 ? ts - 1 : 0;
+                int base = base_s[r];
                 base = base >= a.weather_rows ? a.weather_rows - 1 : (base < 0 ? 0 : base);
                 // fp32 hardware transcendentals: the observation block is float32 (observation_space dtype)
                 auto sat_vp = [](float t) { return 610.78f * __builtin_amdgcn_exp2f(1.44269504f * 17.2694f * t * __builtin_amdgcn_rcpf(t + 238.3f)); };
@@ -369,27 +378,35 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
                         v = (c == 1 || c == 3) ? __builtin_amdgcn_sinf(fr) : __builtin_amdgcn_cosf(fr);
                     }
                 }
-                core[r][j] = v;
+                span[r * dim + j] = v;
+            }
+        }
+        // raw forecast rows, no unit conversion (:175-182): element q of the block = weather[base+1 + q/5][q%5]
+        const int nf = 5 * a.Np;
+        for (int r = 0; r < nrows; ++r) {
+            const int base1 = base_s[r] + 1;
+            for (int q = tid; q < nf; q += 256) {
+                const int i = q / 5, c = q - i * 5;          // division by a constant: mul + shift
+                int row = base1 + i;
+                row = row >= a.weather_rows ? a.weather_rows - 1 : (row < 0 ? 0 : row);
+                span[r * dim + NCORE + q] = (float)a.weather[(size_t)row * a.nd + c];
             }
         }
         __syncthreads();
-        const int total = nrows * dim;
         float* out = a.obs + (size_t)rb * dim;
-        for (int e = tid; e < total; e += 256) {
-            const int r = e / dim, j = e - r * dim;
-            if (a.mask) {
-                if (!a.mask[rb + r]) continue;
-                if (a.term_obs) a.term_obs[(size_t)rb * dim + e] = out[e];      // SB3 terminal_observation
+        if (!a.mask && nrows == ROWS) {                      // full span: 16-byte stores (rb*dim*4 is a multiple of 32)
+            const int n4 = (ROWS * dim) >> 2;                // ROWS = 8 -> exact
+            float4* out4 = reinterpret_cast<float4*>(out);
+            for (int e = tid; e < n4; e += 256) out4[e] = span4[e];
+        } else {
+            for (int r = 0; r < nrows; ++r) {
+                if (a.mask && !a.mask[rb + r]) continue;
+                for (int jj = tid; jj < dim; jj += 256) {
+                    const size_t e = (size_t)r * dim + jj;
+                    if (a.mask && a.term_obs) a.term_obs[(size_t)rb * dim + e] = out[e];     // SB3 terminal_observation
+                    out[e] = span[e];
+                }
             }
-            float v;
-            if (j < NCORE) v = core[r][j];
-            else {                                           // raw forecast rows, no unit conversion (:175-182)
-                const int q = j - NCORE, i = q / 5, c = q - i * 5;
-                int row = base_s[r] + i + 1;
-                row = row >= a.weather_rows ? a.weather_rows - 1 : (row < 0 ? 0 : row);
-                v = (float)a.weather[(size_t)row * a.nd + c];
-            }
-            out[e] = v;
         }
         __syncthreads();
     }
@@ -942,7 +959,8 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     k.Np = a->Np; k.obs = a->obs; k.mask = a->mask; k.term_obs = a->term_obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0; k.nd = h->nd;
     int blocks = (a->B + 7) / 8;                 // 8 env rows per block-iteration
     if (blocks > 4096) blocks = 4096;            // grid-stride beyond that
-    hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), 0, st, k);
+    const size_t lds = (size_t)OBS_ROWS * (OBS_NCORE + 5 * a->Np) * sizeof(float);
+    hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), lds, st, k);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }
@@ -1012,8 +1030,8 @@ extern "C" {
 int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream)
 {
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
-        !a->start_day || !a->obs || a->Np < 0) {
-        g_err = "glgym_obs: bad arguments";
+        !a->start_day || !a->obs || a->Np < 0 || a->Np > OBS_MAX_NP) {
+        g_err = "glgym_obs: bad arguments (null pointer, ld < B, or Np outside 0..288)";
         return GLGYM_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
