@@ -612,6 +612,68 @@ static void rk4_split_impl(const double *x0, const double *u, const double *d, c
     memcpy(x1, x, sizeof x);
 }
 
+/* The kernels' production scheme ("lagged slow auxiliaries"): within one RK4 sub-step the auxiliaries see the three
+ * slowest states that feed expensive sub-expressions -- x23 cLeaf (-> LAI -> all canopy optics and canopy FIR view
+ * factors), x21 tCan24 (1-day filter -> growth inhibition, maintenance respiration) and x26 tCanSum -- frozen at their
+ * predicted sub-step MIDPOINT value  y + dprev/2  (dprev = their increment over the previous sub-step's RK4 part; 0 for
+ * the first sub-step of an env-step).  Every balance, including dx21's own relaxation term, is otherwise evaluated at
+ * the stage state.  These states move by < 1e-6 relative per 3.5 s sub-step and the midpoint prediction makes the lag
+ * second order: on the 10-day fixture the error vs the tight solution is 1.27e-6 without and 1.44e-6 with it (a plain
+ * start-of-sub-step freeze of tCan24 would cost 1e-4 in cBuf: the inhibition logistics are steep).  It lets the kernels
+ * evaluate those sub-expressions once per sub-step instead of four times. */
+int gl_lag_mask = 7;   /* experiment switch: bit 0 tCan24, bit 1 cLeaf, bit 2 tCanSum */
+static void rhs_lagged(const double *xs, const double *ymid, const double *u, const double *d, const double *p,
+                       double *dx, int pipe)
+{
+    double xt[GL_NX];
+    memcpy(xt, xs, sizeof xt);
+    if (gl_lag_mask & 1) xt[21] = ymid[21];
+    if (gl_lag_mask & 2) xt[23] = ymid[23];
+    if (gl_lag_mask & 4) xt[26] = ymid[26];
+    rhs_no_harvest(xt, u, d, p, dx, pipe);
+    dx[21] = (1.0 / 86400.0) * (xs[4] - xs[21]);
+}
+
+static void rk4_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                            double *x1, int pipe)
+{
+    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX];
+    const double h = dt / (double)n_sub;
+    memcpy(x, x0, sizeof x);
+    memset(dprev, 0, sizeof dprev);
+    for (int s = 0; s < n_sub; ++s) {
+        x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
+        x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
+        for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
+        rhs_lagged(x, ym, u, d, p, k1, pipe);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+        rhs_lagged(xs, ym, u, d, p, k2, pipe);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
+        rhs_lagged(xs, ym, u, d, p, k3, pipe);
+        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
+        rhs_lagged(xs, ym, u, d, p, k4, pipe);
+        for (int i = 0; i < GL_NX; ++i) {
+            dprev[i] = (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+            x[i] += dprev[i];
+        }
+        x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
+        x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
+    }
+    memcpy(x1, x, sizeof x);
+}
+
+void gl_oracle_rk4_lagged(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                          double *x1)
+{
+    rk4_lagged_impl(x0, u, d, p, dt, n_sub, x1, 0);
+}
+
+void gl_oracle_rk4_lagged_pipe(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                               double *x1)
+{
+    rk4_lagged_impl(x0, u, d, p, dt, n_sub, x1, 1);
+}
+
 /* Stability guard of the kernels: redo the env-step from x0 with 2x, then 4x sub-steps while the result is not finite.
  * Returns the number of extra attempts (0 normally; 2 with a non-finite result = failed integration). */
 int gl_oracle_rk4_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
@@ -619,7 +681,7 @@ int gl_oracle_rk4_guarded(const double *x0, const double *u, const double *d, co
 {
     int n = n_sub;
     for (int attempt = 0; attempt < 3; ++attempt, n *= 2) {
-        gl_oracle_rk4_split(x0, u, d, p, dt, n, x1);
+        rk4_lagged_impl(x0, u, d, p, dt, n, x1, 0);
         int ok = 1;
         for (int i = 0; i < GL_NX; ++i) ok &= isfinite(x1[i]) ? 1 : 0;
         if (ok) return attempt;

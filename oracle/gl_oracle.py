@@ -43,6 +43,8 @@ def lib():
         L.gl_oracle_rk4_split.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rhs_pipe.argtypes = [_dp] * 6
         L.gl_oracle_rk4_split_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk4_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk4_lagged_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.restype = ctypes.c_int
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
@@ -79,7 +81,8 @@ def rk4(x, u, d, p, dt=900.0, n_sub=256):
 
 
 def rk4_split(x, u, d, p, dt=900.0, n_sub=256):
-    """The kernels' scheme: Strang-split exact harvest flow + RK4 of the remaining RHS (see gl_oracle.c)."""
+    """Strang-split exact harvest flow + RK4 of the remaining RHS, every auxiliary evaluated at every stage
+    (the kernels' scheme without its slow-auxiliary lag; see gl_oracle.c)."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
     out = np.empty(NX)
     lib().gl_oracle_rk4_split(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))
@@ -102,8 +105,18 @@ def rk4_split_pipe(x, u, d14, p, dt=300.0, n_sub=256):
     return out
 
 
+def rk4_lagged(x, u, d, p, dt=900.0, n_sub=256, pipe=False):
+    """Strang-split RK4 with the slow auxiliaries (tCan24, cLeaf, tCanSum) lagged to the sub-step start (gl_oracle.c)."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, 14 if pipe else ND), _c(p, NP)
+    out = np.empty(NX)
+    (lib().gl_oracle_rk4_lagged_pipe if pipe else lib().gl_oracle_rk4_lagged)(_p(x), _p(u), _p(d), _p(p), float(dt),
+                                                                               int(n_sub), _p(out))
+    return out
+
+
 def rk4_guarded(x, u, d, p, dt=900.0, n_sub=256):
-    """rk4_split with the kernels' stability guard (retry with 2x / 4x sub-steps).  Returns (x_next, retries)."""
+    """rk4_lagged (the kernels' scheme) with their stability guard (retry with 2x / 4x sub-steps).
+    Returns (x_next, retries)."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
     out = np.empty(NX)
     r = lib().gl_oracle_rk4_guarded(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))

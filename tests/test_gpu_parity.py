@@ -42,7 +42,7 @@ def test_evalF_signature_and_value(models, golden, oracle):
     out = m64.evalF(X[0], U[0], D[0], P[0])
     assert isinstance(out, list) and len(out) == 28 and all(isinstance(v, float) for v in out)
     ok = np.ones(len(X), dtype=bool)          # every tuple, incl. the harvest-switch zone (exact sub-flow)
-    ref = np.array([oracle.rk4_split(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
+    ref = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
     got64 = np.array([m64.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
     got32 = np.array([m32.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
     assert scaled_err(got64[ok], ref[ok]) < 1e-9
@@ -195,7 +195,7 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
             xg = env.x.double().cpu().numpy()
             for b in range(0, 64, 9):
                 u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-                ref = oracle.rk4_split(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256)
+                ref = oracle.rk4_lagged(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256)
                 assert scaled_err(xg[b], ref) < tol, (dtype, k, b)
         env.close()
 
@@ -266,7 +266,7 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
         for b in range(0, B, 11):
             p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
             u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-            ref = oracle.rk4_split(x_prev[b], u, w[k], p, 900.0, 256)
+            ref = oracle.rk4_lagged(x_prev[b], u, w[k], p, 900.0, 256)
             assert scaled_err(xg[b], ref) < 5e-5
     assert len(np.unique(crop[1])) > B // 2                                            # envs really differ
     assert env.metrics()["n_ode_fail"] == 0
@@ -303,7 +303,7 @@ def test_stability_guard_in_storm(golden, oracle):
         x_prev = env.x.double().cpu().numpy().copy()
         env.step_raw_control(ctrl)
         ref, retries = oracle.rk4_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256)
-        plain_failed |= not np.all(np.isfinite(oracle.rk4_split(x_prev[0], ctrl[0], w[k], p, 900.0, 256)))
+        plain_failed |= not np.all(np.isfinite(oracle.rk4_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256)))
         assert np.all(np.isfinite(ref))
         assert scaled_err(env.x[0].double().cpu().numpy(), ref) < 5e-5, k
     m = env.metrics()
@@ -432,7 +432,7 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     for k in range(env.N + 1):
         u = rng.uniform(0, 1, 6)
         xs, term = env.step_raw_control_pipeinput(np.repeat(u[None], 4, 0))
-        x = oracle.rk4_split_pipe(x, u, w14[k], p64, 300.0, 256)
+        x = oracle.rk4_lagged(x, u, w14[k], p64, 300.0, 256, pipe=True)
         assert scaled_err(xs[0], x) < 1e-9 and np.array_equal(xs[0], xs[3])
         assert bool(term[0]) == (k == env.N)
     env.close(); ref_env.close()

@@ -26,6 +26,9 @@ def test_oracle_rk4_against_tight_step_fixture(oracle, golden):
     assert 4 <= zone.sum() <= 12
     got = np.array([oracle.rk4_split(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
     assert scaled_err(got, XT) < 1.3e-5               # ALL tuples, incl. the harvest zone, with the split scheme
+    lag = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
+    assert scaled_err(lag, XT) < 1.3e-5               # the kernels' scheme (slow auxiliaries lagged per sub-step) ...
+    assert scaled_err(lag, got) < 5e-8                # ... is the same map to 1.5e-8
     assert scaled_err(XB, XT) < 2e-5                  # the CVODES-tolerance proxy band recorded in the fixture
     plain = np.array([oracle.rk4(X[i], U[i], D[i], P[i], 900.0, 256) for i in zone.nonzero()[0]])
     assert scaled_err(plain, XT[zone]) > 1e-3         # classical RK4 of the full RHS is useless there
@@ -42,8 +45,9 @@ def test_oracle_stiff_solver_matches_radau_fixture(oracle, golden):
         assert scaled_err(xs, XT[i]) < 1e-7 and nfev > 0
 
 
+@pytest.mark.parametrize("scheme", ["rk4_split", "rk4_lagged"])
 @pytest.mark.parametrize("fixture", ["rollout_10day", "rollout_3day_synth"])
-def test_oracle_rollout_10day(oracle, golden, fixture):
+def test_oracle_rollout_10day(oracle, golden, fixture, scheme):
     g = golden(fixture)
     acts, w, XR = g["actions"], g["weather"], g["X"]
     p = golden("params_default")["p"].astype(np.float64)
@@ -51,9 +55,9 @@ def test_oracle_rollout_10day(oracle, golden, fixture):
     X = [x]
     for k in range(len(acts)):
         u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))
-        x = oracle.rk4_split(x, u, w[k], p, 900.0, 256)
+        x = getattr(oracle, scheme)(x, u, w[k], p, 900.0, 256)
         X.append(x)
-    assert scaled_err(np.array(X), XR) < 5e-6         # fp64 RK4-256 vs Radau 1e-11 over 10 days
+    assert scaled_err(np.array(X), XR) < 5e-6         # fp64 RK4-256 vs Radau 1e-11 over 10 days (1.3e-6 / 1.4e-6)
 
 
 def test_reward_restatement_against_reference_vectors(golden):
@@ -163,4 +167,6 @@ def test_oracle_ode_pipe_bitwise_and_tight(oracle, golden):
         else:
             assert dx[9] == oracle.rhs(X[i], U[i], D[i, :10], P[i])[9]
     got = np.array([oracle.rk4_split_pipe(X[i], U[i], D[i], P[i], 300.0, 256) for i in range(len(XT))])
-    assert scaled_err(got, XT) < 1.3e-5      # same band as the 900 s one-step fixture (perturbed, harvest-active tuples)
+    assert scaled_err(got, XT) < 1.3e-5
+    lag = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 300.0, 256, pipe=True) for i in range(len(XT))])
+    assert scaled_err(lag, got) < 1e-8      # same band as the 900 s one-step fixture (perturbed, harvest-active tuples)

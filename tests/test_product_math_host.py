@@ -22,7 +22,7 @@ def test_step_map_against_oracle_and_tight(hostmath, oracle, golden):
     g = golden("step_tight")
     X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
     ok = np.ones(len(X), dtype=bool)          # all tuples, incl. the harvest-switch zone (exact sub-flow)
-    ref = np.array([oracle.rk4_split(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
+    ref = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
     g64 = np.array([hostmath.step(X[i], U[i], D[i], P[i], False) for i in range(len(X))])
     g32 = np.array([hostmath.step(X[i], U[i], D[i], P[i], True) for i in range(len(X))])
     assert scaled_err(g64[ok], ref[ok]) < 1e-9
@@ -118,7 +118,7 @@ def test_ode_pipe_variant_host(hostmath, oracle, golden):
     ok = np.ones(len(XT), bool)
     g64 = np.array([hostmath.step_pipe(X[i], U[i], D[i], P[i], False) for i in range(len(XT))])
     g32 = np.array([hostmath.step_pipe(X[i], U[i], D[i], P[i], True) for i in range(len(XT))])
-    ref = np.array([oracle.rk4_split_pipe(X[i], U[i], D[i], P[i], 300.0, 256) for i in range(len(XT))])
+    ref = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 300.0, 256, pipe=True) for i in range(len(XT))])
     assert scaled_err(g64[ok], ref[ok]) < 1e-9
     assert scaled_err(g64[ok], XT[ok]) < 1.3e-5
     assert scaled_err(g32[ok], XT[ok]) < 3e-5
