@@ -499,13 +499,18 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
 // tier 3: the state-dependent right-hand side.  x[28] -> dx[28]
 // ---------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------
-// Tier 2b: sub-expressions that depend on the state ONLY through its three slowest members -- cLeaf (x23, -> LAI ->
-// canopy optics and every canopy / gap FIR coefficient), tCan24 (x21, 1-day filter -> growth inhibition, maintenance
-// respiration) and tCanSum (x26 -> fruit-set ramp).  They move by < 1e-6 relative per 3.5 s sub-step.  The integrator
-// evaluates them ONCE per sub-step, at the predicted sub-step midpoint (y + previous increment / 2: a second-order lag,
-// measured indistinguishable from evaluating them in every stage: 1.27e-6 -> 1.44e-6 on the 10-day fixture), instead
-// of four times: 7 exp, 4 rcp, 2 sqrt and ~110 flops less per stage.  rhs() below evaluates them at the state it is
-// given, which is the reference's right-hand side.
+// Tier 2b: what is evaluated ONCE per RK4 sub-step instead of in each of its four stages.
+//  (i)  Sub-expressions that depend on the state only through its slowest members: cLeaf (x23 -> LAI -> canopy optics,
+//       every canopy / gap FIR coefficient), tCan24 (x21, 1-day filter) and tCanSum (x26).
+//  (ii) The crop block (photosynthesis, carbohydrate flows, respiration; a191..a216).  Its inputs tCan, tAir, co2Air
+//       are not slow, but its outputs feed only the four crop pools (time constants of hours to weeks) and, through
+//       mcAirCan, the CO2 balance of a 4 m air column: a forcing that is smooth on the scale of a 3.5 s sub-step.
+// Both are evaluated at the PREDICTED SUB-STEP MIDPOINT  y + (increment over the previous sub-step) / 2, i.e. the midpoint
+// rule for these terms: second order, where a plain start-of-sub-step freeze would be first order (freezing tCan24 that
+// way costs 1e-4 in cBuf).  Measured against the tight fixtures the scheme is indistinguishable from evaluating
+// everything in every stage (10-day: 1.27e-6 either way; 3-day: 1.65e-6 / 1.66e-6; raw-control day 4.1e-5 / 4.2e-5) and
+// saves 23 transcendentals and ~170 flops per stage.  rhs() below evaluates both at the state it is given, which is
+// the reference's right-hand side.  oracle/gl_oracle.c (gl_oracle_rk4_lagged) restates the scheme independently.
 // ---------------------------------------------------------------------------------------------------
 template <class T> struct SlowCoef {
     T swCan, swFlr, swAir;      // short wave absorbed by canopy / floor / air: sun + lamps, PAR + NIR  (a54..a79)
@@ -514,17 +519,21 @@ template <class T> struct SlowCoef {
     T kPipeCovIn, kPipeSky, kPipeThScr, kPipeBlScr, kFlrCovIn, kFlrSky, kFlrThScr, kFlrBlScr, kLampFlr, kLampPipe;
     T iFlr, iPipe, iCan, iLamp, iBlScr, iThScr, iCovIn, iSky;       // interlights (zero power in the reference)
     T hCanAirK, mvCanK, iCapCan;            // 2 p0 LAI ; kVec LAI ; 1 / (capLeaf LAI)
-    T aPar, j25, gammaA, gammaB;            // photosynthesis: alpha*PAR absorbed ; J25 ; gammaStar = gammaA*tCan + gammaB
-    T flowK, maint, mcLeafAir;              // hT24*gT24 ; maintenance base*Q10 ; leaf maintenance respiration
-    T hTSum;                                // fruit-set ramp (a205)
+    // crop block (aux_states.hpp:1041-1194, a191..a216): photosynthesis, carbohydrate flows, respiration.  It feeds only
+    // the four crop pools and, through mcAirCan, the CO2 balance of the air.
+    T mcAirCan;                             // net CO2 uptake of the canopy (a216)
+    T dBuf, dLeaf, dStem, dFruit;           // d/dt of cBuf, cLeaf, cStem, cFruit without the harvest terms
 };
 
+// ym: the state the slow sub-expressions are evaluated at.  Entries read: 0 co2Air, 2 tAir, 4 tCan, 21 tCan24, 22 cBuf,
+// 23 cLeaf, 24 cStem, 25 cFruit, 26 tCanSum.
 template <class T>
-GL_HD void slow_coef(T cLeaf, T tCan24, T tCanSum, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
-                     SlowCoef<T>& q)
+GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, SlowCoef<T>& q)
 {
     using M = Math<T>;
-    const T one = T(1);
+    const T one = T(1), eps = T(1e-10);
+    const T co2Air = ym[0], tAir = ym[2], tCan = ym[4], tCan24 = ym[21], cBuf = ym[22], cLeaf = ym[23], cStem = ym[24];
+    const T cFruit = ym[25], tCanSum = ym[26];
     // ---- canopy geometry (aux_states.hpp:233, 299-484)
     const T lai = cr.sla * cLeaf;
     const T e1Par = M::expk(m.nk1Par, lai);
@@ -581,20 +590,46 @@ GL_HD void slow_coef(T cLeaf, T tCan24, T tCanSum, const StepCoef<T>& s, const M
     q.hCanAirK = m.hCanAir2 * lai;
     q.mvCanK = m.kVec * lai;
     q.iCapCan = iLai * M::rcp(m.capLeaf);
-    q.aPar = cr.alpha * (s.parUmolK * gPar);
-    q.j25 = lai * cr.j25LeafMax;
-    q.gammaA = iLai * cr.cGamma;
-    q.gammaB = cr.cGamma20 * (one - iLai);
 
-    // ---- 24-h mean canopy temperature and temperature sum (aux_states.hpp:1103-1180)
+    // ---- photosynthesis (aux_states.hpp:1041-1097)
+    const T aPar = cr.alpha * (s.parUmolK * gPar);
+    const T j25 = lai * cr.j25LeafMax;
+    const T gammaStar = iLai * cr.cGamma * tCan + cr.cGamma20 * (one - iLai);
+    const T co2Ppm = m.kPpm * (tAir + Kelvin<T>::c2k()) * co2Air;                      // a138
+    const T co2Stom = cr.etaCo2Stom * co2Ppm;
+    const T iCanK = M::rcp(tCan + Kelvin<T>::c2k());
+    const T jPot = j25 * M::expk(cr.kJ1, (tCan - cr.t25C) * iCanK) * cr.jDen25 *
+                   M::rcp(one + M::exp(cr.kS - cr.kH * iCanK));
+    const T jSum = jPot + aPar;
+    const T q4ja = cr.fourTheta * jPot * aPar;
+    const T jRate = cr.inv2Theta * (q4ja - eps) * M::rcp(jSum + M::sqrt(jSum * jSum - q4ja + eps));
+    // P = J (c - G) / (4 (c + 2G)),  R = P G / c   ->   P - R = J (c - G)^2 / (4 c (c + 2G)): one reciprocal
+    const T cmg = co2Stom - gammaStar;
+    const T net = jRate * cmg * cmg * M::rcp(T(4) * co2Stom * (co2Stom + T(2) * gammaStar));
+    const T hAirBuf = M::rcp(one + M::expk(T(5e-4), cBuf - cr.cBufMax));
+    const T mcAirBuf = cr.mCh2o * hAirBuf * net;
+
+    // ---- carbohydrate flows (aux_states.hpp:1103-1194)
     const T gT24 = T(0.047) * tCan24 + T(0.06);
     const T hT24 = M::rcp((one + M::expk(T(-1.1587), tCan24 - cr.tCan24Min)) *
                           (one + M::expk(T(1.3904), tCan24 - cr.tCan24Max)));
-    q.flowK = hT24 * gT24;
-    q.maint = cr.maintBase * M::expk(cr.q10k, tCan24 - T(25));
-    q.mcLeafAir = q.maint * cLeaf * cr.cLeafM;
+    const T hTCan = M::rcp((one + M::expk(T(-0.869), tCan - cr.tCanMin)) *
+                           (one + M::expk(T(0.5793), tCan - cr.tCanMax)));
     const T devA = tCanSum * m.tEndSumInv, devB = devA - one;      // devA - devB == 1
-    q.hTSum = T(0.5) * ((one + M::sqrt(devA * devA + T(1e-4))) - M::sqrt(devB * devB + T(1e-4)));
+    const T hTSum = T(0.5) * ((one + M::sqrt(devA * devA + T(1e-4))) - M::sqrt(devB * devB + T(1e-4)));
+    const T hBufOrg = M::rcp(one + M::expk(T(-5e-3), cBuf - cr.cBufMin));
+    const T flow = hBufOrg * hT24 * gT24;
+    const T mcBufLeaf = flow * cr.rgLeaf, mcBufStem = flow * cr.rgStem;
+    const T mcBufFruit = flow * hTCan * hTSum * cr.rgFruit;
+    const T mcBufAir = cr.cLeafG * mcBufLeaf + cr.cStemG * mcBufStem + cr.cFruitG * mcBufFruit;
+    const T maint = cr.maintBase * M::expk(cr.q10k, tCan24 - T(25));
+    const T mcLeafAir = maint * cLeaf * cr.cLeafM, mcStemAir = maint * cStem * cr.cStemM;
+    const T mcFruitAir = maint * cFruit * cr.cFruitM;
+    q.mcAirCan = cr.co2PerCh2o * (mcAirBuf - mcBufAir - (mcLeafAir + mcStemAir + mcFruitAir));
+    q.dBuf = mcAirBuf - mcBufFruit - mcBufLeaf - mcBufStem - mcBufAir;
+    q.dLeaf = mcBufLeaf - mcLeafAir;
+    q.dStem = mcBufStem - mcStemAir;
+    q.dFruit = mcBufFruit - mcFruitAir;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -613,8 +648,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
 
     const T co2Air = x[0], co2Top = x[1], tAir = x[2], tTop = x[3], tCan = x[4], tCovIn = x[5], tCovE = x[6];
     const T tThScr = x[7], tFlr = x[8], tPipe = x[9], vpAir = x[15], vpTop = x[16], tLamp = x[17];
-    const T tGroPipe = x[19], tBlScr = x[20], tCan24 = x[21], cBuf = x[22], cLeaf = x[23], cStem = x[24];
-    const T cFruit = x[25];
+    const T tGroPipe = x[19], tBlScr = x[20], tCan24 = x[21], cLeaf = x[23], cFruit = x[25];
 
     // ---- long wave: sigma*T^4 per surface, then pairwise exchange (aux_states.hpp:493-632)
     auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };   // sigma lives in the coefficients
@@ -677,7 +711,6 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
 
     const T tAirK = tAir + c2k, tTopK = tTop + c2k;
     const T iAirK = M::rcp(tAirK), iTopK = M::rcp(tTopK);
-    const T co2Ppm = m.kPpm * tAirK * co2Air;                           // a138
     const T rhoMean = T(0.5) * m.kRho * (iAirK + iTopK);                // a141
     const T dRho = M::abs(m.kRho * (tTop - tAir) * iAirK * iTopK);      // |rhoAir - rhoTop|
     const T dAT = tAir - tTop;
@@ -749,40 +782,14 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
     const T mvAirOut = kMv * fSideAbs * (vAirOverT - s.vpOutOverT);
 
-    // ---- photosynthesis (aux_states.hpp:1041-1097)
-    const T gammaStar = q.gammaA * tCan + q.gammaB;
-    const T co2Stom = cr.etaCo2Stom * co2Ppm;
-    const T tCanK = tCan + c2k;
-    const T iCanK = M::rcp(tCanK);
-    const T jPot = q.j25 * M::expk(cr.kJ1, (tCan - cr.t25C) * iCanK) * cr.jDen25 *
-                   M::rcp(one + M::exp(cr.kS - cr.kH * iCanK));
-    const T aPar = q.aPar;
-    const T jSum = jPot + aPar;
-    const T q4ja = cr.fourTheta * jPot * aPar;
-    const T jRate = cr.inv2Theta * (q4ja - eps) * M::rcp(jSum + M::sqrt(jSum * jSum - q4ja + eps));
-    // P = J (c - G) / (4 (c + 2G)),  R = P G / c   ->   P - R = J (c - G)^2 / (4 c (c + 2G)): one reciprocal
-    const T cmg = co2Stom - gammaStar;
-    const T net = jRate * cmg * cmg * M::rcp(T(4) * co2Stom * (co2Stom + T(2) * gammaStar));
-    const T hAirBuf = M::rcp(one + M::expk(T(5e-4), cBuf - cr.cBufMax));
-    const T mcAirBuf = cr.mCh2o * hAirBuf * net;
-
-    // ---- carbohydrate flows (aux_states.hpp:1103-1194)
-    const T hTCan = M::rcp((one + M::expk(T(-0.869), tCan - cr.tCanMin)) *
-                           (one + M::expk(T(0.5793), tCan - cr.tCanMax)));
-    const T hBufOrg = M::rcp(one + M::expk(T(-5e-3), cBuf - cr.cBufMin));
-    const T flow = hBufOrg * q.flowK;
-    const T mcBufLeaf = flow * cr.rgLeaf, mcBufStem = flow * cr.rgStem;
-    const T mcBufFruit = flow * hTCan * q.hTSum * cr.rgFruit;
-    const T mcBufAir = cr.cLeafG * mcBufLeaf + cr.cStemG * mcBufStem + cr.cFruitG * mcBufFruit;
-    const T mcLeafAir = q.mcLeafAir, mcStemAir = q.maint * cStem * cr.cStemM;
-    const T mcFruitAir = q.maint * cFruit * cr.cFruitM;
+    // ---- crop: photosynthesis and carbohydrate flows come from tier 2b (q.mcAirCan, q.dBuf ... q.dFruit); only the
+    // harvest terms of the reference's full right-hand side are evaluated here (test hook; the integrator splits them off)
     T mcLeafHar = T(0), mcFruitHar = T(0);
     if (HARVEST_IN_RHS) {
         const T kHar = T(2.0 * 4.6052 / 1e4);
         mcLeafHar = T(5e4) * M::rcp(one + M::expk(-kHar, cLeaf - cr.cLeafMax));
         mcFruitHar = T(5e4) * M::rcp(one + M::expk(-kHar, cFruit - cr.cFruitMax));
     }
-    const T mcAirCan = cr.co2PerCh2o * (mcAirBuf - mcBufAir - (mcLeafAir + mcStemAir + mcFruitAir));
 
     // ---- CO2 carried by air (aux_states.hpp:1201-1209)
     const T mcAirTop = fScrAbs * (co2Air - co2Top);
@@ -791,7 +798,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
 
     // ---- balances (ode.hpp:14-121)
     const T L = m.latent;
-    dx[0] = m.iCapCo2Air * (s.mcExtAir - mcAirCan - mcAirTop - mcAirOut);
+    dx[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
     dx[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
     dx[2] = m.iCapAir * (hCanAir + hPipeAir + q.swAir - hAirFlr - hAirThScr - hAirOut - hAirTop - hAirBlScr +
                          hLampAir + hGroPipeAir + hIntLampAir);
@@ -827,10 +834,10 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
                             rBlScrSky - rBlScrThScr + rLampBlScr + iToBlScr);
     const T perDay = T(1.0 / 86400.0);
     dx[21] = perDay * (tCan - tCan24);
-    dx[22] = mcAirBuf - mcBufFruit - mcBufLeaf - mcBufStem - mcBufAir;
-    dx[23] = mcBufLeaf - mcLeafAir - mcLeafHar;
-    dx[24] = mcBufStem - mcStemAir;
-    dx[25] = mcBufFruit - mcFruitAir - mcFruitHar;
+    dx[22] = q.dBuf;
+    dx[23] = q.dLeaf - mcLeafHar;
+    dx[24] = q.dStem;
+    dx[25] = q.dFruit - mcFruitHar;
     dx[26] = perDay * tCan;
     dx[27] = perDay;
 }
@@ -840,7 +847,7 @@ template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false>
 GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T* dx)
 {
     SlowCoef<T> q;
-    slow_coef(x[23], x[21], x[26], s, m, cr, q);
+    slow_coef(x, s, m, cr, q);
     rhs_fast<T, HARVEST_IN_RHS, PIPE>(x, q, s, m, cr, dx);
 }
 
@@ -857,11 +864,11 @@ __device__ __noinline__ inline void rhs_stage_f64(const double* x, const SlowCoe
 {
     rhs_fast<double, false, PIPE>(x, *q, *s, *m, *cr, dx);
 }
-__device__ __noinline__ inline void slow_coef_f64(double cLeaf, double tCan24, double tCanSum, const StepCoef<double>* s,
+__device__ __noinline__ inline void slow_coef_f64(const double* ym, const StepCoef<double>* s,
                                                   const ModelConst<double>* m, const CropConst<double>* cr,
                                                   SlowCoef<double>* q)
 {
-    slow_coef<double>(cLeaf, tCan24, tCanSum, *s, *m, *cr, *q);
+    slow_coef<double>(ym, *s, *m, *cr, *q);
 }
 #endif
 template <class T, bool PIPE> struct RhsStage {
@@ -870,10 +877,10 @@ template <class T, bool PIPE> struct RhsStage {
     {
         rhs_fast<T, false, PIPE>(x, q, s, m, cr, dx);
     }
-    static GL_HD void slow(T cLeaf, T tCan24, T tCanSum, const StepCoef<T>& s, const ModelConst<T>& m,
-                           const CropConst<T>& cr, SlowCoef<T>& q)
+    static GL_HD void slow(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
+                           SlowCoef<T>& q)
     {
-        slow_coef<T>(cLeaf, tCan24, tCanSum, s, m, cr, q);
+        slow_coef<T>(ym, s, m, cr, q);
     }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -883,10 +890,10 @@ template <bool PIPE> struct RhsStage<double, PIPE> {
     {
         rhs_stage_f64<PIPE>(x, &q, &s, &m, &cr, dx);
     }
-    static GL_HD void slow(double cLeaf, double tCan24, double tCanSum, const StepCoef<double>& s,
-                           const ModelConst<double>& m, const CropConst<double>& cr, SlowCoef<double>& q)
+    static GL_HD void slow(const double* ym, const StepCoef<double>& s, const ModelConst<double>& m,
+                           const CropConst<double>& cr, SlowCoef<double>& q)
     {
-        slow_coef_f64(cLeaf, tCan24, tCanSum, &s, &m, &cr, &q);
+        slow_coef_f64(ym, &s, &m, &cr, &q);
     }
 };
 #endif
@@ -949,7 +956,8 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
 {
     const T h = dt / T(n_sub), h2 = T(0.5) * h, h6 = h / T(6);
     T y[NX], xs[NX], k[NX], acc[NX];
-    T dLeaf = T(0), dCan24 = T(0), dSum = T(0);      // increments of the three lagged states over the previous sub-step
+    // increments over the previous sub-step of the states tier 2b reads (0 co2Air, 2 tAir, 4 tCan, 21..26 crop)
+    T dprev[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
     SlowCoef<T> q;
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
@@ -963,8 +971,13 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
         // state's magnitude either way; only the ACCUMULATION below has to stay in delta form)
 #pragma unroll
         for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-        // tier 2b once per sub-step, at the predicted midpoint of the three slow states (see SlowCoef)
-        RhsStage<T, PIPE>::slow(y[23] + T(0.5) * dLeaf, y[21] + T(0.5) * dCan24, y[26] + T(0.5) * dSum, s, m, cr, q);
+        // tier 2b once per sub-step, at the predicted sub-step midpoint  y + (previous increment) / 2  (see SlowCoef)
+        {
+            constexpr int idx[9] = {0, 2, 4, 21, 22, 23, 24, 25, 26};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) xs[idx[j]] = y[idx[j]] + T(0.5) * dprev[j];
+            RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
+        }
         rhs_stage<T, PIPE>(y, q, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
@@ -978,10 +991,11 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const T inc = h6 * (acc[i] + k[i]);
-            if (i == 23) dLeaf = inc;
-            if (i == 21) dCan24 = inc;
-            if (i == 26) dSum = inc;
             del[i] += inc;
+            if (i == 0) dprev[0] = inc;
+            if (i == 2) dprev[1] = inc;
+            if (i == 4) dprev[2] = inc;
+            if (i >= 21 && i <= 26) dprev[i - 18] = inc;
         }
         const T hh = (it == n_sub - 1) ? h2 : h;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);

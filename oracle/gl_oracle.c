@@ -612,16 +612,19 @@ static void rk4_split_impl(const double *x0, const double *u, const double *d, c
     memcpy(x1, x, sizeof x);
 }
 
-/* The kernels' production scheme ("lagged slow auxiliaries"): within one RK4 sub-step the auxiliaries see the three
- * slowest states that feed expensive sub-expressions -- x23 cLeaf (-> LAI -> all canopy optics and canopy FIR view
- * factors), x21 tCan24 (1-day filter -> growth inhibition, maintenance respiration) and x26 tCanSum -- frozen at their
- * predicted sub-step MIDPOINT value  y + dprev/2  (dprev = their increment over the previous sub-step's RK4 part; 0 for
- * the first sub-step of an env-step).  Every balance, including dx21's own relaxation term, is otherwise evaluated at
- * the stage state.  These states move by < 1e-6 relative per 3.5 s sub-step and the midpoint prediction makes the lag
- * second order: on the 10-day fixture the error vs the tight solution is 1.27e-6 without and 1.44e-6 with it (a plain
- * start-of-sub-step freeze of tCan24 would cost 1e-4 in cBuf: the inhibition logistics are steep).  It lets the kernels
- * evaluate those sub-expressions once per sub-step instead of four times. */
-int gl_lag_mask = 7;   /* experiment switch: bit 0 tCan24, bit 1 cLeaf, bit 2 tCanSum */
+/* The kernels' production scheme ("lagged slow auxiliaries").  Within one RK4 sub-step
+ *  (i)  the auxiliaries see the three slowest states that feed expensive sub-expressions -- x23 cLeaf (-> LAI -> all
+ *       canopy optics and canopy FIR view factors), x21 tCan24 (1-day filter) and x26 tCanSum -- and
+ *  (ii) the whole crop block a[191..216] (photosynthesis, carbohydrate flows, respiration), which feeds only dx22..25
+ *       and, through a216 = mcAirCan, dx0,
+ * at the predicted sub-step MIDPOINT state  ymid = y + dprev/2  (dprev = increment over the previous sub-step's RK4 part;
+ * 0 for the first sub-step of an env-step).  Every other balance, including dx21's own relaxation term, is evaluated at
+ * the stage state.  The midpoint prediction makes the lag second order: against the tight fixtures the error is 1.27e-6
+ * (10 days) / 1.65e-6 (3 days) with and without it, whereas a plain start-of-sub-step freeze of tCan24 alone costs 1e-4
+ * in cBuf (the inhibition logistics are steep).  The kernels evaluate those sub-expressions once per sub-step instead of
+ * four times.  Bits of gl_lag_mask (experiments; production = 71): 1 tCan24, 2 cLeaf, 4 tCanSum, 8 cBuf, 16 cStem+cFruit,
+ * 32 soil layers, 64 crop block. */
+int gl_lag_mask = 71;
 static void rhs_lagged(const double *xs, const double *ymid, const double *u, const double *d, const double *p,
                        double *dx, int pipe)
 {
@@ -630,7 +633,20 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
     if (gl_lag_mask & 1) xt[21] = ymid[21];
     if (gl_lag_mask & 2) xt[23] = ymid[23];
     if (gl_lag_mask & 4) xt[26] = ymid[26];
-    rhs_no_harvest(xt, u, d, p, dx, pipe);
+    if (gl_lag_mask & 8) xt[22] = ymid[22];
+    if (gl_lag_mask & 16) { xt[24] = ymid[24]; xt[25] = ymid[25]; }
+    if (gl_lag_mask & 32) { for (int i = 10; i < 15; ++i) xt[i] = ymid[i]; }
+    if (gl_lag_mask & 64) {
+        /* experiment: the whole crop block (photosynthesis + carbohydrate flows, a[191..216]) at the predicted midpoint */
+        double am[GL_NAUX], as[GL_NAUX], dm[GL_NX];
+        if (pipe) gl_oracle_rhs_pipe(ymid, u, d, p, dm, am); else gl_oracle_rhs(ymid, u, d, p, dm, am);
+        dm[23] += am[214]; dm[25] += am[215];
+        if (pipe) gl_oracle_rhs_pipe(xt, u, d, p, dx, as); else gl_oracle_rhs(xt, u, d, p, dx, as);
+        dx[0] += (1.0 / p[122]) * (as[216] - am[216]);
+        for (int i = 22; i <= 25; ++i) dx[i] = dm[i];
+    } else {
+        rhs_no_harvest(xt, u, d, p, dx, pipe);
+    }
     dx[21] = (1.0 / 86400.0) * (xs[4] - xs[21]);
 }
 
