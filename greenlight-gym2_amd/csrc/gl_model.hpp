@@ -523,10 +523,13 @@ template <class T> struct SlowCoef {
     // the four crop pools and, through mcAirCan, the CO2 balance of the air.
     T mcAirCan;                             // net CO2 uptake of the canopy (a216)
     T dBuf, dLeaf, dStem, dFruit;           // d/dt of cBuf, cLeaf, cStem, cFruit without the harvest terms
+    // soil chain (aux_states.hpp:905-935, a158..a163): linear conduction floor -> 5 layers -> deep soil, hours to weeks
+    T hFlrSo1;                              // conduction floor -> layer 1 (also leaves the floor balance)
+    T dSo1, dSo2, dSo3, dSo4, dSo5;         // d/dt of the five layer temperatures
 };
 
-// ym: the state the slow sub-expressions are evaluated at.  Entries read: 0 co2Air, 2 tAir, 4 tCan, 21 tCan24, 22 cBuf,
-// 23 cLeaf, 24 cStem, 25 cFruit, 26 tCanSum.
+// ym: the state the slow sub-expressions are evaluated at.  Entries read: 0 co2Air, 2 tAir, 4 tCan, 8 tFlr, 10..14 soil,
+// 21 tCan24, 22 cBuf, 23 cLeaf, 24 cStem, 25 cFruit, 26 tCanSum.
 template <class T>
 GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, SlowCoef<T>& q)
 {
@@ -630,6 +633,17 @@ GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, 
     q.dLeaf = mcBufLeaf - mcLeafAir;
     q.dStem = mcBufStem - mcStemAir;
     q.dFruit = mcBufFruit - mcFruitAir;
+
+    // ---- soil chain
+    q.hFlrSo1 = m.cFlrSo1 * (ym[8] - ym[10]);
+    const T hSo12 = m.cSo12 * (ym[10] - ym[11]), hSo23 = m.cSo23 * (ym[11] - ym[12]);
+    const T hSo34 = m.cSo34 * (ym[12] - ym[13]), hSo45 = m.cSo45 * (ym[13] - ym[14]);
+    const T hSo5Out = m.cSo5Out * (ym[14] - s.tSoOut);
+    q.dSo1 = m.iCapSo1 * (q.hFlrSo1 - hSo12);
+    q.dSo2 = m.iCapSo2 * (hSo12 - hSo23);
+    q.dSo3 = m.iCapSo3 * (hSo23 - hSo34);
+    q.dSo4 = m.iCapSo4 * (hSo34 - hSo45);
+    q.dSo5 = m.iCapSo5 * (hSo45 - hSo5Out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -745,10 +759,6 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T dPA = tPipe - tAir, dGA = tGroPipe - tAir;
     const T hPipeAir = m.cPipeAir * M::powa(M::abs(dPA + eps), T(0.32)) * dPA;
     const T hGroPipeAir = m.cGroPipeAir * M::powa(M::abs(dGA + eps), T(0.32)) * dGA;
-    const T hFlrSo1 = m.cFlrSo1 * (tFlr - x[10]);
-    const T hSo12 = m.cSo12 * (x[10] - x[11]), hSo23 = m.cSo23 * (x[11] - x[12]);
-    const T hSo34 = m.cSo34 * (x[12] - x[13]), hSo45 = m.cSo45 * (x[13] - x[14]);
-    const T hSo5Out = m.cSo5Out * (x[14] - s.tSoOut);
     const T hCovInCovE = m.cCovCond * (tCovIn - tCovE);
     const T hLampAir = m.cLampAir * (tLamp - tAir);
 
@@ -811,15 +821,15 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     dx[6] = m.iCapCov * (s.sunCovE + hCovInCovE - hCovEOut - rCovESky);
     dx[7] = m.iCapThScr * (hAirThScr + L * mvAirThScr + rCanThScr + rFlrThScr + rPipeThScr - hThScrTop - rThScrCovIn -
                            rThScrSky + rBlScrThScr + rLampThScr + iToThScr);
-    dx[8] = m.iCapFlr * (hAirFlr + q.swFlr + rCanFlr + rPipeFlr - hFlrSo1 - rFlrCovIn - rFlrSky -
+    dx[8] = m.iCapFlr * (hAirFlr + q.swFlr + rCanFlr + rPipeFlr - q.hFlrSo1 - rFlrCovIn - rFlrSky -
                          rFlrThScr + rLampFlr - rFlrBlScr + iToFlr);
     dx[9] = m.iCapPipe * (s.hBoilPipe - rPipeSky - rPipeCovIn - rPipeCan - rPipeFlr - rPipeThScr - hPipeAir +
                           rLampPipe - rPipeBlScr + iToPipe);
-    dx[10] = m.iCapSo1 * (hFlrSo1 - hSo12);
-    dx[11] = m.iCapSo2 * (hSo12 - hSo23);
-    dx[12] = m.iCapSo3 * (hSo23 - hSo34);
-    dx[13] = m.iCapSo4 * (hSo34 - hSo45);
-    dx[14] = m.iCapSo5 * (hSo45 - hSo5Out);
+    dx[10] = q.dSo1;
+    dx[11] = q.dSo2;
+    dx[12] = q.dSo3;
+    dx[13] = q.dSo4;
+    dx[14] = q.dSo5;
     dx[15] = m.kCapVpAir * tAirK * (mvCanAir - mvAirThScr - mvAirTop - mvAirOut - mvAirBlScr);
     dx[16] = m.kCapVpTop * tTopK * (mvAirTop - mvTopCovIn - mvTopOut);
     dx[17] = m.iCapLamp * (s.lampNet - hLampAir - rLampSky - rLampCovIn - rLampThScr - rLampPipe - rLampBlScr -
@@ -950,14 +960,24 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
 // adjacent half steps are merged into one call (group property of the flow).
 // Returns del (x(dt) - x0); the caller adds it once.
 // ---------------------------------------------------------------------------------------------------
+// slot of state i in the integrator's "previous increment" array, -1 if tier 2b does not read the state
+GL_HD constexpr int gl_slow_slot(int i)
+{
+    return i == 0 ? 0 : i == 2 ? 1 : i == 4 ? 2 : i == 8 ? 3 : (i >= 10 && i <= 14) ? i - 6 : (i >= 21 && i <= 26) ? i - 12 : -1;
+}
+// states whose derivative tier 2b holds constant over a sub-step (soil layers, crop pools): RK4 degenerates to  h * dx
+GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || (i >= 22 && i <= 25); }
+
 template <class T, bool PIPE = false>
 GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                      int n_sub, T* del)
 {
     const T h = dt / T(n_sub), h2 = T(0.5) * h, h6 = h / T(6);
     T y[NX], xs[NX], k[NX], acc[NX];
-    // increments over the previous sub-step of the states tier 2b reads (0 co2Air, 2 tAir, 4 tCan, 21..26 crop)
-    T dprev[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    // increments over the previous sub-step of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 21..26)
+    T dprev[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
@@ -973,29 +993,26 @@ GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, 
         for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
         // tier 2b once per sub-step, at the predicted sub-step midpoint  y + (previous increment) / 2  (see SlowCoef)
         {
-            constexpr int idx[9] = {0, 2, 4, 21, 22, 23, 24, 25, 26};
 #pragma unroll
-            for (int j = 0; j < 9; ++j) xs[idx[j]] = y[idx[j]] + T(0.5) * dprev[j];
+            for (int i = 0; i < NX; ++i)
+                if (gl_slow_slot(i) >= 0) xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
             RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
         }
         rhs_stage<T, PIPE>(y, q, s, m, cr, k);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
+        for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
         rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
+        for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
         rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
+        for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
         rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const T inc = h6 * (acc[i] + k[i]);
+            const T inc = gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);     // k1 = k2 = k3 = k4 for those
             del[i] += inc;
-            if (i == 0) dprev[0] = inc;
-            if (i == 2) dprev[1] = inc;
-            if (i == 4) dprev[2] = inc;
-            if (i >= 21 && i <= 26) dprev[i - 18] = inc;
+            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = inc;
         }
         const T hh = (it == n_sub - 1) ? h2 : h;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
