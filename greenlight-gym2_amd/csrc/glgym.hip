@@ -310,19 +310,25 @@ template <class T> struct ObsArgsT {
     int nd;                                          // weather row stride
 };
 
-// 8 consecutive env rows = one contiguous, 32-byte aligned span of the row-major output (8 * dim floats).  The span is
-// assembled in LDS -- phase 1: 8 x 23 lanes convert the state / current-weather / clock features (the only divergent,
-// transcendental work) while the other lanes start on phase 2: the 5*Np raw forecast floats per row, gathered from the
-// L2-resident weather table with (row, column) loops, no per-element division -- and then streamed out with 16-byte
-// stores, lane t writing float4 t, t+256, ... (fully coalesced).  Masked mode (auto-reset) copies only the finished
-// rows, after saving their previous content as SB3's terminal_observation.
-constexpr int OBS_ROWS = 8, OBS_NCORE = 23, OBS_MAX_NP = 288;     // LDS span = 8 rows * (23 + 5 Np) floats <= 46.8 KB
+// OBS_ROWS (16) consecutive env rows = one contiguous, 32-byte aligned span of the row-major output.  The span is
+// assembled in LDS and streamed out with 16-byte stores, lane t writing float4 t, t+256, ... (fully coalesced).
+// The kernel is latency-, not bandwidth-bound (a block's chain is: scalar loads of the rows' clocks -> gathers -> LDS ->
+// barrier -> stores), so everything is arranged to keep many independent loads in flight per lane: the 16 window bases
+// are loaded up front, the 23 state / current-weather / clock features are straight-line code (pointer selects instead
+// of a branch per feature: 3 loads in flight), and each lane gathers one forecast element for all 16 rows at once from
+// the L2-resident weather table.  Measured at B = 65 536, Np = 48: 44 us (first LDS version) -> 33 (independent gathers)
+// -> 26 (branch-free features) -> 24 us (16 rows per block) = 2.9 TB/s written; a plain fill of the buffer takes 11.6 us.
+// Masked mode (auto-reset) copies only the finished rows, after saving their previous content as SB3's
+// terminal_observation.
+#ifndef GL_OBS_ROWS
+#define GL_OBS_ROWS 16
+#endif
+constexpr int OBS_ROWS = GL_OBS_ROWS, OBS_NCORE = 23, OBS_MAX_NP = 128;     // LDS span = rows * (23 + 5 Np) floats <= 42 KB
 template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T> a)
 {
     constexpr int ROWS = OBS_ROWS, NCORE = OBS_NCORE;
     extern __shared__ float4 span4[];               // ROWS * dim floats (dynamic: 8.4 KB at Np = 48), 16-byte aligned
     float* span = reinterpret_cast<float*>(span4);
-    __shared__ int base_s[ROWS];
     const int tid = threadIdx.x;
     const int dim = NCORE + 5 * a.Np;
     const float kPpm = (float)(8.3144598 / (101325.0 * 44.01e-3));
@@ -333,69 +339,70 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
             for (int r = 0; r < nrows; ++r) any |= a.mask[rb + r];
             if (!any) continue;                       // block-uniform
         }
-        if (tid < ROWS) {
-            const int b = rb + (tid < nrows ? tid : 0);
+        // first weather row of each env's window (the row / "timestep" the reference shows is the pre-increment one):
+        // block-uniform addresses -> scalar loads, all eight issued before anything depends on them
+        int base_r[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int b = rb + (r < nrows ? r : 0);
             const int ts = a.timestep[b];
-            base_s[tid] = a.w_off[b] + (ts > 0 ? ts - 1 : 0);   // row / "timestep" the reference shows (pre-increment)
+            base_r[r] = a.w_off[b] + (ts > 0 ? ts - 1 : 0);
         }
-        __syncthreads();
-        if (tid < ROWS * NCORE) {
-            const int r = tid / NCORE, j = tid - r * NCORE, b = rb + r;
-            if (r < nrows) {
-                const int ts = a.timestep[b];
-                const int k = ts > 0 ? ts - 1 : 0;
-                int base = base_s[r];
-                base = base >= a.weather_rows ? a.weather_rows - 1 : (base < 0 ? 0 : base);
-                // fp32 hardware transcendentals: the observation block is float32 (observation_space dtype)
-                auto sat_vp = [](float t) { return 610.78f * __builtin_amdgcn_exp2f(1.44269504f * 17.2694f * t * __builtin_amdgcn_rcpf(t + 238.3f)); };
-                float v;
-                if (j < 4) {                                 // indoor climate (observations.py:70-77)
-                    const float tAir = (float)a.x[(size_t)2 * a.ld + b];
-                    if (j == 0) v = kPpm * (tAir + 273.15f) * (float)a.x[b];
-                    else if (j == 1) v = tAir;
-                    else if (j == 2) v = fminf(fmaxf(100.0f * (float)a.x[(size_t)15 * a.ld + b] * __builtin_amdgcn_rcpf(sat_vp(tAir)), 0.0f), 100.0f);
-                    else v = (float)a.x[(size_t)9 * a.ld + b];
-                } else if (j < 7) {                          // crop (:90-95)
-                    const int idx = j == 4 ? 21 : (j == 5 ? 25 : 26);
-                    v = (float)a.x[(size_t)idx * a.ld + b];
-                } else if (j < 13) {                         // controls (:108-112)
-                    v = (float)a.u[(size_t)(j - 7) * a.ld + b];
-                } else if (j < 18) {                         // current weather (:129-136)
-                    const T* w = a.weather + (size_t)base * a.nd;
-                    const float tOut = (float)w[1];
-                    const int c = j - 13;
-                    if (c == 2) v = fminf(fmaxf(100.0f * (float)w[2] * __builtin_amdgcn_rcpf(sat_vp(tOut)), 0.0f), 100.0f);
-                    else if (c == 3) v = kPpm * (tOut + 273.15f) * (float)w[3];
-                    else v = (float)w[c];
-                } else {                                     // time features (:149-161, tomato_env.py:126-128)
-                    const int c = j - 18;
-                    if (c == 0) v = (float)k;
-                    else {
-                        // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*x)
-                        const double rev = (c <= 2) ? ((double)a.start_day[b] + (double)ts * a.doy_inc) * (1.0 / 365.0)
-                                                    : (double)ts * a.hod_inc * (1.0 / 24.0);
-                        const float fr = (float)(rev - floor(rev));
-                        v = (c == 1 || c == 3) ? __builtin_amdgcn_sinf(fr) : __builtin_amdgcn_cosf(fr);
-                    }
-                }
-                span[r * dim + j] = v;
-            }
+        for (int e = tid; e < ROWS * NCORE; e += 256) {
+            // straight-line code for all 23 features: two pointer selects, three loads in flight, arithmetic selects --
+            // a branch per feature would serialise one memory round trip per branch inside the wave
+            const int r = e / NCORE, j = e - r * NCORE;
+            const int b = rb + (r < nrows ? r : 0);
+            const int ts = a.timestep[b];
+            const int k = ts > 0 ? ts - 1 : 0;
+            int base = 0;
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) base = (rr == r) ? base_r[rr] : base;
+            base = base >= a.weather_rows ? a.weather_rows - 1 : (base < 0 ? 0 : base);
+            const T* wrow = a.weather + (size_t)base * a.nd;
+            // j: 0 co2_ppm(x0,x2) 1 x2 2 RH(x15,x2) 3 x9 | 4 x21 5 x25 6 x26 | 7..12 u | 13 d0 14 d1 15 RH(d2,d1)
+            //    16 co2_ppm(d3,d1) 17 d4 | 18 timestep 19..22 sin/cos clocks      (observations.py:70-161)
+            const int xi = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 15 : j == 3 ? 9 : j == 4 ? 21 : j == 5 ? 25 : 26;
+            const T* p1 = j < 7 ? a.x + (size_t)xi * a.ld + b
+                                : (j < 13 ? a.u + (size_t)(j - 7) * a.ld + b : wrow + (j < 18 ? j - 13 : 0));
+            const T* p2 = j < 13 ? a.x + (size_t)2 * a.ld + b : wrow + 1;        // tAir or tOut
+            const float prim = (float)*p1, aux = (float)*p2, sday = a.start_day[b];
+            // fp32 hardware transcendentals: the observation block is float32 (observation_space dtype)
+            const float sat = 610.78f * __builtin_amdgcn_exp2f(1.44269504f * 17.2694f * aux * __builtin_amdgcn_rcpf(aux + 238.3f));
+            const float rh = fminf(fmaxf(100.0f * prim * __builtin_amdgcn_rcpf(sat), 0.0f), 100.0f);
+            const float ppm = kPpm * (aux + 273.15f) * prim;
+            // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*x)   (tomato_env.py:126-128)
+            const int c = j - 18;
+            const double rev = (c <= 2) ? ((double)sday + (double)ts * a.doy_inc) * (1.0 / 365.0)
+                                        : (double)ts * a.hod_inc * (1.0 / 24.0);
+            const float fr = (float)(rev - floor(rev));
+            const float clk = (c == 1 || c == 3) ? __builtin_amdgcn_sinf(fr) : __builtin_amdgcn_cosf(fr);
+            float v = prim;
+            v = (j == 0 || j == 16) ? ppm : v;
+            v = (j == 2 || j == 15) ? rh : v;
+            v = (j == 18) ? (float)k : v;
+            v = (j > 18) ? clk : v;
+            if (r < nrows) span[r * dim + j] = v;
         }
         // raw forecast rows, no unit conversion (:175-182): element q of the block = weather[base+1 + q/5][q%5]
         const int nf = 5 * a.Np;
-        for (int r = 0; r < nrows; ++r) {
-            const int base1 = base_s[r] + 1;
-            for (int q = tid; q < nf; q += 256) {
-                const int i = q / 5, c = q - i * 5;          // division by a constant: mul + shift
-                int row = base1 + i;
+        for (int q = tid; q < nf; q += 256) {
+            const int i = q / 5, c = q - i * 5;              // division by a constant: mul + shift
+            float v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {                 // eight independent gathers in flight per lane
+                int row = base_r[r] + 1 + i;
                 row = row >= a.weather_rows ? a.weather_rows - 1 : (row < 0 ? 0 : row);
-                span[r * dim + NCORE + q] = (float)a.weather[(size_t)row * a.nd + c];
+                v[r] = (float)a.weather[(size_t)row * a.nd + c];
             }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if (r < nrows) span[r * dim + NCORE + q] = v[r];
         }
         __syncthreads();
         float* out = a.obs + (size_t)rb * dim;
         if (!a.mask && nrows == ROWS) {                      // full span: 16-byte stores (rb*dim*4 is a multiple of 32)
-            const int n4 = (ROWS * dim) >> 2;                // ROWS = 8 -> exact
+            const int n4 = (ROWS * dim) >> 2;                // ROWS multiple of 8 -> exact
             float4* out4 = reinterpret_cast<float4*>(out);
             for (int e = tid; e < n4; e += 256) out4[e] = span4[e];
         } else {
@@ -957,8 +964,9 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     k.B = a->B; k.ld = a->ld; k.x = (const T*)a->x; k.u = (const T*)a->u; k.weather = (const T*)a->weather;
     k.weather_rows = a->weather_rows; k.w_off = a->w_off; k.timestep = a->timestep; k.start_day = a->start_day;
     k.Np = a->Np; k.obs = a->obs; k.mask = a->mask; k.term_obs = a->term_obs; k.doy_inc = std::fmod(h->dt / 86400.0, 365.0); k.hod_inc = h->dt / 3600.0; k.nd = h->nd;
-    int blocks = (a->B + 7) / 8;                 // 8 env rows per block-iteration
-    if (blocks > 4096) blocks = 4096;            // grid-stride beyond that
+    int blocks = (a->B + OBS_ROWS - 1) / OBS_ROWS;   // OBS_ROWS env rows per block-iteration
+    static const int cap = [] { const char* e = std::getenv("GLGYM_OBS_BLOCKS"); return e ? std::atoi(e) : 4096; }();
+    if (blocks > cap) blocks = cap;              // grid-stride beyond that
     const size_t lds = (size_t)OBS_ROWS * (OBS_NCORE + 5 * a->Np) * sizeof(float);
     hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), lds, st, k);
     HIPCHK(hipGetLastError());
@@ -1031,7 +1039,7 @@ int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream)
 {
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
         !a->start_day || !a->obs || a->Np < 0 || a->Np > OBS_MAX_NP) {
-        g_err = "glgym_obs: bad arguments (null pointer, ld < B, or Np outside 0..288)";
+        g_err = "glgym_obs: bad arguments (null pointer, ld < B, or Np outside 0..128)";
         return GLGYM_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
