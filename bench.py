@@ -42,6 +42,11 @@ BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum (SURVEY.md section 
 PMC_TRAFFIC_DEFAULT = (2 * 5741.38 + 12384.0) * 1024
 
 
+DEFAULT_SCHEME = "rk4"
+STAGES = {"rk4": 4, "rk2": 2}
+N_SUB = {"rk4": 256, "rk2": 360}
+
+
 def cpu_baseline(n_sub: int, budget_s: float = 10.0):
     """Oracle (plain-C fp64 port of the same scheme, ODE step only) on a bounded sample: ONE host core (the contract's
     `cpu_baseline`) and, beside it, all host cores (threads over env slices; ctypes releases the GIL)."""
@@ -96,10 +101,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
-    ap.add_argument("--n-sub", type=int, default=256)
+    ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2"],
+                    help="sub-stepper: classical RK4 (n_sub 256) or explicit midpoint (n_sub 360); include/glgym.h")
+    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 256 rk4 / 360 rk2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-scheme", action="store_true", help="skip the informational leg with the other sub-stepper")
     ap.add_argument("--uncertainty", type=float, default=0.0, help="crop-parameter noise scale (config 5: 0.2)")
     ap.add_argument("--vecnorm", action="store_true", help="also run the on-device VecNormalize (obs + reward) each step")
     args = ap.parse_args()
@@ -132,7 +140,10 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     weather = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)          # one year, shared by all envs
     starts = np.arange(0, 35040 - 5760 - 60, 96)                           # any midnight that leaves a 60-day season
+    if args.n_sub is None:
+        args.n_sub = N_SUB[args.scheme]
     env = TomatoVecEnv(B, weather=weather, dtype="float64" if args.dtype == "f64" else "float32", n_sub=args.n_sub,
+                       scheme=args.scheme,
                        season_length=60, pred_horizon=0.5, device=f"cuda:{local}", seed=666 + rank,
                        start_rows=starts, uncertainty_scale=args.uncertainty, auto_reset=True)
     vn = None
@@ -180,6 +191,26 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     m = env.metrics()
+
+    # Informational second leg (never `value`): the same K steps with the other sub-stepper the library offers
+    # (include/glgym.h glgym_scheme), timed the same way right after the main leg.
+    alt = None
+    if not args.no_alt_scheme:
+        other = "rk2" if args.scheme == "rk4" else "rk4"
+        env.set_scheme(other)
+        for i in range(min(W, 2)):
+            one_step(i)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for i in range(K):
+            one_step(W + i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        alt = (other, env.n_sub, time.perf_counter() - ta)
+        env.set_scheme(args.scheme, args.n_sub)
     # final metric gather: the only collective on this path (RCCL all_gather of 6 doubles per rank)
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
@@ -188,8 +219,8 @@ def main():
         agg = aggregate(rows)
         t_max, value, kern_ms_max = agg["t_max"], agg["value"], agg["kernel_ms_max"]
         per_gpu_kernel_rate = B / (kern_ms_max * 1e-3)
-        flops = 4 * args.n_sub * F_RHS
-        specials = 4 * args.n_sub * S_RHS
+        flops = STAGES[args.scheme] * args.n_sub * F_RHS
+        specials = STAGES[args.scheme] * args.n_sub * S_RHS
         ach_tflops = per_gpu_kernel_rate * flops / 1e12
         ach_tops = per_gpu_kernel_rate * specials / 1e12
         frac = ach_tflops / PEAK_VALU_TFLOPS + ach_tops / PEAK_SPECIAL_TOPS
@@ -201,7 +232,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: TomatoEnv batch 65536/GPU, RK4 sub-stepped, synthetic "
                                    "weather year (KNMI Amsterdam files absent), random actions U(-1,1)",
-                       "batch_per_gpu": B, "global_batch": B * world, "n_sub": args.n_sub, "dt_s": 900,
+                       "batch_per_gpu": B, "global_batch": B * world, "integrator": args.scheme, "n_sub": args.n_sub,
+                       "dt_s": 900,
                        "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True,
                        "vecnormalize": bool(args.vecnorm),
                        "uncertainty_scale": args.uncertainty, "parallelism": f"env-shard x{world} (no data-path collective)",
@@ -215,8 +247,8 @@ def main():
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
                                          "WRITE_SIZE, recorded in profiles/r01_v8_pmc_summary.csv (default workload only)",
                          "note": "path is VALU/transcendental-bound, not HBM/MFMA (SURVEY 8d): achieved = algorithmic "
-                                 "add/mul flops (4*n_sub*1502 per env-step) / mean step_kernel time; frac adds the "
-                                 "quarter-rate special-op term (4*n_sub*219 per env-step)",
+                                 "add/mul flops (stages*n_sub*1502 per env-step, stages = 4 rk4 / 2 rk2) / mean "
+                                 "step_kernel time; frac adds the quarter-rate special-op term (stages*n_sub*219)",
                          "executed_note": "frac > 1 because the kernel executes far less than the reference expression "
                                           "graph (hoisting, CSE, slow sub-expressions once per sub-step): PMC on the "
                                           "default workload (profiles/r01_v8_pmc_summary.csv) counts 4.70e8 VALU wave-"
@@ -228,11 +260,16 @@ def main():
                          "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                  "frac": hbm_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                                  "obs_bytes_per_env_step": obs_bytes}},
+            "other_scheme": None if alt is None else {
+                "integrator": alt[0], "n_sub": alt[1], "value": B * world * K / alt[2], "unit": "env-steps/s",
+                "ms_per_step": 1e3 * alt[2] / K,
+                "note": "informational: same workload and timing protocol with the library's other sub-stepper (rank-0 "
+                        "clock); accuracy of both vs the tight fixtures in DESIGN.md section 2"},
             "sum_reward": agg["sum_reward"], "ode_failures": agg["ode_failures"],
             "episodes_finished": agg["episodes_finished"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.n_sub)
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(256)      # the RK4-256 C port
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:

@@ -968,57 +968,85 @@ GL_HD constexpr int gl_slow_slot(int i)
 // states whose derivative tier 2b holds constant over a sub-step (soil layers, crop pools): RK4 degenerates to  h * dx
 GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || (i >= 22 && i <= 25); }
 
-template <class T, bool PIPE = false>
-GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                     int n_sub, T* del)
+// ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 2 = explicit midpoint
+// (2.0, i.e. 1.0 per stage: the same stability margin with 30 % fewer right-hand sides; second order, which at h ~ 2.5 s
+// is still 10x inside the accuracy bar -- DESIGN.md section 2).  WIN: consecutive sub-steps that share one tier-2b
+// evaluation and one pair of harvest half steps (n_sub is rounded up to a multiple of WIN).
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
+GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
+                    int n_sub, T* del)
 {
-    const T h = dt / T(n_sub), h2 = T(0.5) * h, h6 = h / T(6);
+    static_assert(ORDER == 4 || ORDER == 2, "ORDER: 4 (classical RK4) or 2 (explicit midpoint)");
+    const int n_win = (n_sub + WIN - 1) / WIN;
+    const T h = dt / T(n_win * WIN), h2 = T(0.5) * h, h6 = h / T(6);
+    const T hw = h * T(WIN), hw2 = T(0.5) * hw;        // harvest flow: once per window
     T y[NX], xs[NX], k[NX], acc[NX];
-    // increments over the previous sub-step of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 21..26)
-    T dprev[15];
+    // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 21..26)
+    T dprev[15], dmark[15];
 #pragma unroll
     for (int j = 0; j < 15; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
-    // Strang splitting: half a step of the exact harvest flow, RK4 on everything else, half a step again.  The flow is
-    // a one-parameter group, so the trailing half step of one sub-step and the leading half step of the next are ONE
-    // call over h:  H(h/2) [RK4 H(h)]^(n-1) RK4 H(h/2)  -- half as many flow evaluations, same map.
-    del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, h2);
-    del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, h2);
-    for (int it = 0; it < n_sub; ++it) {
-        // y = state at the start of the sub-step; stage inputs y + c*h*k are one FMA each (their rounding is at the
-        // state's magnitude either way; only the ACCUMULATION below has to stay in delta form)
+    // Strang splitting: half a window of the exact harvest flow, RK on everything else, half a window again.  The flow
+    // is a one-parameter group, so the trailing half of one window and the leading half of the next are ONE call:
+    //   H(hw/2) [RK^WIN H(hw)]^(n-1) RK^WIN H(hw/2)  -- half as many flow evaluations, same map.
+    del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hw2);
+    del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hw2);
+    for (int it = 0; it < n_win; ++it) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-        // tier 2b once per sub-step, at the predicted sub-step midpoint  y + (previous increment) / 2  (see SlowCoef)
-        {
+        for (int j = 0; j < WIN; ++j) {
+            // y = state at the start of the sub-step; stage inputs y + c*h*k are one FMA each (their rounding is at the
+            // state's magnitude either way; only the ACCUMULATION below has to stay in delta form)
 #pragma unroll
-            for (int i = 0; i < NX; ++i)
-                if (gl_slow_slot(i) >= 0) xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
-            RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
+            for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+            if (j == 0) {
+                // tier 2b once per window, at the predicted window midpoint  y + (previous window's increment) / 2
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (gl_slow_slot(i) >= 0) {
+                        xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
+                        dmark[gl_slow_slot(i)] = del[i];
+                    }
+                RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
+            }
+            rhs_stage<T, PIPE>(y, q, s, m, cr, k);
+            if (ORDER == 4) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    del[i] += gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);     // k1 = k2 = k3 = k4 for those
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) xs[i] = y[i] + h2 * k[i];
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) del[i] += h * k[i];
+            }
         }
-        rhs_stage<T, PIPE>(y, q, s, m, cr, k);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
-        rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
-        rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
-        rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const T inc = gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);     // k1 = k2 = k3 = k4 for those
-            del[i] += inc;
-            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = inc;
-        }
-        const T hh = (it == n_sub - 1) ? h2 : h;
+        for (int i = 0; i < NX; ++i)
+            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dmark[gl_slow_slot(i)];
+        const T hh = (it == n_win - 1) ? hw2 : hw;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
     }
     del[NX - 1] = dt * T(1.0 / 86400.0);     // x27 = time [days]: dx = 1/86400 exactly, nothing depends on it
+}
+
+template <class T, bool PIPE = false>
+GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
+                     int n_sub, T* del)
+{
+    rk_delta<T, PIPE, 4, 1>(x0, s, m, cr, dt, n_sub, del);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1037,14 +1065,14 @@ template <class T> GL_HD bool all_finite(const T* v)
     return chk == T(0);
 }
 
-template <class T, bool PIPE = false>
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                             int n_sub, T* del, bool* failed)
 {
     int n = n_sub, extra = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        rk4_delta<T, PIPE>(x0, s, m, cr, dt, n, del);
+        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del);
         ok = all_finite(del);
         if (ok) break;
         n *= 2;

@@ -129,7 +129,9 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #define GL_STEP_WAVES_PER_SIMD 1
 #endif
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
-template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false>
+// RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by two of them (GLGYM_SCHEME_RK2)
+// instead of classical RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.
+template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, bool RK2 = false>
 __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
 #endif
     T del[NX];
     bool bad;
-    const int retries = rk4_delta_guarded<T, PIPE>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
+    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 2 : 1>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
 // ---------------------------------------------------------------------------------------------------
 // reference-compatible step map / RHS with row-major double I/O (B small; B = 1 for the drop-in evalF)
 // ---------------------------------------------------------------------------------------------------
-template <class T, bool PER_ENV_CROP, bool PIPE = false>
+template <class T, bool PER_ENV_CROP, bool PIPE = false, bool RK2 = false>
 __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
                                                      const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
                                                      ModelConst<T> m, double* x_next, int rhs_only, int nd)
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
+    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 2 : 1>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
     for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
 }
 
@@ -692,6 +694,7 @@ struct glgym_handle_s {
     float* p0_crop_dev = nullptr;       // shared p[128..161] as f32 (noise kernel input)
     int nd = ND;                        // weather / disturbance row stride: 10, or up to 16 (ODE_pipe reads columns 10, 12)
     int variant = GLGYM_ODE;            // GLGYM_ODE | GLGYM_ODE_PIPE
+    int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-pointer entry points
@@ -784,6 +787,16 @@ int glgym_set_model_variant(glgym_handle h, int variant)
     return GLGYM_OK;
 }
 
+int glgym_set_scheme(glgym_handle h, int scheme)
+{
+    if (!h || (scheme != GLGYM_SCHEME_RK4 && scheme != GLGYM_SCHEME_RK2)) {
+        g_err = "glgym_set_scheme: GLGYM_SCHEME_RK4 or GLGYM_SCHEME_RK2";
+        return GLGYM_EINVAL;
+    }
+    h->scheme = scheme;
+    return GLGYM_OK;
+}
+
 int glgym_set_n_sub(glgym_handle h, int n_sub)
 {
     if (!h || n_sub < 1) return GLGYM_EINVAL;
@@ -826,12 +839,19 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
 {
     const dim3 grid((B + WAVE - 1) / WAVE), block(WAVE);
     if (h->variant == GLGYM_ODE_PIPE) {
-        if (dcrop) {
-            g_err = "glgym_evalF: per-row parameter blocks are not supported with GLGYM_ODE_PIPE";
+        if (dcrop || h->scheme != GLGYM_SCHEME_RK4) {
+            g_err = "glgym_evalF: GLGYM_ODE_PIPE supports neither per-row parameter blocks nor GLGYM_SCHEME_RK2";
             return GLGYM_EINVAL;
         }
         hipLaunchKernelGGL((evalf_kernel<T, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                            T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+    } else if (h->scheme == GLGYM_SCHEME_RK2) {
+        if (dcrop)
+            hipLaunchKernelGGL((evalf_kernel<T, true, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt),
+                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+        else
+            hipLaunchKernelGGL((evalf_kernel<T, false, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt),
+                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
     } else if (dcrop)
         hipLaunchKernelGGL((evalf_kernel<T, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                            T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
@@ -924,8 +944,8 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]); k.nd = h->nd;
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
     if (h->variant == GLGYM_ODE_PIPE) {
-        if (a->crop_p) {
-            g_err = "glgym_step: per-env crop parameters are not supported with GLGYM_ODE_PIPE";
+        if (a->crop_p || h->scheme != GLGYM_SCHEME_RK4) {
+            g_err = "glgym_step: GLGYM_ODE_PIPE supports neither per-env crop parameters nor GLGYM_SCHEME_RK2";
             return GLGYM_EINVAL;
         }
         hipLaunchKernelGGL((step_kernel<T, false, false, true>), grid, block, 0, st, k, m, rw);
@@ -935,6 +955,17 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // fp64 (parity configuration) always takes the generic kernel: its RHS is an out-of-line call that receives the
     // constant block by address, and only the kernarg copy has a usable one.
     const bool def = h->use_specialised && sizeof(T) == 4 && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+    if (h->scheme == GLGYM_SCHEME_RK2) {
+        if (a->crop_p) {
+            if (def) hipLaunchKernelGGL((step_kernel<T, true, true, false, true>), grid, block, 0, st, k, m, rw);
+            else hipLaunchKernelGGL((step_kernel<T, true, false, false, true>), grid, block, 0, st, k, m, rw);
+        } else {
+            if (def) hipLaunchKernelGGL((step_kernel<T, false, true, false, true>), grid, block, 0, st, k, m, rw);
+            else hipLaunchKernelGGL((step_kernel<T, false, false, false, true>), grid, block, 0, st, k, m, rw);
+        }
+        HIPCHK(hipGetLastError());
+        return GLGYM_OK;
+    }
     if (a->crop_p) {
         if (def) hipLaunchKernelGGL((step_kernel<T, true, true>), grid, block, 0, st, k, m, rw);
         else hipLaunchKernelGGL((step_kernel<T, true, false>), grid, block, 0, st, k, m, rw);

@@ -12,6 +12,9 @@ LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
 NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 9
 F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
+SCHEME_RK4, SCHEME_RK2 = 0, 1
+SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2}
+DEFAULT_N_SUB = {"rk4": 256, "rk2": 360}      # same 16-19 % stability margin over the 0.67 1/s cover mode
 OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
@@ -88,6 +91,7 @@ PROTOTYPES = {
     "glgym_set_params": (C.c_int, [C.c_void_p, _DP]),
     "glgym_set_n_sub": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_model_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_scheme": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_reward": (C.c_int, [C.c_void_p, C.POINTER(RewardCfg)]),
     "glgym_get_reward_scale": (C.c_int, [C.c_void_p, _DP, _DP, _DP]),
     "glgym_evalF": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),

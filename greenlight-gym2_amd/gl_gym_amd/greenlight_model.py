@@ -18,10 +18,15 @@ from .parameters import init_default_params
 
 
 class GreenLight:
-    def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=256, device=0, variant="ode"):
+    def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=None, device=0, variant="ode", scheme="rk4"):
         """nd = 10, or 14 as in experiments/gl_predefined_controls.py:95 (rows carry the measured pipe columns).
-        variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
+        variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14).
+        scheme = "rk4" (classical RK4, n_sub 256) or "rk2" (explicit midpoint, n_sub 360): include/glgym.h."""
         self._lib = L.load()
+        if scheme not in L.SCHEMES:
+            raise ValueError("scheme must be 'rk4' or 'rk2'")
+        n_sub = L.DEFAULT_N_SUB[scheme] if n_sub is None else n_sub
+        self.scheme, self.n_sub = scheme, int(n_sub)
         self.nx, self.nu, self.nd, self.np = int(nx), int(nu), int(nd), int(np_)
         self.dt = float(dt)
         self._h = C.c_void_p()
@@ -34,6 +39,7 @@ class GreenLight:
             raise ValueError("variant must be 'ode' or 'ode_pipe'")
         if variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
+        L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
 
     @property
     def handle(self):

@@ -112,12 +112,13 @@ class LazyInfos:
 class TomatoVecEnv:
     def __init__(self, num_envs: int, weather: Optional[np.ndarray] = None, params: Optional[np.ndarray] = None,
                  dt: float = 900.0, season_length: float = 60, pred_horizon: float = 0.5, dtype: str = "float32",
-                 n_sub: int = 256, device: str = "cuda:0", seed: int = 0, uncertainty_scale: float = 0.0,
+                 n_sub: Optional[int] = None, device: str = "cuda:0", seed: int = 0, uncertainty_scale: float = 0.0,
                  start_rows: Optional[Sequence[int]] = None, start_days: Optional[Sequence[float]] = None,
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
                  auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None,
-                 model_variant: str = "ode"):
-        """weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
+                 model_variant: str = "ode", scheme: str = "rk4"):
+        """scheme / n_sub: "rk4" (classical RK4, default n_sub 256) or "rk2" (explicit midpoint, default n_sub 360);
+        weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
         if not torch.cuda.is_available():
@@ -142,7 +143,10 @@ class TomatoVecEnv:
         self.obs_dim = 23 + 5 * self.Np
         self.f64 = str(dtype) in ("float64", "f64", "double")
         self.tdtype = torch.float64 if self.f64 else torch.float32
-        self.n_sub = int(n_sub)
+        if scheme not in L.SCHEMES:
+            raise ValueError("scheme must be 'rk4' or 'rk2'")
+        self.scheme = scheme
+        self.n_sub = int(L.DEFAULT_N_SUB[scheme] if n_sub is None else n_sub)
         self.uncertainty_scale = float(uncertainty_scale)
         self.auto_reset = auto_reset
         self.lazy_infos = (int(num_envs) > 4096) if lazy_infos is None else bool(lazy_infos)
@@ -156,6 +160,7 @@ class TomatoVecEnv:
                                        C.byref(self._h)), "glgym_create")
         if model_variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
+        L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
         rp = dict(DEFAULT_REWARD, **(reward_params or {}))
         cs = dict(DEFAULT_CONSTRAINTS, **(constraints or {}))
         self.reward_params, self.constraints = rp, cs
@@ -410,6 +415,14 @@ class TomatoVecEnv:
         v = self.metrics_t.cpu().numpy()
         return {k: float(v[i]) for i, k in enumerate(L.METRIC_KEYS)}
 
+    def set_scheme(self, scheme: str, n_sub: Optional[int] = None):
+        """Switch the sub-stepper ("rk4" | "rk2", include/glgym.h) and its sub-step count (default: the scheme's own)."""
+        if scheme not in L.SCHEMES:
+            raise ValueError("scheme must be 'rk4' or 'rk2'")
+        L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
+        self.scheme = scheme
+        self.set_n_sub(L.DEFAULT_N_SUB[scheme] if n_sub is None else n_sub)
+
     def set_n_sub(self, n_sub: int):
         self.n_sub = int(n_sub)
         L.check(self._lib.glgym_set_n_sub(self._h, self.n_sub), "glgym_set_n_sub")
@@ -439,9 +452,10 @@ class TomatoEnv:
     """Single-environment Gymnasium-style view over a B = 1 ``TomatoVecEnv`` (no auto-reset)."""
 
     def __init__(self, weather=None, params=None, dt=900.0, season_length=60, pred_horizon=0.5, dtype="float64",
-                 n_sub=256, device="cuda:0", uncertainty_scale=0.0, start_day=0.0, growth_year=2010,
-                 reward_params=None, constraints=None, location="synthetic", training=True, model_variant="ode"):
-        self.vec = TomatoVecEnv(1, model_variant=model_variant, weather=weather, params=params, dt=dt, season_length=season_length,
+                 n_sub=None, device="cuda:0", uncertainty_scale=0.0, start_day=0.0, growth_year=2010,
+                 reward_params=None, constraints=None, location="synthetic", training=True, model_variant="ode",
+                 scheme="rk4"):
+        self.vec = TomatoVecEnv(1, model_variant=model_variant, scheme=scheme, weather=weather, params=params, dt=dt, season_length=season_length,
                                 pred_horizon=pred_horizon, dtype=dtype, n_sub=n_sub, device=device,
                                 uncertainty_scale=uncertainty_scale, start_rows=[0], start_days=[start_day],
                                 reward_params=reward_params, constraints=constraints, auto_reset=False)

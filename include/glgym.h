@@ -59,6 +59,14 @@ typedef enum { GLGYM_F32 = 0, GLGYM_F64 = 1 } glgym_dtype;
  * experiments/gl_predefined_controls.py's setting). */
 typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
 
+/* Sub-stepping scheme of glgym_step / glgym_evalF (greenlight_model.cpp:46-63 uses CVODES BDF; any scheme that meets the
+ * accuracy bar against it is admissible).  Both are stability-bound by the 0.67 1/s cover mode:
+ *   GLGYM_SCHEME_RK4: classical RK4, stable for h <= 4.2 s -> n_sub >= 224 at dt = 900; default n_sub 256.
+ *   GLGYM_SCHEME_RK2: explicit midpoint, stable for h <= 3.0 s -> n_sub >= 302; use n_sub 360.  Same stability margin
+ *     with 30 % fewer right-hand sides; the slow sub-expressions and the harvest flow are shared by two sub-steps
+ *     (n_sub is rounded up to even).  10-day rollout error vs a tight solve: 6.5e-6 (fp64), 1.7e-5 (fp32). */
+typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1 } glgym_scheme;
+
 typedef enum {
     GLGYM_OK = 0,
     GLGYM_EINVAL = -1,   /* bad argument (sizes other than 28/6/10/208, null pointer, n_sub < 1 ...) */
@@ -142,6 +150,7 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
 int glgym_destroy(glgym_handle h);
 int glgym_set_params(glgym_handle h, const double* p);
 int glgym_set_n_sub(glgym_handle h, int n_sub);
+int glgym_set_scheme(glgym_handle h, int scheme);            /* GLGYM_SCHEME_RK4 (default) | GLGYM_SCHEME_RK2 */
 int glgym_set_model_variant(glgym_handle h, int variant);   /* GLGYM_ODE_PIPE needs a handle created with nd >= 14 */
 int glgym_set_reward(glgym_handle h, const glgym_reward_cfg* cfg);
 int glgym_get_reward_scale(glgym_handle h, double* max_profit, double* min_profit, double* fixed_costs);

@@ -654,32 +654,68 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
     dx[21] = (1.0 / 86400.0) * (xs[4] - xs[21]);
 }
 
-static void rk4_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
-                            double *x1, int pipe)
+/* order = 4 classical RK4, 3 Kutta's third-order method, 2 explicit midpoint.  window = number of consecutive sub-steps that
+ * share one tier-2b evaluation and one harvest half-step pair (1 = every sub-step). */
+static void rk_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                           double *x1, int pipe, int order, int window)
 {
-    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX];
+    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX];
     const double h = dt / (double)n_sub;
     memcpy(x, x0, sizeof x);
     memset(dprev, 0, sizeof dprev);
+    memset(ym, 0, sizeof ym);
     for (int s = 0; s < n_sub; ++s) {
-        x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
-        x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
-        for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
-        rhs_lagged(x, ym, u, d, p, k1, pipe);
-        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
-        rhs_lagged(xs, ym, u, d, p, k2, pipe);
-        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
-        rhs_lagged(xs, ym, u, d, p, k3, pipe);
-        for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
-        rhs_lagged(xs, ym, u, d, p, k4, pipe);
-        for (int i = 0; i < GL_NX; ++i) {
-            dprev[i] = (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-            x[i] += dprev[i];
+        const int first = (s % window) == 0, last = ((s + 1) % window) == 0 || s == n_sub - 1;
+        if (first) {
+            const int len = (n_sub - s < window) ? n_sub - s : window;
+            x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h * len);
+            x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h * len);
+            for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];   /* predicted middle of the window */
+            memcpy(xw, x, sizeof xw);
         }
-        x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h);
-        x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h);
+        if (order == 4) {
+            rhs_lagged(x, ym, u, d, p, k1, pipe);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+            rhs_lagged(xs, ym, u, d, p, k2, pipe);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
+            rhs_lagged(xs, ym, u, d, p, k3, pipe);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
+            rhs_lagged(xs, ym, u, d, p, k4, pipe);
+            for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        } else if (order == 3) {
+            rhs_lagged(x, ym, u, d, p, k1, pipe);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+            rhs_lagged(xs, ym, u, d, p, k2, pipe);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * (2.0 * k2[i] - k1[i]);
+            rhs_lagged(xs, ym, u, d, p, k3, pipe);
+            for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 4.0 * k2[i] + k3[i]);
+        } else {
+            rhs_lagged(x, ym, u, d, p, k1, pipe);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+            rhs_lagged(xs, ym, u, d, p, k2, pipe);
+            for (int i = 0; i < GL_NX; ++i) x[i] += h * k2[i];
+        }
+        if (last) {
+            const int len = (s % window) + 1;
+            for (int i = 0; i < GL_NX; ++i) dprev[i] = x[i] - xw[i];         /* increment over the window's RK part */
+            x[23] = harvest_flow_ref(x[23], p[144], 0.5 * h * len);
+            x[25] = harvest_flow_ref(x[25], p[145], 0.5 * h * len);
+        }
     }
     memcpy(x1, x, sizeof x);
+}
+
+static void rk4_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                            double *x1, int pipe)
+{
+    rk_lagged_impl(x0, u, d, p, dt, n_sub, x1, pipe, 4, 1);
+}
+
+/* experiment hook: other orders / tier-2b windows (tools/proto) */
+void gl_oracle_rk_lagged(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                         int order, int window, double *x1)
+{
+    rk_lagged_impl(x0, u, d, p, dt, n_sub, x1, 0, order, window);
 }
 
 void gl_oracle_rk4_lagged(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,

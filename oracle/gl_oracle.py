@@ -45,6 +45,7 @@ def lib():
         L.gl_oracle_rk4_split_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_lagged_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
+        L.gl_oracle_rk_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.restype = ctypes.c_int
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
@@ -111,6 +112,14 @@ def rk4_lagged(x, u, d, p, dt=900.0, n_sub=256, pipe=False):
     out = np.empty(NX)
     (lib().gl_oracle_rk4_lagged_pipe if pipe else lib().gl_oracle_rk4_lagged)(_p(x), _p(u), _p(d), _p(p), float(dt),
                                                                                int(n_sub), _p(out))
+    return out
+
+
+def rk_lagged(x, u, d, p, dt=900.0, n_sub=256, order=4, window=1):
+    """Experiment hook: RK order 2 / 3 / 4 with tier 2b and the harvest flow shared by `window` sub-steps."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    lib().gl_oracle_rk_lagged(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window), _p(out))
     return out
 
 

@@ -81,7 +81,14 @@ def hostmath():
         x, u, d14, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d14, p)]
         lib.hostmath_step_pipe(P(x), P(u), P(d14), P(p), int(f32), ctypes.c_double(dt), int(n_sub), P(out))
         return out
-    H.rhs_pipe, H.step_pipe = staticmethod(_rhs_pipe), staticmethod(_step_pipe)
+    def _step_scheme(x, u, d_, p, f32=False, dt=900.0, n_sub=256, order=4, window=1):
+        out = np.empty(28)
+        x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
+        rc = lib.hostmath_step_scheme(P(x), P(u), P(d_), P(p), int(f32), ctypes.c_double(dt), int(n_sub), int(order),
+                                      int(window), P(out))
+        assert rc == 0, "unsupported (order, window)"
+        return out
+    H.rhs_pipe, H.step_pipe, H.step_scheme = staticmethod(_rhs_pipe), staticmethod(_step_pipe), staticmethod(_step_scheme)
     return H
 
 

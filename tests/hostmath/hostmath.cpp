@@ -40,6 +40,21 @@ static void run(const double* x, const double* u, const double* d, const double*
     for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
 }
 
+// other integrator settings of rk_delta<T, PIPE, ORDER, WIN>: (order, window) in {(4,1), (4,2), (2,1), (2,2)}
+template <class T, int ORDER, int WIN>
+static void run_scheme(const double* x, const double* u, const double* d, const double* p, double dt, int n_sub, double* out)
+{
+    ModelConst<T> m;
+    make_model_const<T>(p, m);
+    T x0[NX], uu[NU], dd[7], del[NX];
+    for (int i = 0; i < NX; ++i) x0[i] = T(x[i]);
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[i]);
+    StepCoef<T> s;
+    precompute(uu, dd, m, m.crop, s);
+    rk_delta<T, false, ORDER, WIN>(x0, s, m, m.crop, T(dt), n_sub, del);
+    for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
+}
 extern "C" {
 double hostmath_harvest_flow(double c, double cmax, double t, int f32)
 {
@@ -61,6 +76,19 @@ void hostmath_step_pipe(const double* x, const double* u, const double* d14, con
 {
     if (f32) run<float, true>(x, u, d14, p, 0, dt, n_sub, x_next, 0);
     else run<double, true>(x, u, d14, p, 0, dt, n_sub, x_next, 0);
+}
+int hostmath_step_scheme(const double* x, const double* u, const double* d, const double* p, int f32, double dt,
+                         int n_sub, int order, int win, double* x_next)
+{
+#define GL_CASE(O, W)                                                              \
+    if (order == O && win == W) {                                                  \
+        if (f32) run_scheme<float, O, W>(x, u, d, p, dt, n_sub, x_next);           \
+        else run_scheme<double, O, W>(x, u, d, p, dt, n_sub, x_next);              \
+        return 0;                                                                  \
+    }
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(2, 1) GL_CASE(2, 2)
+#undef GL_CASE
+    return -1;
 }
 void hostmath_step(const double* x, const double* u, const double* d, const double* p, int f32, int per_env_crop,
                    double dt, int n_sub, double* x_next)

@@ -70,10 +70,11 @@ def test_n_sub_4_is_unstable_and_flagged(golden):
     env.close()
 
 
+@pytest.mark.parametrize("scheme", ["rk4", "rk2"])
 @pytest.mark.parametrize("fixture,dtype,tol", [("rollout_10day", "float64", 5e-6), ("rollout_10day", "float32", 1e-4),
                                                ("rollout_3day_synth", "float64", 5e-6),
                                                ("rollout_3day_synth", "float32", 1e-4)])
-def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol):
+def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme):
     """The headline accuracy bar: step() with the fixture's action sequence vs the tight (Radau 1e-11) states.
     rollout_10day: 961 steps on Bleiswijk autumn weather; rollout_3day_synth: 289 steps on midsummer-like synthetic
     weather (670 W/m2 peaks, strong photosynthesis and ventilation, air temperature 6..28 C)."""
@@ -82,7 +83,9 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol):
     acts, w, XR = g["actions"], g["weather"], g["X"]
     B = 64                                    # 64 identical envs: also checks lane-independence
     n_steps = len(acts)
-    env = TomatoVecEnv(B, weather=w, dtype=dtype, n_sub=256, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
+    if scheme == "rk2" and dtype == "float64":
+        tol = 1e-5                            # explicit midpoint at n_sub = 360: second order, 6.5e-6 / 7.7e-6 in fp64
+    env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
                        auto_reset=False)
     env.reset()
     import torch
@@ -94,7 +97,7 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol):
     X = np.array(X)
     assert np.array_equal(env.x[0].cpu().numpy(), env.x[B - 1].cpu().numpy())
     err = scaled_err(X, XR)
-    print(f"{fixture} {dtype}: max scaled rel err vs tight oracle = {err:.3e}")
+    print(f"{fixture} {dtype} {scheme} (n_sub {env.n_sub}): max scaled rel err vs tight oracle = {err:.3e}")
     assert err < tol
     assert bool(done[0]) is False or True
     env.close()
@@ -436,3 +439,23 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
         assert scaled_err(xs[0], x) < 1e-9 and np.array_equal(xs[0], xs[3])
         assert bool(term[0]) == (k == env.N)
     env.close(); ref_env.close()
+
+
+
+def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
+    """GLGYM_SCHEME_RK2 (explicit midpoint, tier 2b and harvest flow shared by two sub-steps) through glgym_evalF
+    against the oracle's independent restatement of the same scheme, and against the tight one-step solutions."""
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight")
+    X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
+    for dtype, tol_o, tol_t in (("float64", 1e-9, 3e-5), ("float32", 3e-5, 4e-5)):
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk2")
+        assert m.n_sub == 360
+        got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
+        ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, 360, order=2, window=2) for i in range(len(X))])
+        print(f"rk2 {dtype}: vs oracle scheme {scaled_err(got, ref):.2e}, vs tight {scaled_err(got, XT):.2e}")
+        assert scaled_err(got, ref) < tol_o
+        assert scaled_err(got, XT) < tol_t
+        m.set_n_sub(359)                       # odd n_sub is rounded up to a multiple of the 2-sub-step window
+        np.testing.assert_array_equal(np.array(m.evalF(X[0], U[0], D[0], P[0])), got[0])
+        m.close()
