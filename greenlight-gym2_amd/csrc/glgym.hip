@@ -129,7 +129,7 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #define GL_STEP_WAVES_PER_SIMD 1
 #endif
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
-// RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by two of them (GLGYM_SCHEME_RK2)
+// RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by four of them (GLGYM_SCHEME_RK2)
 // instead of classical RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.
 template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, bool RK2 = false>
 __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
 #endif
     T del[NX];
     bool bad;
-    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 2 : 1>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
+    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : 1>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 2 : 1>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
+    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : 1>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
     for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
 }
 

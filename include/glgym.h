@@ -63,8 +63,8 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  * accuracy bar against it is admissible).  Both are stability-bound by the 0.67 1/s cover mode:
  *   GLGYM_SCHEME_RK4: classical RK4, stable for h <= 4.2 s -> n_sub >= 224 at dt = 900; default n_sub 256.
  *   GLGYM_SCHEME_RK2: explicit midpoint, stable for h <= 3.0 s -> n_sub >= 302; use n_sub 360.  Same stability margin
- *     with 30 % fewer right-hand sides; the slow sub-expressions and the harvest flow are shared by two sub-steps
- *     (n_sub is rounded up to even).  10-day rollout error vs a tight solve: 6.5e-6 (fp64), 1.7e-5 (fp32). */
+ *     with 30 % fewer right-hand sides; the slow sub-expressions and the harvest flow are shared by four sub-steps
+ *     (n_sub is rounded up to a multiple of 4).  10-day rollout error vs a tight solve: 9e-6 (fp64), 1.8e-5 (fp32). */
 typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1 } glgym_scheme;
 
 typedef enum {

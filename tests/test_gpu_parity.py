@@ -443,7 +443,7 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
 
 
 def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
-    """GLGYM_SCHEME_RK2 (explicit midpoint, tier 2b and harvest flow shared by two sub-steps) through glgym_evalF
+    """GLGYM_SCHEME_RK2 (explicit midpoint, tier 2b and harvest flow shared by four sub-steps) through glgym_evalF
     against the oracle's independent restatement of the same scheme, and against the tight one-step solutions."""
     from gl_gym_amd import GreenLight
     g = golden("step_tight")
@@ -452,10 +452,10 @@ def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
         m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk2")
         assert m.n_sub == 360
         got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
-        ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, 360, order=2, window=2) for i in range(len(X))])
+        ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, 360, order=2, window=4) for i in range(len(X))])
         print(f"rk2 {dtype}: vs oracle scheme {scaled_err(got, ref):.2e}, vs tight {scaled_err(got, XT):.2e}")
         assert scaled_err(got, ref) < tol_o
         assert scaled_err(got, XT) < tol_t
-        m.set_n_sub(359)                       # odd n_sub is rounded up to a multiple of the 2-sub-step window
+        m.set_n_sub(357)                       # n_sub is rounded up to a multiple of the 4-sub-step window
         np.testing.assert_array_equal(np.array(m.evalF(X[0], U[0], D[0], P[0])), got[0])
         m.close()

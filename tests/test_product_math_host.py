@@ -122,3 +122,18 @@ def test_ode_pipe_variant_host(hostmath, oracle, golden):
     assert scaled_err(g64[ok], ref[ok]) < 1e-9
     assert scaled_err(g64[ok], XT[ok]) < 1.3e-5
     assert scaled_err(g32[ok], XT[ok]) < 3e-5
+
+
+def test_integrator_variants_host(hostmath, oracle, golden):
+    """rk_delta<T, PIPE, ORDER, WIN>: the shipped settings (RK4 / window 1, explicit midpoint / window 4) and two others,
+    product arithmetic vs the oracle's independent restatement (gl_oracle_rk_lagged) and vs the tight one-step maps."""
+    g = golden("step_tight")
+    X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
+    idx = range(0, len(X), 2)
+    for order, win, n, tol_t in ((4, 1, 256, 1.3e-5), (4, 2, 256, 2e-5), (2, 2, 358, 3e-5), (2, 4, 360, 4e-5)):
+        got = np.array([hostmath.step_scheme(X[i], U[i], D[i], P[i], False, 900.0, n, order, win) for i in idx])
+        ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, n, order, win) for i in idx])
+        g32 = np.array([hostmath.step_scheme(X[i], U[i], D[i], P[i], True, 900.0, n, order, win) for i in idx])
+        assert scaled_err(got, ref) < 1e-9, (order, win)
+        assert scaled_err(got, XT[list(idx)]) < tol_t, (order, win)
+        assert scaled_err(g32, XT[list(idx)]) < tol_t + 1e-5, (order, win)
