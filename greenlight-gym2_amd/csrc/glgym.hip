@@ -726,8 +726,10 @@ static int refresh(glgym_handle h)
 
 extern "C" {
 
-const char* glgym_version(void) { return "glgym 0.1 (gfx950; RK4 delta-form; thread-per-env)"; }
+const char* glgym_version(void) { return "glgym 0.2 (gfx950; thread-per-env; RK4 / explicit-midpoint sub-steppers in delta form)"; }
 const char* glgym_last_error(void) { return g_err.c_str(); }
+
+int glgym_destroy(glgym_handle h);
 
 int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int dtype, int n_sub, int device,
                  glgym_handle* out)
@@ -749,11 +751,19 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     std::memcpy(h->p, p, sizeof h->p);
     default_reward(h->rcfg);
     if (const char* e = std::getenv("GLGYM_GENERIC")) h->use_specialised = (e[0] == '1') ? 0 : 1;
-    HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
-    HIPCHK(hipEventCreate(&h->ev0));
-    HIPCHK(hipEventCreate(&h->ev1));
-    const int rc = refresh(h);
-    if (rc != GLGYM_OK) return rc;
+    // from here on a failure must release what was acquired: run the steps through one exit point
+    int rc = [&]() -> int {
+        HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
+        HIPCHK(hipEventCreate(&h->ev0));
+        HIPCHK(hipEventCreate(&h->ev1));
+        return refresh(h);
+    }();
+    if (rc != GLGYM_OK) {
+        const std::string keep = g_err;
+        (void)glgym_destroy(h);
+        g_err = keep;
+        return rc;
+    }
     *out = h;
     return GLGYM_OK;
 }
