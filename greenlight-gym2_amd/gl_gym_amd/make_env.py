@@ -19,6 +19,7 @@ NotImplementedError instead of being silently approximated.
 """
 from __future__ import annotations
 
+import os
 from os.path import join
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -110,12 +111,17 @@ def make_vec_env(env_id: str, env_base_params: Dict[str, Any], env_specific_para
                  eval_env: bool = False, **device_kw):
     """Same call as the reference's ``make_vec_env``; returns the B-env device environment instead of
     ``SubprocVecEnv([...] * n_envs)``, wrapped in the on-device VecNormalize when ``vec_norm_kwargs`` is given
-    (evaluation envs: statistics frozen, rewards not normalised -- RL/utils.py:64-67).  ``monitor_filename``: episode
-    statistics are SB3 ``VecMonitor``'s job; wrap the returned env with it where SB3 is installed."""
+    (evaluation envs: statistics frozen, rewards not normalised -- RL/utils.py:64-67).  The same three-layer stack as
+    the reference: env -> VecMonitorGPU (episode return / length, ``infos[i]["episode"]``, optional monitor CSV) ->
+    VecNormalizeGPU."""
     if env_id != "TomatoEnv":
         raise NotImplementedError(f"env_id {env_id!r}: only TomatoEnv exists (RL/utils.py:24)")
     env = tomato_vec_env_from_config(n_envs, base_env_params=env_base_params, seed=seed, **env_specific_params,
                                      **device_kw)
+    from .vec_monitor import VecMonitorGPU
+    if monitor_filename is not None and os.path.dirname(monitor_filename):
+        os.makedirs(os.path.dirname(monitor_filename), exist_ok=True)
+    env = VecMonitorGPU(env, filename=monitor_filename)
     if vec_norm_kwargs is not None:
         from .vec_normalize import VecNormalizeGPU
         env = VecNormalizeGPU(env, **vec_norm_kwargs)

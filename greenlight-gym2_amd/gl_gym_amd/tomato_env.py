@@ -323,12 +323,20 @@ class TomatoVecEnv:
         """(obs, rewards, dones, infos) as SB3 consumes them, from step_tensor's device tensors."""
         obs_t, r_t, d_t, info_T = out
         obs, rew = self._obs_to_host(obs_t), r_t.float().cpu().numpy()
+        dones, infos = self.host_infos(d_t, info_T)
+        return obs, rew, dones, infos
+
+    def host_infos(self, d_t, info_T, term_obs=None):
+        """(dones [B] bool, infos) on the host.  term_obs: replacement for the raw terminal observations (a wrapper
+        that rescales observations passes its own)."""
         dones = d_t.cpu().numpy().astype(bool)
         # infos: SB3 wants a list of per-env dicts.  Built from two bulk D2H copies (info block, controls) with
         # zip over Python lists -- the cheapest pure-Python construction (about 1 us per env per key).
         rows = info_T.double().t().cpu().numpy()
         ctrl = self.u.double().cpu().numpy()
-        term = self.term_obs_t.cpu().numpy() if (self.auto_reset and dones.any()) else None
+        term = None
+        if self.auto_reset and dones.any():
+            term = self.term_obs_t.cpu().numpy() if term_obs is None else term_obs
         if self.lazy_infos:
             infos = LazyInfos(L.INFO_KEYS, rows, ctrl, dones, term)
         else:
@@ -338,7 +346,7 @@ class TomatoVecEnv:
             if term is not None:
                 for b in np.nonzero(dones)[0]:
                     infos[b]["terminal_observation"] = term[b]
-        return obs, rew, dones, infos
+        return dones, infos
 
     def step(self, actions):
         self.step_async(actions)

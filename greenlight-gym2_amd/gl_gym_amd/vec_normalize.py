@@ -78,13 +78,12 @@ class VecNormalizeGPU:
         t = self.torch
         obs_n, rew_n, done, info_T = self.step_tensor(t.as_tensor(np.asarray(actions, dtype=np.float32),
                                                                   device=self.venv.device))
-        dones = done.cpu().numpy().astype(bool)
-        info = info_T.double().cpu().numpy()
-        infos = [{k: float(info[i, b]) for i, k in enumerate(L.INFO_KEYS)} for b in range(self.num_envs)]
-        if self.venv.auto_reset and dones.any():
+        # infos come from the wrapped env (so a VecMonitorGPU underneath keeps its "episode" entries); the terminal
+        # observations are handed over normalised, as SB3's VecNormalize does
+        term = None
+        if self.venv.auto_reset and bool(done.any()):
             term = self.normalize_obs(self.venv.term_obs_t.cpu().numpy())
-            for b in np.nonzero(dones)[0]:
-                infos[b]["terminal_observation"] = term[b]
+        dones, infos = self.venv.host_infos(done, info_T, term)
         return obs_n.cpu().numpy(), rew_n.cpu().numpy(), dones, infos
 
     def normalize_obs(self, obs):

@@ -52,8 +52,11 @@ def test_make_vec_env_from_reference_style_config(cfg_dir):
     from gl_gym_amd.make_env import load_env_params, make_vec_env
     from gl_gym_amd.tomato_env import TomatoVecEnv
     base, spec = load_env_params("TomatoEnv", str(cfg_dir))
-    env = make_vec_env("TomatoEnv", base, spec, seed=666, n_envs=256, dtype="float64")
-    assert isinstance(env, TomatoVecEnv) and env.N == 48 and env.Np == 0 and env.num_envs == 256
+    from gl_gym_amd.vec_monitor import VecMonitorGPU
+    mon_file = str(cfg_dir / "logs" / "train")
+    env = make_vec_env("TomatoEnv", base, spec, seed=666, n_envs=256, monitor_filename=mon_file, dtype="float64")
+    assert isinstance(env, VecMonitorGPU) and isinstance(env.venv, TomatoVecEnv)
+    assert env.N == 48 and env.Np == 0 and env.num_envs == 256
     obs = env.reset()
     days = np.array(env.get_attr("start_day"))
     assert set(np.unique(days)) == {0.0, 1.0} and 64 < (days == 0).sum() < 192          # both training days get drawn
@@ -64,15 +67,28 @@ def test_make_vec_env_from_reference_style_config(cfg_dir):
                           dtype="float64", start_days=[1.0], auto_reset=False)
     np.testing.assert_array_equal(direct.reset()[0], obs[b])
     a = np.zeros((256, 6), np.float32)
+    ret = np.zeros(256)
     for _ in range(49):
         obs, rew, done, infos = env.step(a)
+        ret += rew
     assert done.all() and "terminal_observation" in infos[0]              # N + 1 = 49 steps, SB3 auto-reset
+    # VecMonitor semantics: episode return = sum of raw rewards, length = N + 1; one CSV row per finished episode
+    ep = infos[5]["episode"]
+    assert ep["l"] == 49 and abs(ep["r"] - ret[5]) < 1e-5 and env.episode_count == 256
+    assert float(env.episode_returns.abs().max()) == 0.0 and int(env.episode_lengths.max()) == 0
+    obs, rew, done, infos = env.step(a)
+    assert not done.any() and "episode" not in infos[5] and int(env.episode_lengths.min()) == 1
     env.close(); direct.close()
+    rows = open(mon_file + ".monitor.csv").read().strip().split("\n")
+    assert rows[0].startswith("#{") and rows[1] == "r,l,t" and len(rows) == 2 + 256
     # evaluation env with VecNormalize: statistics frozen, rewards raw (RL/utils.py:64-67)
     ev = make_vec_env("TomatoEnv", dict(base, training=False), spec, seed=1, n_envs=8, vec_norm_kwargs=dict(
         norm_obs=True, norm_reward=True, clip_obs=10.0, gamma=0.99), eval_env=True)
     assert ev.training is False and ev.norm_reward is False
-    assert set(ev.get_attr("start_day")) == {0.0} or True
     ev.reset()
-    assert set(ev.venv.get_attr("start_day")) == {1.0}                    # eval_options.eval_days
+    assert set(ev.get_attr("start_day")) == {1.0}                         # eval_options.eval_days
+    for _ in range(49):
+        obs, rew, done, infos = ev.step(np.zeros((8, 6), np.float32))
+    assert done.all() and infos[0]["episode"]["l"] == 49                  # monitor entries survive the VecNormalize layer
+    assert np.abs(infos[0]["terminal_observation"]).max() <= 10.0         # ... and terminal observations come normalised
     ev.close()
