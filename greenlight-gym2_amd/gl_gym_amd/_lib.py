@@ -15,6 +15,13 @@ ODE, ODE_PIPE = 0, 1
 SCHEME_RK4, SCHEME_RK2 = 0, 1
 SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2}
 DEFAULT_N_SUB = {"rk4": 256, "rk2": 360}      # same 16-19 % stability margin over the 0.67 1/s cover mode
+
+
+def default_n_sub(scheme: str, dt: float) -> int:
+    """Sub-steps per env-step when the caller gives none: the scheme's count for the reference's dt = 900 s, scaled up
+    (never down) for longer steps so that h = dt / n_sub keeps its stability margin."""
+    n = DEFAULT_N_SUB[scheme] * max(1.0, float(dt) / 900.0)
+    return int(-(-n // 4) * 4)
 OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",

@@ -25,7 +25,7 @@ class GreenLight:
         self._lib = L.load()
         if scheme not in L.SCHEMES:
             raise ValueError("scheme must be 'rk4' or 'rk2'")
-        n_sub = L.DEFAULT_N_SUB[scheme] if n_sub is None else n_sub
+        n_sub = L.default_n_sub(scheme, dt) if n_sub is None else n_sub
         self.scheme, self.n_sub = scheme, int(n_sub)
         self.nx, self.nu, self.nd, self.np = int(nx), int(nu), int(nd), int(np_)
         self.dt = float(dt)

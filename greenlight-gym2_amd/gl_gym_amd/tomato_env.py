@@ -146,7 +146,7 @@ class TomatoVecEnv:
         if scheme not in L.SCHEMES:
             raise ValueError("scheme must be 'rk4' or 'rk2'")
         self.scheme = scheme
-        self.n_sub = int(L.DEFAULT_N_SUB[scheme] if n_sub is None else n_sub)
+        self.n_sub = int(L.default_n_sub(scheme, self.dt) if n_sub is None else n_sub)
         self.uncertainty_scale = float(uncertainty_scale)
         self.auto_reset = auto_reset
         self.lazy_infos = (int(num_envs) > 4096) if lazy_infos is None else bool(lazy_infos)
@@ -429,7 +429,7 @@ class TomatoVecEnv:
             raise ValueError("scheme must be 'rk4' or 'rk2'")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
         self.scheme = scheme
-        self.set_n_sub(L.DEFAULT_N_SUB[scheme] if n_sub is None else n_sub)
+        self.set_n_sub(L.default_n_sub(scheme, self.dt) if n_sub is None else n_sub)
 
     def set_n_sub(self, n_sub: int):
         self.n_sub = int(n_sub)
