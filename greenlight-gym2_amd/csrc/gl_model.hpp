@@ -982,7 +982,12 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     const T hw = h * T(WIN), hw2 = T(0.5) * hw;        // harvest flow: once per window
     T y[NX], xs[NX], k[NX], acc[NX];
     // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 21..26)
-    T dprev[15], dmark[15];
+    // The window increment is summed from the sub-step increments in fp32 (cheapest) and taken as a difference of del in
+    // fp64: hipcc 7.2 miscompiles the fp64 step kernel with the summed form (results off by 1e-9..1e-5 against the host
+    // build of the same code and against the oracle; the fp64 kernels spill heavily, see rhs_stage_f64), and the
+    // difference form is what the fp64 parity tests pinned.
+    constexpr bool SUM_INCS = sizeof(T) == 4;
+    T dprev[15], dwin[15];
 #pragma unroll
     for (int j = 0; j < 15; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
@@ -1006,7 +1011,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int i = 0; i < NX; ++i)
                     if (gl_slow_slot(i) >= 0) {
                         xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
-                        dmark[gl_slow_slot(i)] = del[i];
+                        if (!SUM_INCS) dwin[gl_slow_slot(i)] = del[i];
                     }
                 RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
             }
@@ -1022,19 +1027,28 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    del[i] += gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);     // k1 = k2 = k3 = k4 for those
+                for (int i = 0; i < NX; ++i) {
+                    const T inc = gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);     // k1 = k2 = k3 = k4 for those
+                    del[i] += inc;
+                    if (SUM_INCS && gl_slow_slot(i) >= 0)
+                        dwin[gl_slow_slot(i)] = (j == 0) ? inc : dwin[gl_slow_slot(i)] + inc;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) xs[i] = y[i] + h2 * k[i];
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) del[i] += h * k[i];
+                for (int i = 0; i < NX; ++i) {
+                    const T inc = h * k[i];
+                    del[i] += inc;
+                    if (SUM_INCS && gl_slow_slot(i) >= 0)
+                        dwin[gl_slow_slot(i)] = (j == 0) ? inc : dwin[gl_slow_slot(i)] + inc;
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dmark[gl_slow_slot(i)];
+        for (int i = 0; i < NX; ++i)                        // increment of the window's RK part (harvest excluded)
+            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = SUM_INCS ? dwin[gl_slow_slot(i)] : del[i] - dwin[gl_slow_slot(i)];
         const T hh = (it == n_win - 1) ? hw2 : hw;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);

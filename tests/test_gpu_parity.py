@@ -459,3 +459,29 @@ def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
         m.set_n_sub(357)                       # n_sub is rounded up to a multiple of the 4-sub-step window
         np.testing.assert_array_equal(np.array(m.evalF(X[0], U[0], D[0], P[0])), got[0])
         m.close()
+
+
+@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 1), ("rk2", 2, 4)])
+def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win):
+    """The fp64 step kernels spill heavily and hipcc 7.2 has miscompiled them before (rk_delta's
+    SUM_INCS note): every env-step of a short rollout must agree with the oracle's restatement of the same scheme to
+    rounding level, through glgym_step AND glgym_evalF (two different kernels around the same integrator)."""
+    import torch
+    from gl_gym_amd import GreenLight
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = golden("rollout_3day_synth")
+    A, W, XR = g["actions"], g["weather"], g["X"]
+    p = golden("params_default")["p"].astype(np.float64)
+    env = TomatoVecEnv(64, weather=W, dtype="float64", scheme=scheme, season_length=3, auto_reset=False)
+    env.reset()
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme)
+    u = np.zeros(6)
+    for k in range(16):
+        x_prev = env.x[0].double().cpu().numpy().copy()
+        env.step_tensor(torch.as_tensor(np.repeat(A[k][None], 64, 0), device=env.device), want_obs=False)
+        u = np.clip(u + A[k] * np.float32(0.1), 0, 1)
+        ref = oracle.rk_lagged(x_prev, u, W[k], p, 900.0, env.n_sub, order, win)
+        sc = np.maximum(np.abs(ref), 1e-3 * np.abs(XR).max(axis=0))
+        assert np.max(np.abs(env.x[0].double().cpu().numpy() - ref) / sc) < 1e-11, (scheme, k, "glgym_step")
+        assert np.max(np.abs(np.array(m.evalF(x_prev, u, W[k], p)) - ref) / sc) < 1e-11, (scheme, k, "glgym_evalF")
+    env.close(); m.close()

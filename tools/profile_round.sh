@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 set -x
 SCHEME=${SCHEME:-rk4}
-OUT=gpurun_out/v8_$SCHEME
+OUT=gpurun_out/${TAG:-v9}_$SCHEME
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --scheme $SCHEME > $OUT/bench_stats.log 2>&1
 grep "^{" $OUT/bench_stats.log > $OUT/bench_line.json
