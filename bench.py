@@ -38,8 +38,8 @@ PEAK_HBM_GBPS = 8000.0
 BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum, without the obs block
 # HBM bytes per step_kernel launch from rocprofv3 PMC passes on the DEFAULT workload (B = 65 536, fp32):
 # FETCH_SIZE 5 785 KB (x2: gfx950 reports half of the fetched bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 12 352 KB;
-# profiles/r01_v8_pmc_summary.csv.  bench.py cannot collect counters itself, so this is a recorded measurement.
-PMC_TRAFFIC_DEFAULT = (2 * 5741.38 + 12384.0) * 1024
+# profiles/r01_v9_rk4_pmc_summary.csv.  bench.py cannot collect counters itself, so this is a recorded measurement.
+PMC_TRAFFIC_DEFAULT = (2 * 5749.69 + 12384.0) * 1024
 
 
 DEFAULT_SCHEME = "rk4"
@@ -242,16 +242,17 @@ def main():
                                  "block, soil chain) evaluated once per sub-step at the predicted midpoint (DESIGN.md 2)"},
             "roofline": {"bound": "valu", "kernel": "step_kernel", "achieved": ach_tflops, "peak": PEAK_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": frac,
-                         "traffic": PMC_TRAFFIC_DEFAULT if (B == 65536 and args.dtype == "f32" and not args.uncertainty)
+                         "traffic": PMC_TRAFFIC_DEFAULT if (B == 65536 and args.dtype == "f32" and not args.uncertainty
+                                                            and args.scheme == "rk4")
                          else None,
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                         "WRITE_SIZE, recorded in profiles/r01_v8_pmc_summary.csv (default workload only)",
+                                         "WRITE_SIZE, recorded in profiles/r01_v9_rk4_pmc_summary.csv (default workload only)",
                          "note": "path is VALU/transcendental-bound, not HBM/MFMA (SURVEY 8d): achieved = algorithmic "
                                  "add/mul flops (stages*n_sub*1502 per env-step, stages = 4 rk4 / 2 rk2) / mean "
                                  "step_kernel time; frac adds the quarter-rate special-op term (stages*n_sub*219)",
                          "executed_note": "frac > 1 because the kernel executes far less than the reference expression "
                                           "graph (hoisting, CSE, slow sub-expressions once per sub-step): PMC on the "
-                                          "default workload (profiles/r01_v8_pmc_summary.csv) counts 4.70e8 VALU wave-"
+                                          "default workload (profiles/r01_v9_rk4_pmc_summary.csv) counts 4.70e8 VALU wave-"
                                           "instructions per launch (1 791 per RK4 sub-step per wave, 192 of them "
                                           "transcendental) and SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.887 VALU-busy "
                                           "at one wave per SIMD -- the issue roof that actually binds",
