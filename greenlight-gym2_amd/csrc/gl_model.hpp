@@ -526,10 +526,13 @@ template <class T> struct SlowCoef {
     // soil chain (aux_states.hpp:905-935, a158..a163): linear conduction floor -> 5 layers -> deep soil, hours to weeks
     T hFlrSo1;                              // conduction floor -> layer 1 (also leaves the floor balance)
     T dSo1, dSo2, dSo3, dSo4, dSo5;         // d/dt of the five layer temperatures
+    // grow pipes (unheated in the reference, aux_states.hpp:1221: a221 = 0): they relax towards air / canopy with small
+    // fluxes; both fluxes and the pipe's own balance are held at their window-midpoint value
+    T hGroPipeAir, rGroPipeCan, dGro;
 };
 
 // ym: the state the slow sub-expressions are evaluated at.  Entries read: 0 co2Air, 2 tAir, 4 tCan, 8 tFlr, 10..14 soil,
-// 21 tCan24, 22 cBuf, 23 cLeaf, 24 cStem, 25 cFruit, 26 tCanSum.
+// 19 tGroPipe, 21 tCan24, 22 cBuf, 23 cLeaf, 24 cStem, 25 cFruit, 26 tCanSum.
 template <class T>
 GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, SlowCoef<T>& q)
 {
@@ -644,6 +647,16 @@ GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, 
     q.dSo3 = m.iCapSo3 * (hSo23 - hSo34);
     q.dSo4 = m.iCapSo4 * (hSo34 - hSo45);
     q.dSo5 = m.iCapSo5 * (hSo45 - hSo5Out);
+
+    // ---- grow pipes (aux_states.hpp:560, 930)
+    {
+        const T c2k = Kelvin<T>::c2k();
+        auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };
+        const T dGA = ym[19] - tAir;
+        q.hGroPipeAir = m.cGroPipeAir * M::powa(M::abs(dGA + eps), T(0.32)) * dGA;
+        q.rGroPipeCan = m.fGroPipeCan * (q4(ym[19]) - q4(tCan));
+        q.dGro = m.iCapGroPipe * (-q.rGroPipeCan - q.hGroPipeAir);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -662,12 +675,12 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
 
     const T co2Air = x[0], co2Top = x[1], tAir = x[2], tTop = x[3], tCan = x[4], tCovIn = x[5], tCovE = x[6];
     const T tThScr = x[7], tFlr = x[8], tPipe = x[9], vpAir = x[15], vpTop = x[16], tLamp = x[17];
-    const T tGroPipe = x[19], tBlScr = x[20], tCan24 = x[21], cLeaf = x[23], cFruit = x[25];
+    const T tBlScr = x[20], tCan24 = x[21], cLeaf = x[23], cFruit = x[25];
 
     // ---- long wave: sigma*T^4 per surface, then pairwise exchange (aux_states.hpp:493-632)
     auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };   // sigma lives in the coefficients
     const T qCan = q4(tCan), qCovIn = q4(tCovIn), qCovE = q4(tCovE), qThScr = q4(tThScr), qFlr = q4(tFlr);
-    const T qPipe = q4(tPipe), qLamp = q4(tLamp), qBlScr = q4(tBlScr), qGro = q4(tGroPipe), qSky = s.qSky;
+    const T qPipe = q4(tPipe), qLamp = q4(tLamp), qBlScr = q4(tBlScr), qSky = s.qSky;
 
     const T rCanCovIn = q.kCanCovIn * (qCan - qCovIn);
     const T rCanSky = q.kCanSky * (qCan - qSky);
@@ -694,7 +707,6 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T rLampCovIn = s.cLampCovIn * (qLamp - qCovIn);
     const T rLampSky = s.cLampSky * (qLamp - qSky);
     const T rLampBlScr = s.cLampBlScr * (qLamp - qBlScr);
-    const T rGroPipeCan = m.fGroPipeCan * (qGro - qCan);
     const T rBlScrThScr = s.cBlScrThScr * (qBlScr - qThScr);
     const T rBlScrCovIn = s.cBlScrCovIn * (qBlScr - qCovIn);
     const T rBlScrSky = s.cBlScrSky * (qBlScr - qSky);
@@ -756,9 +768,8 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T hTopCovIn = M::abs(hecTopCov) * dTopCov;
     const T hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
     const T hCovEOut = s.covOutK * (tCovE - s.tOut);
-    const T dPA = tPipe - tAir, dGA = tGroPipe - tAir;
+    const T dPA = tPipe - tAir;
     const T hPipeAir = m.cPipeAir * M::powa(M::abs(dPA + eps), T(0.32)) * dPA;
-    const T hGroPipeAir = m.cGroPipeAir * M::powa(M::abs(dGA + eps), T(0.32)) * dGA;
     const T hCovInCovE = m.cCovCond * (tCovIn - tCovE);
     const T hLampAir = m.cLampAir * (tLamp - tAir);
 
@@ -811,11 +822,11 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     dx[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
     dx[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
     dx[2] = m.iCapAir * (hCanAir + hPipeAir + q.swAir - hAirFlr - hAirThScr - hAirOut - hAirTop - hAirBlScr +
-                         hLampAir + hGroPipeAir + hIntLampAir);
+                         hLampAir + q.hGroPipeAir + hIntLampAir);
     dx[3] = m.iCapTop * (hThScrTop + hAirTop - hTopCovIn - hTopOut + hBlScrTop);
     dx[4] = q.iCapCan *
             (q.swCan + rPipeCan - hCanAir - L * mvCanAir - rCanCovIn - rCanFlr - rCanSky - rCanThScr -
-             rCanBlScr + rLampCan + rGroPipeCan + iToCan);
+             rCanBlScr + rLampCan + q.rGroPipeCan + iToCan);
     dx[5] = m.iCapCov * (hTopCovIn + L * mvTopCovIn + rCanCovIn + rFlrCovIn + rPipeCovIn + rThScrCovIn - hCovInCovE +
                          rLampCovIn + rBlScrCovIn + iToCovIn);
     dx[6] = m.iCapCov * (s.sunCovE + hCovInCovE - hCovEOut - rCovESky);
@@ -835,7 +846,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     dx[17] = m.iCapLamp * (s.lampNet - hLampAir - rLampSky - rLampCovIn - rLampThScr - rLampPipe - rLampBlScr -
                            rLampFlr - rLampCan + iToLamp);
     dx[18] = m.iCapIntLamp * (-hIntLampAir - iToSky - iToCovIn - iToThScr - iToPipe - iToBlScr - iToFlr - iToCan - iToLamp);
-    dx[19] = m.iCapGroPipe * (-rGroPipeCan - hGroPipeAir);
+    dx[19] = q.dGro;
     if (PIPE) {
         dx[9] = (s.pipeTrack != T(0)) ? (s.tPipeSet - x[9]) : dx[9];      // ode.hpp:184-189
         dx[19] = T(0);                                                    // ode.hpp:240
@@ -963,10 +974,13 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
 // slot of state i in the integrator's "previous increment" array, -1 if tier 2b does not read the state
 GL_HD constexpr int gl_slow_slot(int i)
 {
-    return i == 0 ? 0 : i == 2 ? 1 : i == 4 ? 2 : i == 8 ? 3 : (i >= 10 && i <= 14) ? i - 6 : (i >= 21 && i <= 26) ? i - 12 : -1;
+    return i == 0 ? 0 : i == 2 ? 1 : i == 4 ? 2 : i == 8 ? 3 : (i >= 10 && i <= 14) ? i - 6 : i == 19 ? 9
+           : (i >= 21 && i <= 26) ? i - 11 : -1;
 }
-// states whose derivative tier 2b holds constant over a sub-step (soil layers, crop pools): RK4 degenerates to  h * dx
-GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || (i >= 22 && i <= 25); }
+// states whose derivative tier 2b holds constant over a sub-step (soil layers, grow pipes, crop pools): RK4 degenerates
+// to  h * dx
+GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || i == 19 || (i >= 22 && i <= 25); }
+constexpr int GL_N_SLOW = 16;
 
 // ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 2 = explicit midpoint
 // (2.0, i.e. 1.0 per stage: the same stability margin with 30 % fewer right-hand sides; second order, which at h ~ 2.5 s
@@ -981,15 +995,15 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     const T h = dt / T(n_win * WIN), h2 = T(0.5) * h, h6 = h / T(6);
     const T hw = h * T(WIN), hw2 = T(0.5) * hw;        // harvest flow: once per window
     T y[NX], xs[NX], k[NX], acc[NX];
-    // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 21..26)
+    // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 19, 21..26)
     // The window increment is summed from the sub-step increments in fp32 (cheapest) and taken as a difference of del in
     // fp64: hipcc 7.2 miscompiles the fp64 step kernel with the summed form (results off by 1e-9..1e-5 against the host
     // build of the same code and against the oracle; the fp64 kernels spill heavily, see rhs_stage_f64), and the
     // difference form is what the fp64 parity tests pinned.
     constexpr bool SUM_INCS = sizeof(T) == 4;
-    T dprev[15], dwin[15];
+    T dprev[GL_N_SLOW], dwin[GL_N_SLOW];
 #pragma unroll
-    for (int j = 0; j < 15; ++j) dprev[j] = T(0);
+    for (int j = 0; j < GL_N_SLOW; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);

@@ -616,15 +616,16 @@ static void rk4_split_impl(const double *x0, const double *u, const double *d, c
  *  (i)  the auxiliaries see the three slowest states that feed expensive sub-expressions -- x23 cLeaf (-> LAI -> all
  *       canopy optics and canopy FIR view factors), x21 tCan24 (1-day filter) and x26 tCanSum -- and
  *  (ii) the whole crop block a[191..216] (photosynthesis, carbohydrate flows, respiration), which feeds only dx22..25
- *       and, through a216 = mcAirCan, dx0, and the soil conduction chain a[158..163] (dx10..14 and, through a158, dx8)
+ *       and, through a216 = mcAirCan, dx0; the soil conduction chain a[158..163] (dx10..14 and, through a158, dx8); the
+ *       two small fluxes of the unheated grow pipes a105, a166 (dx19 and their share of dx2, dx4)
  * at the predicted sub-step MIDPOINT state  ymid = y + dprev/2  (dprev = increment over the previous sub-step's RK4 part;
  * 0 for the first sub-step of an env-step).  Every other balance, including dx21's own relaxation term, is evaluated at
  * the stage state.  The midpoint prediction makes the lag second order: against the tight fixtures the error is 1.27e-6
  * (10 days) / 1.65e-6 (3 days) with and without it, whereas a plain start-of-sub-step freeze of tCan24 alone costs 1e-4
  * in cBuf (the inhibition logistics are steep).  The kernels evaluate those sub-expressions once per sub-step instead of
- * four times.  Bits of gl_lag_mask (experiments; production = 199): 1 tCan24, 2 cLeaf, 4 tCanSum, 8 cBuf, 16 cStem+cFruit,
- * 32 soil layers as states, 64 crop block, 128 soil chain (needs 64). */
-int gl_lag_mask = 199;
+ * four times.  Bits of gl_lag_mask (experiments; production = 455): 1 tCan24, 2 cLeaf, 4 tCanSum, 8 cBuf, 16 cStem+cFruit,
+ * 32 soil layers as states, 64 crop block, 128 soil chain (needs 64), 256 grow-pipe fluxes (needs 64). */
+int gl_lag_mask = 455;
 static void rhs_lagged(const double *xs, const double *ymid, const double *u, const double *d, const double *p,
                        double *dx, int pipe)
 {
@@ -644,6 +645,11 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
         if (pipe) gl_oracle_rhs_pipe(xt, u, d, p, dx, as); else gl_oracle_rhs(xt, u, d, p, dx, as);
         dx[0] += (1.0 / p[122]) * (as[216] - am[216]);
         for (int i = 22; i <= 25; ++i) dx[i] = dm[i];
+        if (gl_lag_mask & 256) {   /* grow pipes (a105 rGroPipeCan, a166 hGroPipeAir; unheated: a221 = 0) at the midpoint */
+            dx[2] += (1.0 / p[112]) * (am[166] - as[166]);
+            dx[4] += (1.0 / as[32]) * (am[105] - as[105]);
+            dx[19] = dm[19];
+        }
         if (gl_lag_mask & 128) {   /* soil chain (a158..a163: conduction floor -> 5 layers -> deep soil) at the midpoint */
             dx[8] += (1.0 / p[113]) * (as[158] - am[158]);
             for (int i = 10; i <= 14; ++i) dx[i] = dm[i];
