@@ -180,17 +180,6 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
         make_crop_const<T, T>(pc, a.gasR, a.tCanMin, crLocal);
     }
     const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
-#if defined(GL_COEF_IN_LDS)
-    // experiment: tier-2 coefficients of each lane staged in LDS instead of VGPRs
-    __shared__ StepCoef<T> s_lds[WAVE];
-    {
-        StepCoef<T> tmp;
-        precompute(u, d, m, cr, tmp);
-        s_lds[lane] = tmp;
-    }
-    __syncthreads();
-    const StepCoef<T>& s = s_lds[lane];
-#else
     StepCoef<T> s;
     precompute(u, d, m, cr, s);
     if (PIPE) {                                                           // ode.hpp:184-189
@@ -198,7 +187,6 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
         s.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
         s.tPipeSet = tPipe;
     }
-#endif
     T del[NX];
     bool bad;
     const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : 1>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
