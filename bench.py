@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step sequence from a captured HIP graph (one launch per step instead of five); the "
+                         "step_kernel time for the roofline leg is then taken from W eager warm-up steps")
     ap.add_argument("--no-alt-scheme", action="store_true", help="skip the informational leg with the other sub-stepper")
     ap.add_argument("--uncertainty", type=float, default=0.0, help="crop-parameter noise scale (config 5: 0.2)")
     ap.add_argument("--vecnorm", action="store_true", help="also run the on-device VecNormalize (obs + reward) each step")
@@ -173,9 +176,15 @@ def main():
         if vn is not None:
             vn._call(env.obs_t, env.reward_t, env.done_t)
 
+    warm_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(W)]
     for i in range(W):
-        one_step(i)
+        one_step(i, warm_events[i])
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    replay = None
+    if args.graph:
+        if vn is not None or args.uncertainty > 0:
+            raise SystemExit("--graph: not with --vecnorm / --uncertainty (host-side per-step state)")
+        replay = env.capture_step_graph(want_obs=not args.no_obs)
     if env.metrics_t is not None:
         env.metrics_t.zero_()
     if use_dist:
@@ -183,13 +192,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        one_step(W + i, events[i])
+        if replay is not None:
+            replay(acts[(W + i) % len(acts)])
+        else:
+            one_step(W + i, events[i])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in (warm_events if replay is not None else events)]))
     m = env.metrics()
 
     # Informational second leg (never `value`): the same K steps with the other sub-stepper the library offers
@@ -234,7 +246,7 @@ def main():
                                    "weather year (KNMI Amsterdam files absent), random actions U(-1,1)",
                        "batch_per_gpu": B, "global_batch": B * world, "integrator": args.scheme, "n_sub": args.n_sub,
                        "dt_s": 900,
-                       "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True,
+                       "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True, "hip_graph": bool(args.graph),
                        "vecnormalize": bool(args.vecnorm),
                        "uncertainty_scale": args.uncertainty, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE, n_sub=256 run",

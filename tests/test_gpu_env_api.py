@@ -189,3 +189,29 @@ def test_step_rule_based_closed_loop_matches_host_mirror(golden):
         assert bool(da[0]) == (k == 96)
     assert set(ia[0]) >= {"EPI", "controls"}
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_step_graph_replay_equals_eager_steps(golden):
+    """capture_step_graph(): the five launches of a step replayed from one HIP graph give bit-identical tensors to
+    step_tensor, across an episode boundary (auto-reset inside the graph)."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"]
+    kw = dict(weather=w, dtype="float32", season_length=0.05, start_rows=[0, 40, 300], start_days=[0.0, 0.4167, 3.125], seed=3)
+    a, b = TomatoVecEnv(200, **kw), TomatoVecEnv(200, **kw)
+    a.reset_tensor(); b.reset_tensor()
+    replay = b.capture_step_graph()
+    assert torch.equal(a.x_T, b.x_T) and torch.equal(a.timestep_t, b.timestep_t)     # capture left the state alone
+    g = torch.Generator(device=a.device); g.manual_seed(0)
+    for k in range(12):                                   # N = 4: episodes end at steps 5 and 10
+        act = torch.rand(200, 6, generator=g, device=a.device) * 2 - 1
+        oa, ra, da, ia = a.step_tensor(act)
+        ob, rb, db, ib = replay(act)
+        for ta, tb in ((oa, ob), (ra, rb), (da, db), (ia, ib), (a.x_T, b.x_T), (a.term_obs_t, b.term_obs_t),
+                       (a.w_off_t, b.w_off_t)):
+            assert torch.equal(ta, tb), k
+        assert bool(da.all()) == (k % 5 == 4)
+    ma, mb = a.metrics(), b.metrics()                     # float atomics: order-dependent in the last bits
+    assert all(abs(ma[k] - mb[k]) <= 1e-5 * max(1.0, abs(ma[k])) for k in ma)
+    a.close(); b.close()
