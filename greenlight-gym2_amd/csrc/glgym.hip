@@ -128,6 +128,10 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #ifndef GL_STEP_WAVES_PER_SIMD
 #define GL_STEP_WAVES_PER_SIMD 1
 #endif
+// Tier-2b / harvest window of the RK4 scheme: two sub-steps (7 s) in fp32, where rounding (1e-5) hides the 2e-6 this costs
+// against the tight fixtures; one sub-step in fp64, the parity configuration.  (The explicit-midpoint scheme uses 4.)
+template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? 2 : 1; };
+
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
 // RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by four of them (GLGYM_SCHEME_RK2)
 // instead of classical RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
     }
     T del[NX];
     bool bad;
-    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : 1>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
+    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : 1>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
+    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
     for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
 }
 
