@@ -86,7 +86,7 @@ int hostmath_step_scheme(const double* x, const double* u, const double* d, cons
         else run_scheme<double, O, W>(x, u, d, p, dt, n_sub, x_next);              \
         return 0;                                                                  \
     }
-    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4)
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 4) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4)
 #undef GL_CASE
     return -1;
 }
