@@ -11,7 +11,13 @@
 //   tier 2  StepCoef<T>    -- everything that depends on (u, d) of THIS env-step (cover optics, FIR view
 //                             factors, ventilation constants, lamp/boiler inputs...).  Per lane, VGPRs,
 //                             computed once per env-step and amortised over 4*n_sub RHS evaluations.
-//   tier 3  rhs()          -- the state-dependent remainder, one lane per environment.
+//   tier 2b SlowCoef<T>    -- state-dependent sub-expressions whose outputs drive only slow balances (LAI optics and
+//                             canopy FIR coefficients, the crop block, the soil chain, the grow pipes): once per
+//                             window of 1-4 sub-steps at the predicted window midpoint (slow_coef()).
+//   tier 3  rhs_fast()     -- the remainder that follows the fast states, one lane per environment, four (RK4) or two
+//                             (explicit midpoint) evaluations per sub-step; its FIR block runs on register pairs in fp32.
+//   rhs() = slow_coef() + rhs_fast() at one state = the reference's right-hand side (test hook, glgym_rhs).
+//   rk_delta<T, PIPE, ORDER, WIN>() -- the sub-stepper, in delta form, with the exact harvest sub-flow.
 //
 // fp32-specific measures (hard part 2), all algebraically identical to the reference:
 //   * harvest switch as a logistic instead of (tanh z + 1)/2      (aux_states.hpp:75-79)
@@ -22,7 +28,7 @@
 //
 // The header also compiles with a plain host compiler (GL_HD empty): tests/ builds a host-only
 // library from it to unit-test this exact arithmetic against the oracle on machines without a GPU.
-// The product (C-ABI in glgym_capi.hip) never uses that host build.
+// The product (C ABI in glgym.hip) never uses that host build.
 #pragma once
 #include <cmath>
 
