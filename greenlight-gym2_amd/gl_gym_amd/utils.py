@@ -40,6 +40,33 @@ def vaporPres2rh(temp, vaporPres):
     return np.clip(100 * vaporPres / satVp(temp), a_min=0., a_max=100.)
 
 
+def vaporDens2rh(temp, vaporDens):
+    """Vapour density [kg m-3] -> relative humidity [%], clipped to 0..100 (ideal gas law over the Magnus saturation pressure)."""
+    return np.clip(100.0 * 8.3144598 * (temp + 273.15) / (18.01528e-3 * satVp(temp)) * vaporDens, 0, 100)
+
+
+def compute_sky_temp(air_temp, cloud):
+    """Sky temperature [C] from air temperature [C] and cloud cover (0-1): clear-sky long-wave 213 + 5.5 T, emissivity
+    blended towards 1 with 0.84 * cloud, radiating temperature of the result."""
+    sigma, c2k = 5.67e-8, 273.15
+    t4 = sigma * (air_temp + c2k) ** 4
+    eps = (1 - 0.84 * cloud) * (213 + 5.5 * air_temp) / t4 + 0.84 * cloud
+    return (eps * t4 / sigma) ** 0.25 - c2k
+
+
+def days2date(timeInDays, referenceDate):
+    """Days since ``referenceDate`` ('DD-MM-YYYY') -> list of 'YYYY-MM-DD HH:MM:SS' strings (minutes truncated)."""
+    from datetime import datetime, timedelta
+    ref = datetime.strptime(referenceDate, "%d-%m-%Y")
+    t = np.atleast_1d(np.asarray(timeInDays, dtype=np.float64))
+    days = np.floor(t).astype(int)
+    hours_f = (t - days) * 24
+    hours = hours_f.astype(int)
+    minutes = ((hours_f - hours) * 60).astype(int)
+    return [(ref + timedelta(days=int(d), hours=int(h), minutes=int(m))).strftime("%Y-%m-%d %H:%M:%S")
+            for d, h, m in zip(days, hours, minutes)]
+
+
 def soilTempNl(time):
     year = 3600 * 24 * 365
     return 10 + 5 * np.sin((2 * np.pi * (time + 0.625 * year) / year))
@@ -104,6 +131,19 @@ def compute_is_day(rad, dt):
             smooth[k - half:k + half] = 1 - ramp_s
             in_sunset = True
     return is_day, smooth
+
+
+# the reference's spellings of the two helpers above (gl_gym/environments/utils.py:177, 214)
+dailLightSum = daily_light_sum
+computeisDay = compute_is_day
+
+
+def expandWeatherData(weatherDataDir, rawWeather, location, source, growthYear, time, dt):
+    """Append next year's CSV (time column shifted to continue after ``time[-1]``) to ``rawWeather``."""
+    import pandas as pd
+    nxt = pd.read_csv(join(join(weatherDataDir, location), source + str(growthYear + 1)) + ".csv", sep=",")
+    nxt["time"] += time[-1] + dt
+    return pd.concat([rawWeather, nxt.iloc[:, :]])
 
 
 def weather_from_raw(time, i_glob, t_out, rh, wind, t_sky, h, nd=10, co2_ppm=400):

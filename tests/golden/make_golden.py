@@ -318,7 +318,20 @@ def g_pipe():
     np.savez_compressed(HERE / "pipe_kat.npz", X=X, U=U, D14=D14, P=P, DX=DX, X_tight300=XT)
 
 
-ALL = dict(pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+def g_helpers2():
+    """Known answers for the remaining helpers of environments/utils.py (vaporDens2rh, compute_sky_temp, days2date)."""
+    from gl_gym.environments.utils import vaporDens2rh, compute_sky_temp, days2date
+    t = np.linspace(-5, 35, 9)
+    vd = np.linspace(1e-3, 3e-2, 9)
+    cl = np.linspace(0, 1, 9)
+    days = np.array([0.0, 0.5, 1.25, 58.999, 365.75])
+    np.savez_compressed(HERE / "weather_helpers2.npz", t=t, vd=vd, cloud=cl, vaporDens2rh=vaporDens2rh(t, vd),
+                        compute_sky_temp=compute_sky_temp(t, cl), days=days,
+                        days2date=np.array(days2date(days, "01-01-2009")))
+    print("weather_helpers2 ok")
+
+
+ALL = dict(helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

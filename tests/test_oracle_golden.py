@@ -148,6 +148,11 @@ def test_weather_loader_and_helpers(golden):
                         vaporDens2pres=U.vaporDens2pres(t, U.rh2vaporDens(t, rh)), co2dens2ppm=U.co2dens2ppm(t, 7e-4),
                         vaporPres2rh=U.vaporPres2rh(t, 1500.), soilTempNl=U.soilTempNl(np.linspace(0, 3e7, 9))).items():
         np.testing.assert_allclose(v, h[name], rtol=1e-14, err_msg=name)
+    h2 = golden("weather_helpers2")
+    np.testing.assert_allclose(U.vaporDens2rh(h2["t"], h2["vd"]), h2["vaporDens2rh"], rtol=1e-14)
+    np.testing.assert_allclose(U.compute_sky_temp(h2["t"], h2["cloud"]), h2["compute_sky_temp"], rtol=1e-12)
+    assert U.days2date(h2["days"], "01-01-2009") == [str(s) for s in h2["days2date"]]
+    assert U.dailLightSum is U.daily_light_sum and U.computeisDay is U.compute_is_day    # the reference's spellings
     w = U.synthetic_weather(n_rows=960)
     assert w.shape == (960, 10) and np.all(np.isfinite(w)) and w[:, 0].min() == 0 and w[:, 0].max() > 300
 
