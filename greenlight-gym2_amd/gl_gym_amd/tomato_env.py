@@ -63,14 +63,34 @@ DEFAULT_REWARD = dict(fixed_greenhouse_cost=15., fixed_co2_cost=0.015, fixed_lam
                       pen_weights=[4.e-4, 5.e-3, 7.e-4], pen_lamp=0.1)               # TomatoEnv.yml:56-67
 DEFAULT_CONSTRAINTS = dict(co2_min=300., co2_max=1600., temp_min=15., temp_max=34., rh_min=50., rh_max=85.)
 
-OBS_NAMES_CORE = ["co2_air", "temp_air", "rh_air", "pipe_temp", "24CanTemp", "cFruit", "tSum", "uBoil", "uCo2",
-                  "uThScr", "uVent", "uLamp", "uBlScr", "glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed",
-                  "timestep", "day of year sin", "day of year cos", "hour of day sin", "hour of day cos"]
-
 
 def _torch():
     import torch
     return torch
+
+
+class ObservationModule:
+    """Descriptor of one of the reference's observation modules (observations.py:59-182): what the experiment manager
+    reads through ``env.get_attr("observation_modules")`` (RL/experiment_manager.py:43-45).  The values themselves are
+    produced by glgym_obs; ``low`` / ``high`` are the module's Box bounds as the reference declares them."""
+
+    def __init__(self, name, obs_names, low=-1e-4, high=1e4):
+        self.name, self.obs_names, self.n_obs, self.low, self.high = name, list(obs_names), len(obs_names), low, high
+
+    def __repr__(self):
+        return f"{self.name}({self.n_obs})"
+
+
+def observation_modules(Np: int):
+    """The six modules in configs/envs/TomatoEnv.yml order = the column layout of glgym_obs."""
+    wx = ["glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed"]
+    return [ObservationModule("IndoorClimateObservations", ["co2_air", "temp_air", "rh_air", "pipe_temp"]),
+            ObservationModule("BasicCropObservations", ["24CanTemp", "cFruit", "tSum"]),
+            ObservationModule("ControlObservations", ["uBoil", "uCo2", "uThScr", "uVent", "uLamp", "uBlScr"], 0.0, 1.0),
+            ObservationModule("WeatherObservations", wx),
+            ObservationModule("TimeObservations", ["timestep", "day of year sin", "day of year cos", "hour of day sin",
+                                                   "hour of day cos"]),
+            ObservationModule("WeatherForecastObservations", wx * Np)]
 
 
 class LazyInfos:
@@ -211,7 +231,12 @@ class TomatoVecEnv:
         self._draw = 0
         self.x, self.u = self.x_T[:, :self.B].t(), self.u_T[:, :self.B].t()      # [B,28] / [B,6] views
 
-        self.observation_space = _box(-1e4, 1e4, (self.obs_dim,), np.float32)
+        # observation space = concatenation of the modules' bounds (tomato_env.py:83-95; the reference's lower bound
+        # really is -1e-4)
+        self.observation_modules = observation_modules(self.Np)
+        lo = np.concatenate([np.full(m.n_obs, m.low, np.float32) for m in self.observation_modules])
+        hi = np.concatenate([np.full(m.n_obs, m.high, np.float32) for m in self.observation_modules])
+        self.observation_space = _box(lo, hi, (self.obs_dim,), np.float32)
         self.action_space = _box(-1.0, 1.0, (L.NU,), np.float32)
         self._actions = None
         self.reset_infos: List[dict] = [{} for _ in range(self.B)]
@@ -393,7 +418,13 @@ class TomatoVecEnv:
         return [False for _ in self._indices(indices)]
 
     def get_obs_names(self):
-        return OBS_NAMES_CORE + ["glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed"] * self.Np
+        return [n for m in self.observation_modules for n in m.obs_names]
+
+    def set_seed(self, seed: int):
+        """base_env.py:166-170 (called through env_method in experiments/evaluate_rl.py:113): re-seed the generator
+        that draws the episode starts."""
+        self.seed_value = int(seed)
+        self.episode_t.zero_()
 
     # ---- clocks and the weather row of the coming step, as device tensors (for controllers) ---------
     def current_weather(self):

@@ -57,6 +57,12 @@ def test_make_vec_env_from_reference_style_config(cfg_dir):
     env = make_vec_env("TomatoEnv", base, spec, seed=666, n_envs=256, monitor_filename=mon_file, dtype="float64")
     assert isinstance(env, VecMonitorGPU) and isinstance(env.venv, TomatoVecEnv)
     assert env.N == 48 and env.Np == 0 and env.num_envs == 256
+    # what the experiment manager reads (RL/experiment_manager.py:43-45) and the reference's Box bounds
+    mods = env.get_attr("observation_modules")[0]
+    names = [n.replace("_", " ") for m in mods for n in m.obs_names]
+    assert len(names) == env.obs_dim == 23 and names[:4] == ["co2 air", "temp air", "rh air", "pipe temp"]
+    sp = env.observation_space
+    assert np.all(sp.low[7:13] == 0) and np.all(sp.high[7:13] == 1) and sp.low[0] == np.float32(-1e-4) and sp.high[0] == 1e4
     obs = env.reset()
     days = np.array(env.get_attr("start_day"))
     assert set(np.unique(days)) == {0.0, 1.0} and 64 < (days == 0).sum() < 192          # both training days get drawn
@@ -78,6 +84,11 @@ def test_make_vec_env_from_reference_style_config(cfg_dir):
     assert float(env.episode_returns.abs().max()) == 0.0 and int(env.episode_lengths.max()) == 0
     obs, rew, done, infos = env.step(a)
     assert not done.any() and "episode" not in infos[5] and int(env.episode_lengths.min()) == 1
+    # set_seed through env_method (experiments/evaluate_rl.py:113) re-keys the episode-start draws reproducibly
+    env.env_method("set_seed", 777); env.reset(); d1 = np.array(env.get_attr("start_day"))
+    env.env_method("set_seed", 777); env.reset(); d2 = np.array(env.get_attr("start_day"))
+    env.env_method("set_seed", 778); env.reset(); d3 = np.array(env.get_attr("start_day"))
+    assert np.array_equal(d1, d2) and not np.array_equal(d1, d3)
     env.close(); direct.close()
     rows = open(mon_file + ".monitor.csv").read().strip().split("\n")
     assert rows[0].startswith("#{") and rows[1] == "r,l,t" and len(rows) == 2 + 256
