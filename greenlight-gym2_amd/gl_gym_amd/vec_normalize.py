@@ -111,6 +111,18 @@ class VecNormalizeGPU:
                              gamma=self.gamma, epsilon=self.epsilon, norm_obs=self.norm_obs,
                              norm_reward=self.norm_reward), f)
 
+    @classmethod
+    def load(cls, load_path, venv):
+        """``VecNormalize.load(path, venv)`` (experiments/evaluate_rl.py:31): a wrapper around ``venv`` with the saved
+        statistics and settings (file written by ``save``)."""
+        with open(load_path, "rb") as f:
+            d = pickle.load(f)
+        self = cls(venv, norm_obs=d["norm_obs"], norm_reward=d["norm_reward"], clip_obs=d["clip_obs"],
+                   clip_reward=d["clip_reward"], gamma=d["gamma"], epsilon=d["epsilon"])
+        for k in ("obs_mean", "obs_var", "obs_count", "ret_stats"):
+            getattr(self, k).copy_(d[k])
+        return self
+
     def load_stats(self, path):
         with open(path, "rb") as f:
             d = pickle.load(f)

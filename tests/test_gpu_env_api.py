@@ -127,6 +127,16 @@ def test_vecnormalize_on_device_matches_sb3_algorithm(golden):
     m0 = vn.obs_rms.mean.copy()
     _, rew_e, _, _ = vn.step(np.zeros((B, 6), np.float32))
     assert np.array_equal(vn.obs_rms.mean, m0) and np.allclose(rew_e, vn.get_original_reward())
+    # save / VecNormalize.load round trip (experiments/evaluate_rl.py:31, callbacks' best_vecnormalize.pkl)
+    import os, tempfile
+    path = os.path.join(tempfile.mkdtemp(), "best_vecnormalize.pkl")
+    vn.save(path)
+    vn2 = VecNormalizeGPU.load(path, env)
+    vn2.training, vn2.norm_reward = False, False
+    assert np.array_equal(vn2.obs_rms.mean, vn.obs_rms.mean) and np.array_equal(vn2.obs_rms.var, vn.obs_rms.var)
+    assert vn2.clip_obs == 10.0 and vn2.gamma == 0.9631
+    raw = vn.get_original_obs()
+    np.testing.assert_array_equal(vn2.normalize_obs(raw), vn.normalize_obs(raw))
     env.close()
 
 
