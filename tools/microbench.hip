@@ -18,10 +18,14 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
     __syncthreads();
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pc = {c, c}, pd = {d, d};
+    // KIND 10 / 11: the v_fma_f32 body with only the lower 32 / 16 lanes of the wave active (does a half-empty EXEC mask
+    // shorten the 4-cycle pass of a wave64 instruction?)
+    const bool active = KIND == 10 ? threadIdx.x < 32 : (KIND == 11 ? threadIdx.x < 16 : true);
+    if (active)
     for (int i = 0; i < n; ++i) {
 #pragma unroll
       for (int rep = 0; rep < 8; ++rep) {      // 64+ instructions per loop trip: the taken branch costs a lone wave ~40 cycles
-        if (KIND == 0) {          // 8 independent v_fma_f32
+        if (KIND == 0 || KIND == 10 || KIND == 11) {          // 8 independent v_fma_f32
             a0 = fmaf(a0, c, d); a1 = fmaf(a1, c, d); a2 = fmaf(a2, c, d); a3 = fmaf(a3, c, d);
             a4 = fmaf(a4, c, d); a5 = fmaf(a5, c, d); a6 = fmaf(a6, c, d); a7 = fmaf(a7, c, d);
         } else if (KIND == 1) {   // 4 independent v_pk_fma_f32 (8 fmas)
@@ -101,5 +105,7 @@ int main()
     run<5>("(ds_read bcast + v_fma) x8", out, in, 16);
     run<6>("(ds_read per-lane + v_fma) x8", out, in, 16);
     run<7>("dependent v_fma chain x8", out, in, 8);
+    run<10>("v_fma_f32 x8, 32 of 64 lanes active", out, in, 8);
+    run<11>("v_fma_f32 x8, 16 of 64 lanes active", out, in, 8);
     return 0;
 }
