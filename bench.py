@@ -44,7 +44,7 @@ PMC_TRAFFIC_DEFAULT = (2 * 5822.62 + 12384.0) * 1024
 
 DEFAULT_SCHEME = "rk4"
 STAGES = {"rk4": 4, "rk2": 2}
-N_SUB = {"rk4": 256, "rk2": 360}
+N_SUB = {"rk4": 320, "rk2": 360}
 
 
 def cpu_baseline(n_sub: int, budget_s: float = 10.0):
@@ -98,12 +98,15 @@ def cpu_baseline(n_sub: int, budget_s: float = 10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # Defaults measure SUSTAINED throughput: under continuous load the MI355X settles at a lower clock within ~0.1 s, so a
+    # 20-step (20 ms) timed region after an idle period reports the boost-clock burst (about 25 % higher; tools/
+    # sustained_rate.py).  2 000 steps = 2.3 s timed after 0.25 s of warm-up; the whole default run takes about 40 s.
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
     ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2"],
-                    help="sub-stepper: classical RK4 (n_sub 256) or explicit midpoint (n_sub 360); include/glgym.h")
-    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 256 rk4 / 360 rk2)")
+                    help="sub-stepper: classical RK4 (n_sub 320) or explicit midpoint (n_sub 360); include/glgym.h")
+    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 320 rk4 / 360 rk2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -249,7 +252,8 @@ def main():
                        "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True, "hip_graph": bool(args.graph),
                        "vecnormalize": bool(args.vecnorm),
                        "uncertainty_scale": args.uncertainty, "parallelism": f"env-shard x{world} (no data-path collective)",
-                       "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE, n_sub=256 run",
+                       "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE (floor 224); the default "
+                                    "n_sub keeps the stability guard idle under sustained random actions (DESIGN.md 2)",
                        "scheme": "classical RK4, Strang-split exact harvest flow, slow sub-expressions (LAI optics, crop "
                                  "block, soil chain) evaluated once per sub-step at the predicted midpoint (DESIGN.md 2)"},
             "roofline": {"bound": "valu", "kernel": "step_kernel", "achieved": ach_tflops, "peak": PEAK_VALU_TFLOPS,
@@ -282,7 +286,7 @@ def main():
             "episodes_finished": agg["episodes_finished"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(256)      # the RK4-256 C port
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(N_SUB["rk4"])      # the RK4 C port at the default sub-step count
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:

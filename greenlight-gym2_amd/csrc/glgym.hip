@@ -130,7 +130,10 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #endif
 // Tier-2b / harvest window of the RK4 scheme: two sub-steps (7 s) in fp32, where rounding (1e-5) hides the 2e-6 this costs
 // against the tight fixtures; one sub-step in fp64, the parity configuration.  (The explicit-midpoint scheme uses 4.)
-template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? 2 : 1; };
+#ifndef GL_RK4_WIN_F32
+#define GL_RK4_WIN_F32 2
+#endif
+template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : 1; };
 
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
 // RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by four of them (GLGYM_SCHEME_RK2)

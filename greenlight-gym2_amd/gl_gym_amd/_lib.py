@@ -14,7 +14,12 @@ F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
 SCHEME_RK4, SCHEME_RK2 = 0, 1
 SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2}
-DEFAULT_N_SUB = {"rk4": 256, "rk2": 360}      # same 16-19 % stability margin over the 0.67 1/s cover mode
+# Sub-steps per 900 s env-step.  The floor is the 0.67 1/s cover mode (RK4: 224, midpoint: 302); the defaults add the margin
+# that keeps the top-compartment modes stable with vents wide open in 10-20 m/s wind, so that the stability guard (retry
+# with 2x sub-steps, which stalls a whole launch at one wave per SIMD) practically never fires: 0 retries in 1.3e8
+# random-action env-steps on the synthetic weather year for both (RK4 at 256: 2 353, and 8 % LOWER sustained throughput
+# than at 320 -- tools/sustained_rate.py).
+DEFAULT_N_SUB = {"rk4": 320, "rk2": 360}
 
 
 def default_n_sub(scheme: str, dt: float) -> int:

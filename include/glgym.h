@@ -61,7 +61,9 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
 
 /* Sub-stepping scheme of glgym_step / glgym_evalF (greenlight_model.cpp:46-63 uses CVODES BDF; any scheme that meets the
  * accuracy bar against it is admissible).  Both are stability-bound by the 0.67 1/s cover mode:
- *   GLGYM_SCHEME_RK4: classical RK4, stable for h <= 4.2 s -> n_sub >= 224 at dt = 900; default n_sub 256.  The slow
+ *   GLGYM_SCHEME_RK4: classical RK4, stable for h <= 4.2 s -> n_sub >= 224 at dt = 900; use n_sub 320 (with vents wide
+ *     open in strong wind the top-compartment modes reach 0.8 1/s; at 256 the stability guard then fires often enough
+ *     to cost more than the extra sub-steps).  The slow
  *     sub-expressions and the harvest flow are evaluated once per sub-step in fp64, once per two sub-steps in fp32
  *     (n_sub is then rounded up to even).
  *   GLGYM_SCHEME_RK2: explicit midpoint, stable for h <= 3.0 s -> n_sub >= 302; use n_sub 360.  Same stability margin

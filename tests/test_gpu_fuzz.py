@@ -42,7 +42,7 @@ def test_random_tuples_against_oracle_scheme(golden, oracle, scheme, order, win6
     X, U, D, P = _tuples(N, golden)
     scale = np.maximum(np.abs(X).max(axis=0), 1e-3)
     for dtype, win, tol in (("float64", win64, 1e-11), ("float32", win32, 5e-6)):
-        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme)
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
         worst, guarded = 0.0, 0
         for i in range(N):
             ref = oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, n_sub, order, win)

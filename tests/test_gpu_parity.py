@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def models():
     from gl_gym_amd import GreenLight
-    m64 = GreenLight(28, 6, 10, 208, 900.0, dtype="float64")
-    m32 = GreenLight(28, 6, 10, 208, 900.0, dtype="float32")
+    m64 = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=256)      # the oracle references below use 256
+    m32 = GreenLight(28, 6, 10, 208, 900.0, dtype="float32", n_sub=256)
     yield m64, m32
     m64.close(); m32.close()
 
@@ -396,7 +396,7 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     X, U, D, P, DX, XT = g["X"], g["U"], g["D14"], g["P"], g["DX"], g["X_tight300"]
     n = len(XT)
     for dtype, tol_rhs, tol_step in (("float64", 1e-11, 1.3e-5), ("float32", 2e-4, 3e-5)):
-        m = GreenLight(28, 6, 14, 208, 300.0, dtype=dtype, variant="ode_pipe")
+        m = GreenLight(28, 6, 14, 208, 300.0, dtype=dtype, n_sub=256, variant="ode_pipe")
         for grp in (0, 1):                                    # even tuples: default p; odd: the MATLAB-comparison overrides
             idx = np.arange(grp, len(X), 2)
             if not np.array_equal(P[idx[0]], P[idx[-1]]):     # crop-noise tuples differ: one row at a time
@@ -412,8 +412,8 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
         assert err < tol_step
         m.close()
     # (2) default variant, 14-column rows
-    a = GreenLight(28, 6, 14, 208, 300.0)
-    b = GreenLight(28, 6, 10, 208, 300.0)
+    a = GreenLight(28, 6, 14, 208, 300.0, n_sub=256)
+    b = GreenLight(28, 6, 10, 208, 300.0, n_sub=256)
     np.testing.assert_array_equal(a.evalF_batch(X[:8], U[:8], D[:8]), b.evalF_batch(X[:8], U[:8], D[:8, :10]))
     with pytest.raises(Exception):
         GreenLight(28, 6, 10, 208, 300.0, variant="ode_pipe")          # needs the measured-pipe columns
@@ -426,9 +426,9 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     w14[::13, 10] = 0.0
     p = P[1]
     env = TomatoVecEnv(4, weather=w14, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
-                       model_variant="ode_pipe", auto_reset=False)
+                       n_sub=256, model_variant="ode_pipe", auto_reset=False)
     ref_env = TomatoVecEnv(4, weather=w10, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
-                           auto_reset=False)
+                           n_sub=256, auto_reset=False)
     np.testing.assert_array_equal(env.reset(), ref_env.reset())           # obs / reset read the 14-wide rows correctly
     x = env.x[0].double().cpu().numpy()
     p64 = np.asarray(env.p, dtype=np.float64)
