@@ -38,8 +38,8 @@ PEAK_HBM_GBPS = 8000.0
 BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum, without the obs block
 # HBM bytes per step_kernel launch from rocprofv3 PMC passes on the DEFAULT workload (B = 65 536, fp32):
 # FETCH_SIZE 5 820 KB (x2: gfx950 reports half of the fetched bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 12 384 KB;
-# profiles/r01_v11_rk4_pmc_summary.csv.  bench.py cannot collect counters itself, so this is a recorded measurement.
-PMC_TRAFFIC_DEFAULT = (2 * 5822.62 + 12384.0) * 1024
+# profiles/r01_v12_rk4_pmc_summary.csv.  bench.py cannot collect counters itself, so this is a recorded measurement.
+PMC_TRAFFIC_DEFAULT = (2 * 5822.73 + 12384.0) * 1024
 
 
 DEFAULT_SCHEME = "rk4"
@@ -262,15 +262,15 @@ def main():
                                                             and args.scheme == "rk4")
                          else None,
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                         "WRITE_SIZE, recorded in profiles/r01_v11_rk4_pmc_summary.csv (default workload only)",
+                                         "WRITE_SIZE, recorded in profiles/r01_v12_rk4_pmc_summary.csv (default workload only)",
                          "note": "path is VALU/transcendental-bound, not HBM/MFMA (SURVEY 8d): achieved = algorithmic "
                                  "add/mul flops (stages*n_sub*1502 per env-step, stages = 4 rk4 / 2 rk2) / mean "
                                  "step_kernel time; frac adds the quarter-rate special-op term (stages*n_sub*219)",
                          "executed_note": "frac > 1 because the kernel executes far less than the reference expression "
                                           "graph (hoisting, CSE, slow sub-expressions once per sub-step): PMC on the "
-                                          "default workload (profiles/r01_v11_rk4_pmc_summary.csv) counts 3.92e8 VALU wave-"
+                                          "default workload (profiles/r01_v12_rk4_pmc_summary.csv) counts 4.90e8 VALU wave-"
                                           "instructions per launch (1 496 per RK4 sub-step per wave, 169 of them "
-                                          "transcendental) and SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.871 VALU-busy "
+                                          "transcendental) and SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.883 VALU-busy "
                                           "at one wave per SIMD -- the issue roof that actually binds",
                          "special_ops_achieved_Tops": ach_tops, "special_ops_peak_Tops": PEAK_SPECIAL_TOPS,
                          "kernel_ms": kern_ms_max, "kernel_env_steps_per_s": per_gpu_kernel_rate,

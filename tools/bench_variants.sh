@@ -1,5 +1,5 @@
 p() { grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', '%.3e' % d['value'], 'ms/step %.3f' % d['ms_per_step'], 'kernel_ms %.3f' % d['roofline']['kernel_ms'], 'fail', d['ode_failures'])"; }
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | p default
+python bench.py --no-cpu-baseline 2>&1 | p default_sustained
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --uncertainty 0.2 2>&1 | p config5
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --vecnorm 2>&1 | p vecnorm
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --dtype f64 --batch 4096 2>&1 | p f64_4096
