@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- TomatoEnv env-steps/sec on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--n-sub S] [--dtype f32|f64] [--no-obs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scheme rk4|rk2] [--n-sub S] [--dtype f32|f64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -10,7 +10,10 @@ A "step" is one batched TomatoEnv.step(): crop-noise-free control update, fused 
 independent environments resident in HBM.  Workload = BASELINE.json configs[2]: batch 65 536, fp32, one
 synthetic weather year (the Amsterdam KNMI files are not in the reference mount), random actions.
 Deviation from the config text: "RK4 with 4 sub-steps" diverges (stiff ODE, lambda_max ~ 0.67 1/s needs
->= 224 sub-steps, tests/test_gpu_parity.py::test_n_sub_4_is_unstable_and_flagged); n_sub = 256 is run.
+>= 224 sub-steps, tests/test_gpu_parity.py::test_n_sub_4_is_unstable_and_flagged); n_sub = 320 is run -- the count at
+which the stability guard stays idle under sustained random actions.  The defaults time 2 000
+steps so that `value` is the sustained rate, not the first milliseconds after a reset.  A second, informational leg
+times the library's explicit-midpoint sub-stepper on the same workload (`other_scheme`).
 
 Prints ONE JSON line on rank 0.  `value` = all env-steps of all ranks / max-over-ranks wall time.
 """
