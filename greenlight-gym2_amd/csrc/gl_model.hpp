@@ -38,6 +38,18 @@
 #define GL_HD inline
 #endif
 
+// wave-uniform "does any lane ...": lets a whole wavefront skip a rarely needed block (host build: the lane itself)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GL_WAVE_ANY(c) (__any(c) != 0)
+#else
+#define GL_WAVE_ANY(c) (c)
+#endif
+
+// stability control of the sub-stepper (rk_delta): fraction of the scheme's real-axis stability interval a sub-step may use
+#ifndef SC_SAFETY
+#define SC_SAFETY 0.92
+#endif
+
 namespace glm {
 
 constexpr int NX = 28, NU = 6, ND = 10, NP = 208;
@@ -48,6 +60,7 @@ constexpr int CROP0 = 128;
 // math: fast hardware transcendentals in fp32 on the device, libm otherwise
 // ---------------------------------------------------------------------------------------------------
 template <class T> struct Math;
+template <class T> GL_HD T ceil_pos(T v) { return T(::ceil(v)); }
 
 template <> struct Math<double> {
     static GL_HD double exp(double v) { return ::exp(v); }
@@ -384,6 +397,10 @@ template <class T> struct StepCoef {
     // ODE_pipe variant only (ode.hpp:184-189): track the measured pipe temperature d10 unless d10 < 1 or d12 > 0.
     // Set by the caller after precompute(); dead (and removed by the compiler) in the default ODE instantiations.
     T pipeTrack, tPipeSet;
+    // stability control (rate_bound in rhs_fast): long-wave part of the diagonal relaxation rate of the two screens and
+    // the inner cover face [W m-2 K-1] (4 sigma T^3 x the surface's exchange coefficients, T = 313 K, canopy view
+    // factors <= 1), and the complete Gershgorin row of the outer cover face [1/s], which depends on (u, d) only
+    T firTh, firBl, firCovIn, rateCovE;
 };
 
 // C-to-K offsets: the reference uses 273.15 everywhere except airMv(), whose offset is a C `float`
@@ -499,6 +516,15 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
     s.mcExtAir = uCo2 * m.co2PerFlr;
     s.pipeTrack = T(0);
     s.tPipeSet = T(0);
+    {
+        const T k4T3 = T(4.0 * 313.15 * 313.15 * 313.15);      // d(T^4)/dT at 40 C (sigma is in the coefficients)
+        s.firTh = k4T3 * ((m.bCanThScr + m.bPipeThScr + m.bFlrThScr + m.bLampThScr) * uThBl +
+                          (m.bThScrCovIn + m.bThScrSky) * uTh + s.cBlScrThScr);
+        s.firBl = k4T3 * (s.cCanBlScr + s.cPipeBlScr + s.cFlrBlScr + s.cBlScrThScr + s.cBlScrCovIn + s.cBlScrSky +
+                          s.cLampBlScr);
+        s.firCovIn = k4T3 * (s.cCanCovIn + s.cPipeCovIn + s.cFlrCovIn + s.cLampCovIn + s.cThScrCovIn + s.cBlScrCovIn);
+        s.rateCovE = m.iCapCov * (T(2) * m.cCovCond + s.covOutK + k4T3 * m.fCovESky);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -778,9 +804,11 @@ template <> struct FirBlock<float> {
 // (harvest_flow below).
 // PIPE = true: the reference's ODE_pipe (ode.hpp:126-263) -- dxdt(9) follows the measured pipe temperature, dxdt(19) = 0.
 // ---------------------------------------------------------------------------------------------------
-template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false>
+// RATES = true additionally returns in *lam an upper bound on the fastest relaxation rate [1/s] at this state, from
+// quantities the evaluation has in hand anyway (the stability control of rk_delta; derivation at rk_delta).
+template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false, bool RATES = false>
 GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                    const CropConst<T>& cr, T* dx)
+                    const CropConst<T>& cr, T* dx, T* lam = nullptr)
 {
     using M = Math<T>;
     const T one = T(1), eps = T(1e-10), third = T(1.0 / 3.0);
@@ -850,8 +878,10 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T hAirBlScr = M::abs(hecAirBl) * dABl;
     const T hAirOut = s.hAirOutK * dTOut;
     const T hAirTop = m.rhoCp * fScrAbs * dAT;
-    const T hThScrTop = s.hTh * M::powa(M::abs(dThTop + eps), third) * dThTop;
-    const T hBlScrTop = s.hBl * M::powa(M::abs(dBlTop + eps), third) * dBlTop;
+    const T hecThTop = s.hTh * M::powa(M::abs(dThTop + eps), third);
+    const T hecBlTop = s.hBl * M::powa(M::abs(dBlTop + eps), third);
+    const T hThScrTop = hecThTop * dThTop;
+    const T hBlScrTop = hecBlTop * dBlTop;
     const T hTopCovIn = M::abs(hecTopCov) * dTopCov;
     const T hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
     const T hCovEOut = s.covOutK * (tCovE - s.tOut);
@@ -861,7 +891,8 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T hLampAir = m.cLampAir * (tLamp - tAir);
 
     // ---- transpiration (aux_states.hpp:958-981)
-    auto satVp = [&](T t) { return T(610.78) * M::expk(T(17.2694), t * M::rcp(t + T(238.3))); };
+    auto satVpR = [&](T t, T& r) { r = M::rcp(t + T(238.3)); return T(610.78) * M::expk(T(17.2694), t * r); };
+    auto satVp = [&](T t) { T r; return satVpR(t, r); };
     const T vpd = satVp(tCan) - vpAir;
     const T co2Dev = m.etaMgPpm * co2Air - T(200);
     const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
@@ -870,13 +901,14 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T mvCanAir = vpd * q.mvCanK * M::rcp(m.rB + rS);
 
     // ---- condensation and vapour carried by air (aux_states.hpp:999-1024)
-    auto cond = [&](T hec, T vp1, T vp2) {
-        const T dv = vp1 - vp2;
-        return hec * T(6.4e-9) * dv * M::rcp(one + M::expk(T(-0.1), dv));
-    };
-    const T mvAirThScr = cond(hecAirTh, vpAir, satVp(tThScr));
-    const T mvAirBlScr = cond(hecAirBl, vpAir, satVp(tBlScr));
-    const T mvTopCovIn = cond(hecTopCov, vpTop, satVp(tCovIn));
+    // gate(dv) = dv / (1 + exp(-0.1 dv));  condensation = 6.4e-9 hec gate
+    auto gate = [&](T dv) { return dv * M::rcp(one + M::expk(T(-0.1), dv)); };
+    T rTh, rBl, rCov;
+    const T svTh = satVpR(tThScr, rTh), svBl = satVpR(tBlScr, rBl), svCov = satVpR(tCovIn, rCov);
+    const T gTh = gate(vpAir - svTh), gBl = gate(vpAir - svBl), gCov = gate(vpTop - svCov);
+    const T mvAirThScr = hecAirTh * T(6.4e-9) * gTh;
+    const T mvAirBlScr = hecAirBl * T(6.4e-9) * gBl;
+    const T mvTopCovIn = hecTopCov * T(6.4e-9) * gCov;
     T vAirOverT, vTopOverT;
     if (sizeof(T) == 8) {   // the float-typed Kelvin offset of the reference's airMv() is only visible in fp64
         vAirOverT = vpAir * M::rcp(tAir + Kelvin<T>::c2kF32());
@@ -940,6 +972,73 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     dx[25] = q.dFruit - mcFruitHar;
     dx[26] = perDay * tCan;
     dx[27] = perDay;
+
+    if (RATES) {
+        // Upper bound on the spectral radius of the fast block (all eigenvalues are real and negative, oracle/studies/
+        // eig_proto.py): exact diagonals of co2Top / tTop / vpTop / tThScr / tBlScr and Gershgorin rows of the
+        // conduction-coupled cover pair.  d(|dT|^n dT)/dT = (1+n)|dT|^n; the screen air flux grows at most like
+        // |dT|^(2/3) dT.  "wet": a surface below the dew point carries  L 6.4e-9 hec gate(dv)  with hec ~ |dT|^(1/3):
+        // d/dT_surface = hec (gate' dsat/dT + gate / (3 |dT|)) -- the second term is unbounded as the surface
+        // temperature closes in on the air's.  Validated against the finite-difference Jacobian of the oracle RHS:
+        // 1.00 ... 1.25 x lambda_max on tests/golden/step_tight_storm.npz (oracle/gl_oracle.c gl_rate_bound restates it).
+        // *lam holds, on entry, the rate the caller's nominal sub-step covers (see the second pass below).
+        const T lam_nominal = *lam;
+        const T fAir = fScrAbs + fRoofAbs, hTopCovAbs = M::abs(hecTopCov), f43 = T(4.0 / 3.0);
+        const T LK = L * T(6.4e-9), kDs = T(1.1 * 17.2694 * 238.3);
+        // smooth part of a surface's exchange slope [W m-2 K-1] and its singular part at the CURRENT dT
+        auto wet_smooth = [&](T hec, T sv, T r) { return LK * hec * (kDs * sv * r * r); };
+        auto wet_sing = [&](T hec, T g, T dT) { return LK * hec * M::max(g, T(0)) * M::rcp(T(3) * M::abs(dT) + T(1e-9)); };
+        const T r1 = m.iCapCo2Top * fAir;
+        const T r3 = m.iCapTop * (m.rhoCp * (fRoofAbs + T(5.0 / 3.0) * fScrAbs) + f43 * (hTopCovAbs + hecThTop + hecBlTop));
+        const T r16 = m.kCapVpTop * (kMv * fAir + tTopK * T(6.4e-9 * 1.1) * hTopCovAbs);
+        const T base5 = T(2) * m.cCovCond + wet_smooth(hTopCovAbs, svCov, rCov) + s.firCovIn;
+        const T base7 = f43 * hecThTop + wet_smooth(hecAirTh, svTh, rTh) + s.firTh;
+        const T base20 = f43 * hecBlTop + wet_smooth(hecAirBl, svBl, rBl) + s.firBl;
+        T row5 = m.iCapCov * (base5 + f43 * hTopCovAbs + wet_sing(hTopCovAbs, gCov, dTopCov));
+        T r7 = m.iCapThScr * (base7 + f43 * hecAirTh + wet_sing(hecAirTh, gTh, dATh));
+        T r20 = m.iCapBlScr * (base20 + f43 * hecAirBl + wet_sing(hecAirBl, gBl, dABl));
+        const T rOther = M::max(M::max(r1, r3), M::max(r16, s.rateCovE));
+        // Second pass, only where some lane's singular slope exceeds what its nominal sub-step covers.  The tangent slope
+        // at the current dT also spikes whenever a wet surface merely CROSSES the air temperature (the term itself vanishes
+        // there like |dT|^(1/3)), and that is common: in a hot, humid, closed greenhouse the screens sit within 0.1 K of
+        // the air and change sides as it cools.  Two questions decide whether the singular slope has to be resolved:
+        //  (1) can it do harm?  With  d(dT)/dt = rfree - kap |dT|^(1/3) (dT + G)  (kap = hcoef / cap, G = L 6.4e-9 gate,
+        //      rfree = everything but the exchange itself) an unresolved step misplaces the surface by about
+        //      A = (kap G h)^(3/2) kelvin.  Below 1e-4 max(|T|, 2 K) that is inside the accuracy bar (measured on 19 such
+        //      crossings from the bench workload: the fixed step is as accurate as anywhere else, 1e-6 ... 1e-4) and the
+        //      singular slope is ignored;
+        //  (2) is the surface PINNED?  A stable equilibrium near dT = 0 exists iff dT > 0 and rfree > 0: s = dT_eq^(1/3)
+        //      solves  kap s (s^3 + G) = rfree  and relaxes at  kap (4/3 s + G / (3 s^2)) -- that rate is what the
+        //      sub-step has to cover (a cold, wet screen in a storm: 2 ... 15 1/s).  Otherwise the surface passes through
+        //      dT = 0 at finite speed and only the smooth slope counts.
+        if (GL_WAVE_ANY(M::max(M::max(row5, r7), r20) > lam_nominal)) {
+            const T h_nominal = T(SC_SAFETY * 2.785) * M::rcp(lam_nominal);    // within 30 % for either scheme
+            auto pinned = [&](T iCap, T hcoef, T hec, T g, T dT, T ddT, T base, T tSurf) {
+                const T G = LK * M::max(g, T(0)), kap = iCap * M::abs(hcoef);
+                const T rfree = ddT + iCap * hec * (dT + LK * g);
+                const T tolA = T(1e-4) * M::max(M::abs(tSurf), T(2));
+                const T kGh = kap * G * h_nominal;
+                const bool harm = kGh * M::sqrt(kGh) > tolA;
+                const bool pin = harm && (dT > T(0)) && (rfree > T(0)) && (kap > T(0));
+                const T kq = pin ? kap : one, rq = pin ? rfree : one;
+                T sq = M::min(rq * M::rcp(kq * G + T(1e-30)), M::sqrt(M::sqrt(rq * M::rcp(kq))));
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {                      // Newton from above on a convex increasing function
+                    const T s3 = sq * sq * sq;
+                    sq -= (kq * sq * (s3 + G) - rq) * M::rcp(kq * (T(4) * s3 + G));
+                }
+                sq = M::max(sq, T(1e-4));
+                const T at_eq = kq * (f43 * sq + G * M::rcp(T(3) * sq * sq));
+                return iCap * base + (pin ? at_eq : iCap * f43 * hec);
+            };
+            row5 = pinned(m.iCapCov, m.cTopCov, hTopCovAbs, gCov, dTopCov, dx[3] - dx[5], base5, tCovIn);
+            r7 = pinned(m.iCapThScr, s.hTh, hecAirTh, gTh, dATh, dx[2] - dx[7], base7, tThScr);
+            r20 = pinned(m.iCapBlScr, s.hBl, hecAirBl, gBl, dABl, dx[2] - dx[20], base20, tBlScr);
+        }
+        T r = M::max(M::max(rOther, row5), M::max(r7, r20));
+        if (PIPE) r = (s.pipeTrack != T(0)) ? M::max(r, one) : r;         // dxdt(9) = tPipeSet - x9: rate 1 1/s
+        *lam = r;
+    }
 }
 
 // The reference's right-hand side at one state: slow sub-expressions evaluated at that same state.
@@ -958,11 +1057,12 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
 // optimisation level (fp32 and the host build were unaffected).  Out of line, each function fits its register budget.
 // ---------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
-template <bool PIPE>
+template <bool PIPE, bool RATES>
 __device__ __noinline__ inline void rhs_stage_f64(const double* x, const SlowCoef<double>* q, const StepCoef<double>* s,
-                                                  const ModelConst<double>* m, const CropConst<double>* cr, double* dx)
+                                                  const ModelConst<double>* m, const CropConst<double>* cr, double* dx,
+                                                  double* lam)
 {
-    rhs_fast<double, false, PIPE>(x, *q, *s, *m, *cr, dx);
+    rhs_fast<double, false, PIPE, RATES>(x, *q, *s, *m, *cr, dx, lam);
 }
 __device__ __noinline__ inline void slow_coef_f64(const double* ym, const StepCoef<double>* s,
                                                   const ModelConst<double>* m, const CropConst<double>* cr,
@@ -972,10 +1072,11 @@ __device__ __noinline__ inline void slow_coef_f64(const double* ym, const StepCo
 }
 #endif
 template <class T, bool PIPE> struct RhsStage {
+    template <bool RATES>
     static GL_HD void run(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                          const CropConst<T>& cr, T* dx)
+                          const CropConst<T>& cr, T* dx, T* lam)
     {
-        rhs_fast<T, false, PIPE>(x, q, s, m, cr, dx);
+        rhs_fast<T, false, PIPE, RATES>(x, q, s, m, cr, dx, lam);
     }
     static GL_HD void slow(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
                            SlowCoef<T>& q)
@@ -985,10 +1086,11 @@ template <class T, bool PIPE> struct RhsStage {
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <bool PIPE> struct RhsStage<double, PIPE> {
+    template <bool RATES>
     static GL_HD void run(const double* x, const SlowCoef<double>& q, const StepCoef<double>& s,
-                          const ModelConst<double>& m, const CropConst<double>& cr, double* dx)
+                          const ModelConst<double>& m, const CropConst<double>& cr, double* dx, double* lam)
     {
-        rhs_stage_f64<PIPE>(x, &q, &s, &m, &cr, dx);
+        rhs_stage_f64<PIPE, RATES>(x, &q, &s, &m, &cr, dx, lam);
     }
     static GL_HD void slow(const double* ym, const StepCoef<double>& s, const ModelConst<double>& m,
                            const CropConst<double>& cr, SlowCoef<double>& q)
@@ -997,11 +1099,11 @@ template <bool PIPE> struct RhsStage<double, PIPE> {
     }
 };
 #endif
-template <class T, bool PIPE = false>
+template <class T, bool PIPE = false, bool RATES = false>
 GL_HD void rhs_stage(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                     const CropConst<T>& cr, T* dx)
+                     const CropConst<T>& cr, T* dx, T* lam = nullptr)
 {
-    RhsStage<T, PIPE>::run(x, q, s, m, cr, dx);
+    RhsStage<T, PIPE>::template run<RATES>(x, q, s, m, cr, dx, lam);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1061,55 +1163,111 @@ GL_HD constexpr int gl_slow_slot(int i)
 GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || i == 19 || (i >= 22 && i <= 25); }
 constexpr int GL_N_SLOW = 16;
 
+// ---------------------------------------------------------------------------------------------------
+// The sub-stepper, round 2: STABILITY-CONTROLLED.
+//
 // ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 2 = explicit midpoint
-// (2.0, i.e. 1.0 per stage: the same stability margin with 30 % fewer right-hand sides; second order, which at h ~ 2.5 s
-// is still 10x inside the accuracy bar -- DESIGN.md section 2).  WIN: consecutive sub-steps that share one tier-2b
-// evaluation and one pair of harvest half steps (n_sub is rounded up to a multiple of WIN).
+// (2.0, i.e. 1.0 per stage: the same stability margin with 30 % fewer right-hand sides; second order).  WIN: nominal
+// number of sub-steps per WINDOW; a window shares one tier-2b evaluation and one pair of harvest half steps.
+//
+// The env-step is n_win = ceil(n_sub / WIN) windows of length hw.  Inside a window every lane takes
+//        n = ceil(t_rem / hs)  equal sub-steps,     hs = min(hw / WIN, S / lam),     S = SC_SAFETY * (2.785 | 2.0),
+// lam being the rate bound rhs_fast<RATES> returns with the first stage of the window's first sub-step (that stage is
+// evaluated at the END of the previous sub-step: it is also the comparison stage of the error estimate below) and, once
+// a lane is refined, with the first stage of every sub-step.  A nominal lane (lam * hw / WIN <= S) takes exactly WIN
+// sub-steps of hw / WIN: the round-1 fixed-step scheme.  A lane in a storm (top-compartment rates > 0.9 1/s) or with a
+// wet screen pinned to the air temperature (rates of 3 ... 15 1/s) takes more, smaller ones -- per lane, per window,
+// decided before the step is taken, so nothing is ever rolled back.  A lane whose rate bound stays beyond what
+// SC_MAX_REFINE x the nominal count covers for more than SC_CAP_S seconds of an env-step is flagged (SC_FLAG_CAP): like
+// a failed CVODES call in the reference (tomato_env.py:119-123) it terminates the episode with the state unchanged.
+// Safety net: an embedded error estimate on the nine fast states.  With k1' = f(y_{n+1}) (= the next sub-step's first
+// stage, free), y* = y_n + h/6 (k1 + 2 k2 + 2 k3 + k1') is a third-order solution, so  e = h/6 |k4 - k1'|  estimates the
+// local error of RK4 (for a mode at the stability limit e ~ 2x the mode's amplitude); midpoint: e = h/6 |k1 - 2 k2 + k1'|.
+// It is checked at every window boundary (every sub-step once refined); SC_FLAG_ERR makes the guard redo the env-step
+// with 2x, then 4x windows.  oracle/gl_oracle.c (rk_sc_impl) restates all of it.
+// ---------------------------------------------------------------------------------------------------
+#ifndef SC_MAX_REFINE
+#define SC_MAX_REFINE 16
+#endif
+// After a control jump the fast states legitimately move by kelvins within seconds (the estimate decays 5x per window,
+// e.g. 0.16 K -> 0.034 -> 0.006 after a 0 -> 1 actuator jump at n_sub = 320): the estimate tolerance is SC_GRACE_MUL x
+// looser during the first SC_GRACE_S seconds of an env-step.  An instability keeps growing and is caught after that.
+#define SC_GRACE_S 60.0
+#define SC_GRACE_MUL 64.0
+#define SC_CAP_S 120.0
+constexpr int SC_FLAG_CAP = 1, SC_FLAG_NONFINITE = 2, SC_FLAG_ERR = 4;
+constexpr int SC_NFAST = 9;
+GL_HD constexpr int sc_fast(int j) { return j == 0 ? 1 : j == 1 ? 3 : j == 2 ? 5 : j == 3 ? 6 : j == 4 ? 7 : j == 5 ? 15 : j == 6 ? 16 : j == 7 ? 17 : 20; }
+// 1 / tolerance of the per-sub-step error estimate: co2Top 12.5 mg m-3, temperatures 0.125 K (lamp 0.5 K), vapour
+// pressures 12.5 Pa.  Accurate steps stay below 0.07 x that on the storm fixture and below 1e-2 x on nominal rollouts
+// (outside the grace period below); an instability that has become visible in the state is far above it.
+GL_HD constexpr double sc_itol(int j) { return (j == 0 || j == 5 || j == 6) ? 1.0 / 12.5 : j == 7 ? 1.0 / 0.5 : 1.0 / 0.125; }
+
+template <class T> struct ScStat {
+    int n_steps;      // sub-steps taken
+    int flags;        // SC_FLAG_*
+};
+
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                    int n_sub, T* del)
+                    int n_sub, T* del, ScStat<T>& st)
 {
     static_assert(ORDER == 4 || ORDER == 2, "ORDER: 4 (classical RK4) or 2 (explicit midpoint)");
+    using M = Math<T>;
     const int n_win = (n_sub + WIN - 1) / WIN;
-    const T h = dt / T(n_win * WIN), h2 = T(0.5) * h, h6 = h / T(6);
-    const T hw = h * T(WIN), hw2 = T(0.5) * hw;        // harvest flow: once per window
-    T y[NX], xs[NX], k[NX], acc[NX];
+    const T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WIN);
+    const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : 2.0));
+    const T hmin = hnom * T(1.0 / SC_MAX_REFINE);
+    T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
     // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 19, 21..26)
-    // The window increment is summed from the sub-step increments in fp32 (cheapest) and taken as a difference of del in
-    // fp64: hipcc 7.2 miscompiles the fp64 step kernel with the summed form (results off by 1e-9..1e-5 against the host
-    // build of the same code and against the oracle; the fp64 kernels spill heavily, see rhs_stage_f64), and the
-    // difference form is what the fp64 parity tests pinned.
-    constexpr bool SUM_INCS = sizeof(T) == 4;
     T dprev[GL_N_SLOW], dwin[GL_N_SLOW];
 #pragma unroll
     for (int j = 0; j < GL_N_SLOW; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
+    int n_steps = 0, flags = 0;
+    T t_cap = T(0);                 // time spent with the rate bound beyond what SC_MAX_REFINE covers
     // Strang splitting: half a window of the exact harvest flow, RK on everything else, half a window again.  The flow
     // is a one-parameter group, so the trailing half of one window and the leading half of the next are ONE call:
-    //   H(hw/2) [RK^WIN H(hw)]^(n-1) RK^WIN H(hw/2)  -- half as many flow evaluations, same map.
+    //   H(hw/2) [RK.. H(hw)]^(n-1) RK.. H(hw/2)
     del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hw2);
     del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hw2);
+    const T lam_nominal = S * M::rcp(hnom);                       // the rate a nominal sub-step covers
+    T lam = lam_nominal;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+    RhsStage<T, PIPE>::slow(y, s, m, cr, q);                      // first window: no previous increment to predict with
+    rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam);
+    const int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
+    auto check = [&](T h, int it) {                               // embedded error estimate against the fresh first stage
+        T worst = T(0);
+#pragma unroll
+        for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * T(sc_itol(j)));
+        const T tolmul = (it < n_grace) ? T(SC_GRACE_MUL) : T(1);
+        flags |= (worst * h * T(1.0 / 6.0) <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
+    };
     for (int it = 0; it < n_win; ++it) {
+        // A rate beyond SC_MAX_REFINE x the nominal one is followed at the finest sub-step (the seconds before a cold, wet
+        // surface crosses the air temperature); only one that PERSISTS is unresolvable: reported as a failed integration
+        flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
+        if (flags & SC_FLAG_CAP) break;
+        T t_rem = hw, h_last = hnom;
+        bool refined = lam * hnom > S;
 #pragma unroll
-        for (int j = 0; j < WIN; ++j) {
-            // y = state at the start of the sub-step; stage inputs y + c*h*k are one FMA each (their rounding is at the
-            // state's magnitude either way; only the ACCUMULATION below has to stay in delta form)
-#pragma unroll
-            for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-            if (j == 0) {
-                // tier 2b once per window, at the predicted window midpoint  y + (previous window's increment) / 2
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    if (gl_slow_slot(i) >= 0) {
-                        xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
-                        if (!SUM_INCS) dwin[gl_slow_slot(i)] = del[i];
-                    }
-                RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
-            }
-            rhs_stage<T, PIPE>(y, q, s, m, cr, k);
+        for (int i = 0; i < NX; ++i)
+            if (gl_slow_slot(i) >= 0) dwin[gl_slow_slot(i)] = del[i];
+        for (;;) {
+            // ---- this lane's sub-step: as many equal ones as stability asks for, never fewer than the nominal count
+            T hs = refined ? S * M::rcp(lam) : hnom;
+            hs = M::min(hs, hnom);
+            const bool capped = !(hs >= hmin);                 // also true for a NaN rate
+            hs = capped ? hmin : hs;
+            const T n_rem = M::max(T(1), ceil_pos(t_rem * M::rcp(hs) - T(1e-3)));
+            const bool last = n_rem <= T(1);
+            const T h = last ? t_rem : t_rem * M::rcp(n_rem), h2 = T(0.5) * h;
             if (ORDER == 4) {
+                const T h6 = h * T(1.0 / 6.0);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
@@ -1120,49 +1278,69 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const T inc = gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);     // k1 = k2 = k3 = k4 for those
-                    del[i] += inc;
-                    if (SUM_INCS && gl_slow_slot(i) >= 0)
-                        dwin[gl_slow_slot(i)] = (j == 0) ? inc : dwin[gl_slow_slot(i)] + inc;
-                }
+                for (int j = 0; j < SC_NFAST; ++j) est[j] = k[sc_fast(j)];
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    del[i] += gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);       // k1 = k2 = k3 = k4 for those
             } else {
+#pragma unroll
+                for (int j = 0; j < SC_NFAST; ++j) est[j] = -k[sc_fast(j)];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) xs[i] = y[i] + h2 * k[i];
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const T inc = h * k[i];
-                    del[i] += inc;
-                    if (SUM_INCS && gl_slow_slot(i) >= 0)
-                        dwin[gl_slow_slot(i)] = (j == 0) ? inc : dwin[gl_slow_slot(i)] + inc;
-                }
+                for (int j = 0; j < SC_NFAST; ++j) est[j] += T(2) * k[sc_fast(j)];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) del[i] += h * k[i];
+            }
+            ++n_steps;
+            t_rem -= h;
+            h_last = h;
+            t_cap += capped ? h : T(0);
+            if (last) break;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+            // first stage of the next sub-step of this window (same tier 2b); the rate bound only where some lane of the
+            // wavefront is refined -- a nominal lane does not look at it before the window ends
+            if (GL_WAVE_ANY(refined)) {
+                T lam_new = lam_nominal;
+                rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam_new);
+                if (refined) { lam = lam_new; check(h, it); }
+            } else {
+                rhs_stage<T, PIPE>(y, q, s, m, cr, k);
             }
         }
+        // ---- window end: increment of the window's RK part (harvest excluded), harvest flow, next tier 2b
 #pragma unroll
-        for (int i = 0; i < NX; ++i)                        // increment of the window's RK part (harvest excluded)
-            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = SUM_INCS ? dwin[gl_slow_slot(i)] : del[i] - dwin[gl_slow_slot(i)];
+        for (int i = 0; i < NX; ++i)
+            if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dwin[gl_slow_slot(i)];
         const T hh = (it == n_win - 1) ? hw2 : hw;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
+        if (it == n_win - 1) break;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+        // tier 2b at the predicted window midpoint  y + (previous window's increment) / 2
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (gl_slow_slot(i) >= 0) xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
+        RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
+        lam = lam_nominal;
+        rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam);
+        check(h_last, it);
     }
     del[NX - 1] = dt * T(1.0 / 86400.0);     // x27 = time [days]: dx = 1/86400 exactly, nothing depends on it
-}
-
-template <class T, bool PIPE = false>
-GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                     int n_sub, T* del)
-{
-    rk_delta<T, PIPE, 4, 1>(x0, s, m, cr, dt, n_sub, del);
+    st.n_steps = n_steps;
+    st.flags = flags;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stability guard.  Classical RK4 is stable for h*lambda <= 2.785; lambda_max is ~0.67 1/s nominally (h = 3.5 s at
-// n_sub = 256 leaves 16 % margin) but the top-compartment exchange rate grows with wind * vent opening, and in
-// storms (18-20 m/s, vents and screens open) the state moves past the limit DURING the step and the sub-stepper
-// overflows (about 1.3e-6 of random-action env-steps on synthetic weather).  The reference's implicit solver has no
-// such limit, so instead of reporting a failed integration the step is redone from x0 with 2x, then 4x sub-steps;
-// only a step that still overflows is flagged.  Returns the number of extra attempts used (0 in the common case).
+// Guard.  The stability control above keeps every lane inside its scheme's stability region; what is left is the
+// unforeseen: a non-finite result or an error estimate above tolerance.  Such an env-step is redone from x0 with 2x,
+// then 4x windows; a lane that still fails, or whose rate bound asked for more than SC_MAX_REFINE x the nominal
+// sub-step count (not retried: halving h does not rescue a surface pinned at > 15 1/s), is reported as a failed
+// integration -- the reference's behaviour for a failed CVODES call (tomato_env.py:119-123).
+// Returns the number of extra attempts used (0 in the common case); *extra_steps = sub-steps beyond n_sub, all attempts.
 // ---------------------------------------------------------------------------------------------------
 template <class T> GL_HD bool all_finite(const T* v)
 {
@@ -1174,19 +1352,30 @@ template <class T> GL_HD bool all_finite(const T* v)
 
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                            int n_sub, T* del, bool* failed)
+                            int n_sub, T* del, bool* failed, int* extra_steps = nullptr)
 {
-    int n = n_sub, extra = 0;
+    int n = n_sub, extra = 0, total = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del);
-        ok = all_finite(del);
-        if (ok) break;
+        ScStat<T> st;
+        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del, st);
+        total += st.n_steps;
+        ok = all_finite(del) && st.flags == 0;
+        if (ok || (st.flags & SC_FLAG_CAP)) break;
         n *= 2;
         ++extra;
     }
     *failed = !ok;
-    return ok ? extra : 2;
+    if (extra_steps) { const int ex = total - ((n_sub + WIN - 1) / WIN) * WIN; *extra_steps = ex > 0 ? ex : 0; }
+    return ok ? extra : (extra > 2 ? 2 : extra);
+}
+
+template <class T, bool PIPE = false>
+GL_HD void rk4_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
+                     int n_sub, T* del)
+{
+    ScStat<T> st;
+    rk_delta<T, PIPE, 4, 1>(x0, s, m, cr, dt, n_sub, del, st);
 }
 
 }  // namespace glm

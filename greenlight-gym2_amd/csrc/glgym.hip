@@ -196,7 +196,8 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
     }
     T del[NX];
     bool bad;
-    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad);
+    int extra_steps;
+    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps);
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
         const float w = live ? 1.f : 0.f;
         float mv[GLGYM_NMETRIC] = {w * (float)reward, w * (float)profit, (live && term) ? 1.f : 0.f,
                                    (live && bad) ? 1.f : 0.f, w * (float)viol[0], w * (float)viol[1],
-                                   w * (float)viol[2], w, w * (float)retries};
+                                   w * (float)viol[2], w, w * (float)retries, w * (float)extra_steps};
 #pragma unroll
         for (int i = 0; i < GLGYM_NMETRIC; ++i) {
             const float sum = wave_sum(mv[i]);
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(Step
 template <class T, bool PER_ENV_CROP, bool PIPE = false, bool RK2 = false>
 __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
                                                      const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
-                                                     ModelConst<T> m, double* x_next, int rhs_only, int nd)
+                                                     ModelConst<T> m, double* x_next, int rhs_only, int nd,
+                                                     int* n_failed)
 {
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= B) return;
@@ -290,8 +292,11 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, dt, n_sub, del, &failed);      // a still-failing step returns non-finite values
-    for (int i = 0; i < NX; ++i) x_next[(size_t)b * NX + i] = (double)x0[i] + (double)del[i];
+    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, dt, n_sub, del, &failed);
+    // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
+    for (int i = 0; i < NX; ++i)
+        x_next[(size_t)b * NX + i] = failed ? __builtin_nan("") : (double)x0[i] + (double)del[i];
+    if (failed) atomicAdd(n_failed, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -687,6 +692,7 @@ struct glgym_handle_s {
     RewardConst<double> rd;
     double max_profit = 0, min_profit = 0, fixed_costs = 0;
     float* p0_crop_dev = nullptr;       // shared p[128..161] as f32 (noise kernel input)
+    int* fail_dev = nullptr;            // glgym_evalF: number of rows whose integration failed
     int nd = ND;                        // weather / disturbance row stride: 10, or up to 16 (ODE_pipe reads columns 10, 12)
     int variant = GLGYM_ODE;            // GLGYM_ODE | GLGYM_ODE_PIPE
     int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2
@@ -721,7 +727,7 @@ static int refresh(glgym_handle h)
 
 extern "C" {
 
-const char* glgym_version(void) { return "glgym 0.2 (gfx950; thread-per-env; RK4 / explicit-midpoint sub-steppers in delta form)"; }
+const char* glgym_version(void) { return "glgym 0.3 (gfx950; thread-per-env; stability-controlled RK4 / explicit-midpoint sub-steppers in delta form)"; }
 const char* glgym_last_error(void) { return g_err.c_str(); }
 
 int glgym_destroy(glgym_handle h);
@@ -749,6 +755,7 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     // from here on a failure must release what was acquired: run the steps through one exit point
     int rc = [&]() -> int {
         HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
+        HIPCHK(hipMalloc(&h->fail_dev, sizeof(int)));
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         return refresh(h);
@@ -768,6 +775,7 @@ int glgym_destroy(glgym_handle h)
     if (!h) return GLGYM_EINVAL;
     (void)hipSetDevice(h->device);
     if (h->p0_crop_dev) (void)hipFree(h->p0_crop_dev);
+    if (h->fail_dev) (void)hipFree(h->fail_dev);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -849,20 +857,20 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
             return GLGYM_EINVAL;
         }
         hipLaunchKernelGGL((evalf_kernel<T, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     } else if (h->scheme == GLGYM_SCHEME_RK2) {
         if (dcrop)
             hipLaunchKernelGGL((evalf_kernel<T, true, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt),
-                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
         else
             hipLaunchKernelGGL((evalf_kernel<T, false, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt),
-                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     } else if (dcrop)
         hipLaunchKernelGGL((evalf_kernel<T, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     else
         hipLaunchKernelGGL((evalf_kernel<T, false>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd);
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }
@@ -906,6 +914,7 @@ static int evalf_impl(glgym_handle h, const double* x, const double* u, const do
             for (int i = 0; i < NCROP; ++i) crop[(size_t)b * NCROP + i] = p[(size_t)b * NP + CROP0 + i];
         HIPCHK(hipMemcpy(dcrop, crop.data(), crop.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    HIPCHK(hipMemset(h->fail_dev, 0, sizeof(int)));
     if (h->dtype == GLGYM_F32) {
         ModelConst<float> m = h->mf;
         if (p) make_model_const<float>(p_used, m);
@@ -917,6 +926,14 @@ static int evalf_impl(glgym_handle h, const double* x, const double* u, const do
     }
     if (rc != GLGYM_OK) return rc;
     HIPCHK(hipMemcpy(out, dout, (size_t)B * NX * sizeof(double), hipMemcpyDeviceToHost));
+    int n_failed = 0;
+    HIPCHK(hipMemcpy(&n_failed, h->fail_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_failed > 0) {
+        g_err = "glgym_evalF: the integration failed for " + std::to_string(n_failed) + " of " + std::to_string(B) +
+                " rows (rate bound beyond 16x the nominal sub-step count, or error estimate / non-finite result after "
+                "the 2x and 4x retries); their rows of x_next are NaN";
+        return GLGYM_EODE;
+    }
     return GLGYM_OK;
 }
 

@@ -9,16 +9,16 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
 
-NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 9
+NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 10
 F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
 SCHEME_RK4, SCHEME_RK2 = 0, 1
 SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2}
-# Sub-steps per 900 s env-step.  The floor is the 0.67 1/s cover mode (RK4: 224, midpoint: 302); the defaults add the margin
-# that keeps the top-compartment modes stable with vents wide open in 10-20 m/s wind, so that the stability guard (retry
-# with 2x sub-steps, which stalls a whole launch at one wave per SIMD) practically never fires: 0 retries in 1.3e8
-# random-action env-steps on the synthetic weather year for both (RK4 at 256: 2 353, and 8 % LOWER sustained throughput
-# than at 320 -- tools/sustained_rate.py).
+# NOMINAL sub-steps per 900 s env-step.  The floor is the 0.67-0.72 1/s cover mode (RK4: 224, midpoint: 302).  The kernels
+# are stability-controlled per environment (gl_model.hpp rk_delta): a lane whose local rate bound exceeds what the nominal
+# sub-step covers (0.91 1/s at 320) takes more, smaller sub-steps in that window -- and at one wave per SIMD the whole
+# launch waits for it.  320 / 360 keep that rare on the bench workload (rate bound above 0.85 1/s in 5e-6 of random-action
+# env-steps on the synthetic weather year, never above 0.91 in 1.9e5); lower counts refine in most launches and end up slower.
 DEFAULT_N_SUB = {"rk4": 320, "rk2": 360}
 
 
@@ -27,16 +27,21 @@ def default_n_sub(scheme: str, dt: float) -> int:
     (never down) for longer steps so that h = dt / n_sub keeps its stability margin."""
     n = DEFAULT_N_SUB[scheme] * max(1.0, float(dt) / 900.0)
     return int(-(-n // 4) * 4)
-OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
+OK, EINVAL, ENODEV, EHIP, ENOMEM, EODE = 0, -1, -2, -3, -4, -5
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
              "temp_violation", "co2_violation", "rh_violation", "lamp_violation")      # tomato_env.py:208-222
 METRIC_KEYS = ("sum_reward", "sum_EPI", "n_done", "n_ode_fail", "sum_co2_violation", "sum_temp_violation",
-               "sum_rh_violation", "n_env_steps", "n_substep_retries")
+               "sum_rh_violation", "n_env_steps", "n_guard_retries", "n_refined_substeps")
 
 
 class GlgymError(RuntimeError):
     pass
+
+
+class GlgymOdeError(GlgymError):
+    """glgym_evalF: the integration failed for at least one row (GLGYM_EODE) -- the counterpart of the RuntimeError the
+    reference's evalF raises when CVODES fails (greenlight_model.cpp:110, caught at tomato_env.py:119-123)."""
 
 
 class RewardCfg(C.Structure):
@@ -147,4 +152,4 @@ def check(rc: int, what: str = "glgym"):
     if rc != OK:
         msg = load().glgym_last_error().decode() or {EINVAL: "invalid argument", ENODEV: "no HIP device",
                                                        EHIP: "HIP error", ENOMEM: "out of memory"}.get(rc, "")
-        raise GlgymError(f"{what} failed (status {rc}): {msg}")
+        raise (GlgymOdeError if rc == EODE else GlgymError)(f"{what} failed (status {rc}): {msg}")

@@ -45,8 +45,10 @@ extern "C" {
 #define GLGYM_NCROP 34      /* p[128..161], the block noise.py perturbs */
 #define GLGYM_NINFO 11      /* EPI, revenue, variable_costs, fixed_costs, co2_cost, heat_cost, elec_cost,
                                temp_violation, co2_violation, rh_violation, lamp_violation (tomato_env.py:208-222) */
-#define GLGYM_NMETRIC 9     /* sum reward, sum EPI, n done, n ODE failures, sum co2/temp/rh violation, n env-steps,
-                               n sub-step retries (stability guard: env-steps redone with 2x / 4x sub-steps) */
+#define GLGYM_NMETRIC 10    /* sum reward, sum EPI, n done, n failed integrations, sum co2/temp/rh violation, n env-steps,
+                               n guard retries (env-steps redone with 2x / 4x windows after a non-finite result or an
+                               error estimate above tolerance), n refined sub-steps (sub-steps beyond n_sub that the
+                               stability control inserted: storms, wet screens pinned to the air temperature) */
 
 typedef struct glgym_handle_s* glgym_handle;
 
@@ -55,20 +57,25 @@ typedef enum { GLGYM_F32 = 0, GLGYM_F64 = 1 } glgym_dtype;
 /* Right-hand side variants of gl_gym/environments/models/ode.hpp.  GLGYM_ODE = ODE (:6-124), what the reference's
  * compiled module integrates.  GLGYM_ODE_PIPE = ODE_pipe (:126-263): columns 10..13 of each weather / d row are
  * (tPipe, tGroPipe, pipeSwitchOff, groPipeSwitchOff); dxdt(9) = d10 - x9 unless d10 < 1 or d12 > 0, dxdt(19) = 0.
- * Its tracking term has rate 1 1/s: keep dt / n_sub below 2.7 s (dt = 300, n_sub = 256 in
- * experiments/gl_predefined_controls.py's setting). */
+ * Its tracking term has rate 1 1/s, which the stability control accounts for (smaller sub-steps while tracking when
+ * dt / n_sub > 2.5 s; none needed at dt = 300, n_sub = 256, experiments/gl_predefined_controls.py's setting). */
 typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
 
-/* Sub-stepping scheme of glgym_step / glgym_evalF (greenlight_model.cpp:46-63 uses CVODES BDF; any scheme that meets the
- * accuracy bar against it is admissible).  Both are stability-bound by the 0.67 1/s cover mode:
- *   GLGYM_SCHEME_RK4: classical RK4, stable for h <= 4.2 s -> n_sub >= 224 at dt = 900; use n_sub 320 (with vents wide
- *     open in strong wind the top-compartment modes reach 0.8 1/s; at 256 the stability guard then fires often enough
- *     to cost more than the extra sub-steps).  The slow
- *     sub-expressions and the harvest flow are evaluated once per sub-step in fp64, once per two sub-steps in fp32
- *     (n_sub is then rounded up to even).
- *   GLGYM_SCHEME_RK2: explicit midpoint, stable for h <= 3.0 s -> n_sub >= 302; use n_sub 360.  Same stability margin
- *     with 30 % fewer right-hand sides; the slow sub-expressions and the harvest flow are shared by four sub-steps
- *     (n_sub is rounded up to a multiple of 4).  10-day rollout error vs a tight solve: 9e-6 (fp64), 1.8e-5 (fp32). */
+/* Sub-stepping scheme of glgym_step / glgym_evalF (greenlight_model.cpp:46-63 uses CVODES BDF, error-controlled and
+ * implicit; any scheme that meets the accuracy bar against it is admissible).  n_sub is the NOMINAL (= minimum) number
+ * of sub-steps per env-step.  Both schemes are stability-controlled per environment: a bound on the fastest local
+ * relaxation rate (cover pair 0.67-0.72 1/s; top-compartment exchange up to 1.1 1/s in storms; a wet screen pinned to
+ * the air temperature 3 ... 15 1/s) is evaluated once per window of 1-4 nominal sub-steps and the environment takes as
+ * many smaller sub-steps in that window as its scheme's stability interval asks for; an embedded error estimate is the
+ * safety net (env-step redone with 2x / 4x n_sub, counted in GLGYM_NMETRIC).  An environment whose rate bound asks for
+ * more than 16x the nominal count, or that still fails after the retries, is reported like a failed CVODES call in the
+ * reference (tomato_env.py:119-123): done = 1, state unchanged (glgym_step) / GLGYM_EODE (glgym_evalF).
+ *   GLGYM_SCHEME_RK4: classical RK4 (stability interval 2.785): n_sub >= 224 at dt = 900; use n_sub 320 (nominal lanes
+ *     then cover rates up to 0.91 1/s without refinement).  The slow sub-expressions and the harvest flow are evaluated
+ *     once per nominal sub-step in fp64, once per two in fp32 (n_sub is then rounded up to even).
+ *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 360.  Same stability margin with 30 % fewer
+ *     right-hand sides; the slow sub-expressions and the harvest flow are shared by four nominal sub-steps (n_sub is
+ *     rounded up to a multiple of 4).  Second order: 1e-4 one-step errors occur after abrupt control changes. */
 typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1 } glgym_scheme;
 
 typedef enum {
@@ -76,7 +83,9 @@ typedef enum {
     GLGYM_EINVAL = -1,   /* bad argument (sizes other than 28/6/10/208, null pointer, n_sub < 1 ...) */
     GLGYM_ENODEV = -2,   /* no usable HIP device */
     GLGYM_EHIP = -3,     /* a HIP runtime call failed; see glgym_last_error() */
-    GLGYM_ENOMEM = -4
+    GLGYM_ENOMEM = -4,
+    GLGYM_EODE = -5      /* glgym_evalF: the integration failed for at least one row (the reference's evalF raises on a
+                            CVODES failure, greenlight_model.cpp:110); failed rows of x_next are NaN, the others valid */
 } glgym_status;
 
 /* Reward constants (gl_gym/configs/envs/TomatoEnv.yml:38-67; rewards.py:47-124). */
@@ -104,7 +113,7 @@ typedef struct {
     void* reward;              /* [ld] T out */
     void* info;                /* SoA [11][ld] T out, order of GLGYM_NINFO */
     uint8_t* done;             /* [B] out: terminated (season end, or ODE failure -> state left unchanged) */
-    float* metrics;            /* [9] f32 accumulators (atomicAdd, GLGYM_NMETRIC order) or NULL */
+    float* metrics;            /* [GLGYM_NMETRIC] f32 accumulators (atomicAdd, GLGYM_NMETRIC order) or NULL */
 } glgym_step_args;
 
 /* Device-pointer arguments of observation assembly (row-major output, what SB3 / Gymnasium consume). */

@@ -26,6 +26,8 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define GL_NX 28
 #define GL_NU 6
@@ -734,6 +736,247 @@ void gl_oracle_rk4_lagged_pipe(const double *x0, const double *u, const double *
                                double *x1)
 {
     rk4_lagged_impl(x0, u, d, p, dt, n_sub, x1, 1);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Round 2: the kernels' STABILITY-CONTROLLED sub-stepper (gl_model.hpp rk_delta / rate_bound), restated.
+ *
+ * Why: a fixed step h = dt / n_sub is stable only while h * lambda_max stays below the scheme's real-axis limit
+ * (2.785 RK4, 2.0 explicit midpoint).  lambda_max is ~0.67-0.72 1/s nominally (cover conduction pair) but
+ *   (A) the top-compartment exchange rates (co2Top, tTop, vpTop) grow with wind x vent opening: > 1 1/s in storms, and
+ *   (B) a wet screen / cover whose temperature is pinned to the air's: the condensation flux carries the exchange
+ *       law's |dT|^(1/3), whose slope is unbounded at dT -> 0 (3 ... 50 1/s observed),
+ * and a fixed step then returns finite but wrong states.  The reference's implicit, error-controlled
+ * solver (greenlight_model.cpp:46-63) has no such limit.
+ *
+ * What: the env-step is still n_sub / window windows of length hw, each with one tier-2b evaluation and one harvest
+ * half-step pair (as before); inside a window the lane takes  n = ceil(t_rem / hs)  equal sub-steps,
+ *   hs = min(hw / window, S / lam),  S = SAFETY * (2.785 | 2.0),
+ * where lam is an analytic bound on the spectral radius of the fast block (gl_rate_bound below: Gershgorin rows of the
+ * cover pair, exact diagonals of co2Top / tTop / vpTop / tThScr / tBlScr incl. the singular condensation slope),
+ * evaluated with the first stage of the window's first sub-step and, once a lane is refined, of every sub-step.
+ * Nominal lanes (lam * hw / window <= S) take exactly `window` sub-steps: the round-1 scheme, bit for bit.
+ * On top, an embedded error estimate is the safety net: the sub-step's last stage k_s against the next sub-step's first
+ * stage k_1' gives a third-order comparison solution for free (RK4: e = h/6 |k4 - k1'|; midpoint: e = h/6 |k1 - 2 k2 + k1'|);
+ * a step whose estimate exceeds SC_ETOL on a fast state is flagged and the env-step is redone with 2x / 4x windows.
+ * ---------------------------------------------------------------------------------- */
+#define SC_SAFETY 0.92
+#define SC_MAX_REFINE 16.0
+#define SC_CAP_S 120.0       /* a rate beyond the cap may last this long within one env-step before the lane is failed */
+#define SC_GRACE_S 60.0      /* after a control jump the fast states legitimately move by K within seconds: */
+#define SC_GRACE_MUL 64.0    /* looser estimate tolerance during the first SC_GRACE_S of the env-step */
+static const int SC_FAST[9] = {1, 3, 5, 6, 7, 15, 16, 17, 20};
+/* tolerance of the per-sub-step error estimate: co2Top 12.5 mg m-3, temperatures 0.125 K (lamp 0.5 K), vapour pressures 12.5 Pa */
+static const double SC_TOL[9] = {12.5, 0.125, 0.125, 0.125, 0.125, 12.5, 12.5, 0.5, 0.125};
+
+static double dsat_vp(double t) { return sat_vp(t) * 17.2694 * 238.3 / ((t + 238.3) * (t + 238.3)); }
+
+/* Upper bound on the fastest relaxation rate [1/s] of the ODE at state x (negative real spectrum; validated against the
+ * finite-difference Jacobian on tests/golden/step_tight_storm.npz: 1.00 ... 1.25 x lambda_max).  dx = the right-hand side at
+ * x (the kernels use the stage they have in hand).  Two passes, as in gl_model.hpp rhs_fast<RATES>: tangent slopes first;
+ * if a wet surface's singular slope exceeds lam_nominal, that slope is replaced by the relaxation rate of the equilibrium the
+ * surface is pinned at (or dropped when the surface merely crosses the air temperature). */
+static double sc_pinned(double iCap, double hcoef, double hec, double g, double dT, double ddT, double base, double LK,
+                        double tSurf, double h_nominal)
+{
+    const double G = LK * fmax(g, 0.0), kap = iCap * fabs(hcoef);
+    const double rfree = ddT + iCap * hec * (dT + LK * g);
+    const double kGh = kap * G * h_nominal;
+    const int harm = kGh * sqrt(kGh) > 1e-4 * fmax(fabs(tSurf), 2.0);    /* (kap G h)^(3/2): misplacement if unresolved */
+    if (!(harm && (dT > 0.0) && (rfree > 0.0) && (kap > 0.0))) return iCap * base + iCap * (4.0 / 3.0) * hec;
+    double s = fmin(rfree / (kap * G + 1e-30), sqrt(sqrt(rfree / kap)));
+    for (int it = 0; it < 3; ++it) {
+        const double s3 = s * s * s;
+        s -= (kap * s * (s3 + G) - rfree) / (kap * (4.0 * s3 + G));
+    }
+    s = fmax(s, 1e-4);
+    return iCap * base + kap * ((4.0 / 3.0) * s + G / (3.0 * s * s));
+}
+
+double gl_rate_bound_dx(const double *x, const double *u, const double *d, const double *p, const double *dx,
+                        double lam_nominal)
+{
+    double a[GL_NAUX];
+    gl_oracle_aux(x, u, d, p, a);
+    const double fRoof = fabs(a[136]), fScr = fabs(a[144]);
+    const double rhoCp = p[111] * p[23], L = p[1], LK = L * 6.4e-9;
+    const double tAir = x[2], tTop = x[3], tCovIn = x[5], tTh = x[7], tBl = x[20], vpAir = x[15], vpTop = x[16];
+    const double uTh = u[2], uBl = u[5];
+    const double third = 1.0 / 3.0, f43 = 4.0 / 3.0;
+    const double dTopCov = tTop - tCovIn, dThTop = tTh - tTop, dBlTop = tBl - tTop, dATh = tAir - tTh, dABl = tAir - tBl;
+    const double cTopCov = p[50] * p[47] / p[46];
+    const double hecTopCov = fabs(cTopCov * pow(fabs(dTopCov + 1e-10), third));
+    const double hecThTop = 1.7 * uTh * pow(fabs(dThTop + 1e-10), third), hecBlTop = 1.7 * uBl * pow(fabs(dBlTop + 1e-10), third);
+    const double hecATh = 1.7 * uTh * pow(fabs(dATh + 1e-10), third), hecABl = 1.7 * uBl * pow(fabs(dABl + 1e-10), third);
+    /* FIR: 4 sigma T^3 x (sum of the exchange coefficients of the surface), T = 313.15 K, canopy view factors <= 1 */
+    const double sig4 = 4.0 * p[2] * 313.15 * 313.15 * 313.15;
+    const double aCovFir = 1.0 - p[70] - p[67], tauCovFir = p[70];
+    const double pipeCover = 0.49 * PI_ * p[107] * p[105], pipeShade = 1.0 - pipeCover;
+    const double tauThF = 1.0 - uTh * (1.0 - p[81]), tauBlF = 1.0 - uBl * (1.0 - p[91]);
+    const double thbl = tauThF * tauBlF, uThBl = uTh * tauBlF;
+    const double eCan = p[3], eSky = p[4], eFlr = p[95], eTh = p[74], eBl = p[85], aPipe = p[124], ePipe = p[104];
+    const double aLamp = p[181], eLampT = p[182], tauLampFir = p[178], tauIntFir = p[199];
+    const double firTh = sig4 * eTh * (eCan * tauLampFir * uThBl + aPipe * ePipe * tauIntFir * tauLampFir * 0.49 * uThBl +
+                                       eFlr * tauIntFir * tauLampFir * pipeShade * uThBl + aCovFir * uTh +
+                                       eSky * tauCovFir * uTh + eBl * uBl * uTh + aLamp * eLampT * uThBl);
+    const double firBl = sig4 * eBl * uBl * (eCan * tauLampFir + aPipe * ePipe * tauIntFir * tauLampFir * 0.49 +
+                                             eFlr * tauIntFir * tauLampFir * pipeShade + eTh * uTh + aCovFir * tauThF +
+                                             eSky * tauCovFir * tauThF + aLamp * eLampT);
+    const double firCovIn = sig4 * aCovFir * ((eCan * tauLampFir + aPipe * ePipe * tauIntFir * tauLampFir * 0.49 +
+                                               eFlr * tauIntFir * tauLampFir * pipeShade + aLamp * eLampT) * thbl +
+                                              eTh * uTh + eBl * uBl * tauThF);
+    const double firCovE = sig4 * aCovFir * eSky;
+    const double iCapTop = 1.0 / p[120], iCapCo2Top = 1.0 / p[123], iCapCov = 1.0 / a[33];
+    const double kCapVpTop = p[39] / (p[38] * (p[49] - p[48])), iCapTh = 1.0 / p[119], iCapBl = 1.0 / p[121];
+    const double cCov = fabs(1.0 / (p[73] / p[71]));
+    const double covOutK = fabs(p[47] / p[46] * (p[51] + p[52] * pow(d[4], p[53])));
+    const double r1 = iCapCo2Top * (fScr + fRoof);
+    const double r3 = iCapTop * (rhoCp * (fRoof + (5.0 / 3.0) * fScr) + f43 * (hecTopCov + hecThTop + hecBlTop));
+    const double r16 = kCapVpTop * (0.002165 * (fScr + fRoof) + (tTop + C2K) * 6.4e-9 * hecTopCov * 1.1);
+    const double row6 = iCapCov * (2.0 * cCov + covOutK + firCovE);
+    const double dvCov = vpTop - sat_vp(tCovIn), dvTh = vpAir - sat_vp(tTh), dvBl = vpAir - sat_vp(tBl);
+    const double gCov = dvCov / (1.0 + exp(-0.1 * dvCov)), gTh = dvTh / (1.0 + exp(-0.1 * dvTh)), gBl = dvBl / (1.0 + exp(-0.1 * dvBl));
+    const double base5 = 2.0 * cCov + LK * hecTopCov * 1.1 * dsat_vp(tCovIn) + firCovIn;
+    const double base7 = f43 * hecThTop + LK * hecATh * 1.1 * dsat_vp(tTh) + firTh;
+    const double base20 = f43 * hecBlTop + LK * hecABl * 1.1 * dsat_vp(tBl) + firBl;
+#define SC_SING(hec, g, dT) (LK * (hec) * fmax(g, 0.0) / (3.0 * fabs(dT) + 1e-9))
+    double row5 = iCapCov * (base5 + f43 * hecTopCov + SC_SING(hecTopCov, gCov, dTopCov));
+    double r7 = iCapTh * (base7 + f43 * hecATh + SC_SING(hecATh, gTh, dATh));
+    double r20 = iCapBl * (base20 + f43 * hecABl + SC_SING(hecABl, gBl, dABl));
+#undef SC_SING
+    if (fmax(fmax(row5, r7), r20) > lam_nominal) {
+        const double h_nominal = SC_SAFETY * 2.785 / lam_nominal;
+        row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, h_nominal);
+        r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, h_nominal);
+        r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, h_nominal);
+    }
+    double r = fmax(fmax(r1, r3), fmax(r16, row6));
+    r = fmax(fmax(r, row5), fmax(r7, r20));
+    return r;
+}
+
+/* convenience: the bound with the second pass always on (lam_nominal = 0) and dx evaluated here */
+double gl_rate_bound(const double *x, const double *u, const double *d, const double *p)
+{
+    double dx[GL_NX];
+    rhs_no_harvest(x, u, d, p, dx, 0);
+    return gl_rate_bound_dx(x, u, d, p, dx, 1e-3);     /* h_nominal = 2 562 s: every wet surface counts as harmful */
+}
+
+/* stats: [0] sub-steps taken, [1] max error-estimate ratio (checked ones), [2] max rate bound, [3] flags (1 refinement
+ * cap hit, 2 non-finite, 4 error estimate above tolerance) */
+static void rk_sc_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                       double *x1, int pipe, int order, int window, double *stats)
+{
+    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX], kn[GL_NX];
+    const int n_win = (n_sub + window - 1) / window;
+    const double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
+    const double S = SC_SAFETY * (order == 4 ? 2.785 : 2.0);
+    double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0;
+    int flags = 0;
+    const int n_grace = (int)ceil(SC_GRACE_S / hw);
+    memcpy(x, x0, sizeof x);
+    memset(dprev, 0, sizeof dprev);
+    x[23] = harvest_flow_ref(x[23], p[144], 0.5 * hw);
+    x[25] = harvest_flow_ref(x[25], p[145], 0.5 * hw);
+    memcpy(ym, x, sizeof ym);
+    const double lam_nominal = S / hnom;
+    rhs_lagged(x, ym, u, d, p, k1, pipe);
+    double lam = gl_rate_bound_dx(x, u, d, p, k1, lam_nominal);
+    if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
+    lmax = lam;
+    for (int it = 0; it < n_win; ++it) {
+        if (t_cap > SC_CAP_S) flags |= 1;
+        if (flags & 1) break;
+        double t_rem = hw;
+        int refined = lam * hnom > S;
+        memcpy(xw, x, sizeof xw);
+        for (;;) {
+            double hs = refined ? S / lam : hnom;
+            hs = fmin(hs, hnom);
+            const int capped = !(hs >= hmin);
+            if (capped) hs = hmin;
+            const double n_rem = fmax(1.0, ceil(t_rem / hs - 1e-3));
+            const int last = n_rem <= 1.0;
+            const double h = last ? t_rem : t_rem / n_rem;
+            double est[9];
+            if (order == 4) {
+                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+                rhs_lagged(xs, ym, u, d, p, k2, pipe);
+                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
+                rhs_lagged(xs, ym, u, d, p, k3, pipe);
+                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
+                rhs_lagged(xs, ym, u, d, p, k4, pipe);
+                for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+                for (int j = 0; j < 9; ++j) est[j] = k4[SC_FAST[j]];
+            } else {
+                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+                rhs_lagged(xs, ym, u, d, p, k2, pipe);
+                for (int i = 0; i < GL_NX; ++i) x[i] += h * k2[i];
+                for (int j = 0; j < 9; ++j) est[j] = 2.0 * k2[SC_FAST[j]] - k1[SC_FAST[j]];
+            }
+            n_steps += 1.0;
+            t_rem -= h;
+            if (capped) t_cap += h;
+            if (last) {
+                for (int i = 0; i < GL_NX; ++i) dprev[i] = x[i] - xw[i];
+                const double hh = (it == n_win - 1) ? 0.5 * hw : hw;
+                x[23] = harvest_flow_ref(x[23], p[144], hh);
+                x[25] = harvest_flow_ref(x[25], p[145], hh);
+                if (it == n_win - 1) break;
+                for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
+            }
+            rhs_lagged(x, ym, u, d, p, kn, pipe);
+            if (last || refined) {
+                lam = gl_rate_bound_dx(x, u, d, p, kn, lam_nominal);
+                if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
+                if (lam > lmax) lmax = lam;
+                double worst = 0.0;
+                for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - kn[SC_FAST[j]]) / SC_TOL[j]);
+                worst *= h / 6.0;
+                if (getenv("SC_TRACE")) fprintf(stderr, "it %d t_rem %.3f h %.3f ratio %.4f lam %.3f\n", it, t_rem, h, worst, lam);
+                if (it < n_grace) worst *= 1.0 / SC_GRACE_MUL;
+                if (!(worst <= 1.0)) flags |= 4;
+                if (worst > emax) emax = worst;
+            }
+            memcpy(k1, kn, sizeof k1);
+            if (last) break;
+        }
+    }
+    for (int i = 0; i < GL_NX; ++i) if (!isfinite(x[i])) flags |= 2;
+    memcpy(x1, x, sizeof x);
+    if (stats) { stats[0] = n_steps; stats[1] = emax; stats[2] = lmax; stats[3] = (double)flags; }
+}
+
+void gl_oracle_rk_sc(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                     int order, int window, double *x1, double *stats)
+{
+    rk_sc_impl(x0, u, d, p, dt, n_sub, x1, 0, order, window, stats);
+}
+
+/* The kernels' guard around it (gl_model.hpp rk4_delta_guarded): a non-finite result or an error estimate above tolerance
+ * -> redo from x0 with 2x, then 4x windows; a refinement-cap hit is not retried.  Returns the retries used; out[0] = 1
+ * if the integration failed (x1 then holds the last attempt), out[1] = sub-steps beyond n_sub over all attempts.
+ * pipe != 0: ODE_pipe (d has 14 entries). */
+int gl_oracle_rk_sc_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                            int order, int window, int pipe, double *x1, double *out)
+{
+    int n = n_sub, extra = 0, ok = 0;
+    double total = 0.0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        double st[4];
+        rk_sc_impl(x0, u, d, p, dt, n, x1, pipe, order, window, st);
+        total += st[0];
+        ok = ((int)st[3] == 0);
+        if (ok || ((int)st[3] & 1)) break;
+        n *= 2;
+        ++extra;
+    }
+    if (out) {
+        out[0] = ok ? 0.0 : 1.0;
+        out[1] = total - (double)(((n_sub + window - 1) / window) * window);
+    }
+    return ok ? extra : (extra > 2 ? 2 : extra);
 }
 
 /* Stability guard of the kernels: redo the env-step from x0 with 2x, then 4x sub-steps while the result is not finite.

@@ -46,6 +46,11 @@ def lib():
         L.gl_oracle_rk4_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_lagged_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]
+        L.gl_oracle_rk_sc.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]
+        L.gl_rate_bound.argtypes = [_dp] * 4
+        L.gl_oracle_rk_sc_guarded.argtypes = [_dp] * 4 + [ctypes.c_double] + [ctypes.c_int] * 4 + [_dp, _dp]
+        L.gl_oracle_rk_sc_guarded.restype = ctypes.c_int
+        L.gl_rate_bound.restype = ctypes.c_double
         L.gl_oracle_rk4_guarded.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.restype = ctypes.c_int
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
@@ -121,6 +126,32 @@ def rk_lagged(x, u, d, p, dt=900.0, n_sub=256, order=4, window=1):
     out = np.empty(NX)
     lib().gl_oracle_rk_lagged(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window), _p(out))
     return out
+
+
+def rk_sc(x, u, d, p, dt=900.0, n_sub=320, order=4, window=2):
+    """The kernels' stability-controlled sub-stepper (gl_oracle.c rk_sc_impl).  Returns (x_next, stats) with
+    stats = [sub-steps taken, max error-estimate ratio, max rate bound, flags]."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    st = np.zeros(4)
+    lib().gl_oracle_rk_sc(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window), _p(out), _p(st))
+    return out, st
+
+
+def rk_sc_guarded(x, u, d, p, dt=900.0, n_sub=320, order=4, window=2, pipe=False):
+    """rk_sc with the kernels' guard (retry with 2x / 4x windows on a non-finite result or an error estimate above
+    tolerance).  Returns (x_next, retries, refined sub-steps beyond n_sub, failed)."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, 14 if pipe else ND), _c(p, NP)
+    out = np.empty(NX)
+    st = np.zeros(2)
+    r = lib().gl_oracle_rk_sc_guarded(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window),
+                                      int(bool(pipe)), _p(out), _p(st))
+    return out, int(r), int(st[1]), bool(st[0])
+
+
+def rate_bound(x, u, d, p):
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    return float(lib().gl_rate_bound(_p(x), _p(u), _p(d), _p(p)))
 
 
 def rk4_guarded(x, u, d, p, dt=900.0, n_sub=256):

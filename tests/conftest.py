@@ -81,14 +81,32 @@ def hostmath():
         x, u, d14, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d14, p)]
         lib.hostmath_step_pipe(P(x), P(u), P(d14), P(p), int(f32), ctypes.c_double(dt), int(n_sub), P(out))
         return out
-    def _step_scheme(x, u, d_, p, f32=False, dt=900.0, n_sub=256, order=4, window=1):
+    def _step_scheme(x, u, d_, p, f32=False, dt=900.0, n_sub=256, order=4, window=1, stats=False):
         out = np.empty(28)
+        st = np.zeros(2)
         x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
         rc = lib.hostmath_step_scheme(P(x), P(u), P(d_), P(p), int(f32), ctypes.c_double(dt), int(n_sub), int(order),
-                                      int(window), P(out))
+                                      int(window), P(out), P(st))
         assert rc == 0, "unsupported (order, window)"
-        return out
+        return (out, st) if stats else out            # st = [sub-steps taken, SC_FLAG_* bits]
+
+    def _step_guarded(x, u, d_, p, f32=False, dt=900.0, n_sub=320, order=4, window=2):
+        """The guarded step map as the kernels call it: (x_next, retries, extra sub-steps, failed)."""
+        out = np.empty(28)
+        st = np.zeros(2)
+        x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
+        r = lib.hostmath_step_guarded(P(x), P(u), P(d_), P(p), int(f32), ctypes.c_double(dt), int(n_sub), int(order),
+                                      int(window), P(out), P(st))
+        assert r >= 0, "unsupported (order, window)"
+        return out, int(r), int(st[0]), bool(st[1])
+
+    lib.hostmath_rate_bound.restype = ctypes.c_double
+
+    def _rate_bound(x, u, d_, p, f32=False):
+        x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
+        return lib.hostmath_rate_bound(P(x), P(u), P(d_), P(p), int(f32))
     H.rhs_pipe, H.step_pipe, H.step_scheme = staticmethod(_rhs_pipe), staticmethod(_step_pipe), staticmethod(_step_scheme)
+    H.step_guarded, H.rate_bound = staticmethod(_step_guarded), staticmethod(_rate_bound)
     return H
 
 

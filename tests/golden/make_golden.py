@@ -331,7 +331,95 @@ def g_helpers2():
     print("weather_helpers2 ok")
 
 
-ALL = dict(helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+def g_storm():
+    """One-step maps in the regime round 1 never tested: wind 15-35 m/s, tOut -5..15 C, roof
+    vents 0.7-1, screens / lamps random, states spun up for 1800 s under (nearly) the same inputs.  Two things go wrong for
+    a fixed-step explicit scheme here: (A) the top-compartment exchange rates grow with wind x vent opening (0.8-1.1 1/s);
+    (B) a wet screen / cover pinned to the air temperature: the condensation flux carries the exchange law's
+    |dT|^(1/3), whose slope is unbounded at dT -> 0 (local rates of 3 ... 50 1/s), and an overshoot lands on a spurious
+    branch (screen several K above the air) -- finite but wrong.
+    Truth = Radau rtol = atol = 1e-11 on the C oracle RHS, cross-checked against plain RK4 with 16 384 / 32 768 sub-steps
+    (h = 0.027 s); a tuple is kept only if two independent solutions agree to 2e-7 (scaled)."""
+    sys.path.insert(0, str(HERE.parent.parent / "greenlight-gym2_amd"))
+    from gl_gym_amd.utils import synthetic_weather
+    p = init_default_params(208).astype(np.float64)
+    w = synthetic_weather(n_rows=35040, seed=2024)
+    rng = np.random.default_rng(20261003)
+
+    def sc_err(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * np.maximum(np.abs(b), 1.0))))
+
+    def radau(x, u, d, dt):
+        try:
+            # clip: diverging Newton iterates at the |dT|^(1/3) kinks otherwise reach 1e77 and the RHS returns NaN; the
+            # box is never active on a converged solution
+            s = solve_ivp(lambda t, y: O.rhs(np.clip(y, -1e3, 1e9), u, d, p), (0.0, dt), x, method="Radau", rtol=1e-11,
+                          atol=1e-11)
+            return s.y[:, -1] if s.success and np.all(np.isfinite(s.y[:, -1])) else None
+        except (ValueError, FloatingPointError):
+            return None
+
+    def truth(x, u, d, dt):
+        a = radau(x, u, d, dt)
+        n = int(32768 * dt / 900.0)
+        b = O.rk4(x, u, d, p, dt, n)
+        if a is not None and sc_err(a, b) < 2e-7:
+            return a, 0, sc_err(a, b)
+        c = O.rk4(x, u, d, p, dt, n // 2)
+        if np.all(np.isfinite(b)) and sc_err(c, b) < 2e-7 / 15:      # RK4: halving h divides the error by 16
+            return b, 1, sc_err(c, b)
+        return None, -1, np.inf
+
+    fixed = [(21.7, -0.7, [.31, .49, .20, .83, .83, 0.]), (22.6, 0.9, [.89, .67, .05, .90, .60, .77]),
+             (20.4, -1.9, [.44, .20, .71, .96, .90, 0.]), (22.5, -0.8, [.59, .87, 0., .86, .37, 0.]),
+             (17.0, -1.4, [.55, .08, .20, .72, .03, 0.]), (30.0, 2.0, [.5, .5, 0., 1., .5, 0.]),
+             (35.0, 12.0, [.5, .5, 0., .97, .5, 0.]), (38.0, 12.0, [.2, .5, 0., 1., .2, 0.])]
+    cand = []
+    for row in (10, 50, 70):
+        for wind, tout, u in fixed:
+            d = w[row].copy(); d[4] = wind; d[1] = tout
+            cand.append((d, np.array(u), None))
+    while len(cand) < 330:
+        d = w[int(rng.integers(0, 35040))].copy()
+        d[4] = rng.uniform(15, 35); d[1] = rng.uniform(-5, 15); d[5] = d[1] - rng.uniform(5, 20)
+        u = rng.uniform(0, 1, 6); u[3] = rng.uniform(0.7, 1.0)
+        for j in (2, 5):
+            if rng.uniform() < 1 / 3:
+                u[j] = 0.0
+        # a third of the tuples start from a state spun up under the PREVIOUS control (one Delta-u-clipped action back)
+        u_prev = np.clip(u - 0.1 * rng.uniform(-1, 1, 6), 0, 1) if rng.uniform() < 1 / 3 else None
+        cand.append((d, u, u_prev))
+    X, U, D, XT, KIND, AGREE, LAM = [], [], [], [], [], [], []
+    dropped = 0
+    for d, u, u_prev in cand:
+        # spin-up: any accurate solve will do (from the reset state, where every exchange law sits exactly on its kink,
+        # the branch a wet screen ends up on is sensitive at the 1e-4 level, so two solvers need not agree here)
+        xs = radau(init_state(d), u if u_prev is None else u_prev, d, 1800.0)
+        if xs is None:
+            xs = O.rk4(init_state(d), u if u_prev is None else u_prev, d, p, 1800.0, 65536)
+        if not np.all(np.isfinite(xs)):
+            dropped += 1; continue
+        xt, kind, agree = truth(xs, u, d, 900.0)
+        if xt is None:
+            dropped += 1; continue
+        J = np.empty((28, 28))
+        for j in range(28):
+            h = 1e-8 * max(abs(xs[j]), 1.0)
+            xp = xs.copy(); xp[j] += h; xm = xs.copy(); xm[j] -= h
+            J[:, j] = (O.rhs(xp, u, d, p) - O.rhs(xm, u, d, p)) / (2 * h)
+        X.append(xs); U.append(u); D.append(d); XT.append(xt); KIND.append(kind); AGREE.append(agree)
+        LAM.append(float(np.max(-np.linalg.eigvals(J).real)))
+        if len(X) >= 288:
+            break
+    LAM = np.array(LAM)
+    print("step_tight_storm: %d tuples kept, %d dropped (no two truths agreed), %d by fine RK4; lam_max at the start: "
+          "median %.2f, >1: %d, >2.8: %d, max %.1f" % (len(X), dropped, int(np.sum(np.array(KIND) == 1)),
+                                                      np.median(LAM), int(np.sum(LAM > 1)), int(np.sum(LAM > 2.8)), LAM.max()))
+    np.savez_compressed(HERE / "step_tight_storm.npz", X=np.array(X), U=np.array(U), D=np.array(D), X_tight=np.array(XT),
+                        truth_kind=np.array(KIND), truth_agreement=np.array(AGREE), lam_max_start=LAM)
+
+
+ALL = dict(storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

@@ -42,7 +42,8 @@ static void run(const double* x, const double* u, const double* d, const double*
 
 // other integrator settings of rk_delta<T, PIPE, ORDER, WIN>: (order, window) in {(4,1), (4,2), (2,1), (2,2), (2,4)}
 template <class T, int ORDER, int WIN>
-static void run_scheme(const double* x, const double* u, const double* d, const double* p, double dt, int n_sub, double* out)
+static void run_scheme(const double* x, const double* u, const double* d, const double* p, double dt, int n_sub, double* out,
+                       double* stats)
 {
     ModelConst<T> m;
     make_model_const<T>(p, m);
@@ -52,8 +53,46 @@ static void run_scheme(const double* x, const double* u, const double* d, const 
     for (int i = 0; i < 7; ++i) dd[i] = T(d[i]);
     StepCoef<T> s;
     precompute(uu, dd, m, m.crop, s);
-    rk_delta<T, false, ORDER, WIN>(x0, s, m, m.crop, T(dt), n_sub, del);
+    ScStat<T> st;
+    rk_delta<T, false, ORDER, WIN>(x0, s, m, m.crop, T(dt), n_sub, del, st);
     for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
+    if (stats) { stats[0] = st.n_steps; stats[1] = st.flags; }
+}
+// the guarded step map exactly as step_kernel / evalf_kernel call it: returns retries, *failed, extra sub-steps
+template <class T, int ORDER, int WIN>
+static int run_guarded(const double* x, const double* u, const double* d, const double* p, double dt, int n_sub, double* out,
+                       double* stats)
+{
+    ModelConst<T> m;
+    make_model_const<T>(p, m);
+    T x0[NX], uu[NU], dd[7], del[NX];
+    for (int i = 0; i < NX; ++i) x0[i] = T(x[i]);
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[i]);
+    StepCoef<T> s;
+    precompute(uu, dd, m, m.crop, s);
+    bool failed;
+    int extra = 0;
+    const int r = rk4_delta_guarded<T, false, ORDER, WIN>(x0, s, m, m.crop, T(dt), n_sub, del, &failed, &extra);
+    for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
+    if (stats) { stats[0] = extra; stats[1] = failed ? 1 : 0; }
+    return r;
+}
+// rate bound of rhs_fast<RATES> at one state
+template <class T> static double run_rate(const double* x, const double* u, const double* d, const double* p)
+{
+    ModelConst<T> m;
+    make_model_const<T>(p, m);
+    T x0[NX], uu[NU], dd[7], k[NX], lam = T(1e-3);  // tiny nominal rate: second pass always on, every wet surface counts as harmful
+    for (int i = 0; i < NX; ++i) x0[i] = T(x[i]);
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[i]);
+    StepCoef<T> s;
+    precompute(uu, dd, m, m.crop, s);
+    SlowCoef<T> q;
+    slow_coef(x0, s, m, m.crop, q);
+    rhs_fast<T, false, false, true>(x0, q, s, m, m.crop, k, &lam);
+    return (double)lam;
 }
 extern "C" {
 double hostmath_harvest_flow(double c, double cmax, double t, int f32)
@@ -78,17 +117,32 @@ void hostmath_step_pipe(const double* x, const double* u, const double* d14, con
     else run<double, true>(x, u, d14, p, 0, dt, n_sub, x_next, 0);
 }
 int hostmath_step_scheme(const double* x, const double* u, const double* d, const double* p, int f32, double dt,
-                         int n_sub, int order, int win, double* x_next)
+                         int n_sub, int order, int win, double* x_next, double* stats)
 {
-#define GL_CASE(O, W)                                                              \
-    if (order == O && win == W) {                                                  \
-        if (f32) run_scheme<float, O, W>(x, u, d, p, dt, n_sub, x_next);           \
-        else run_scheme<double, O, W>(x, u, d, p, dt, n_sub, x_next);              \
-        return 0;                                                                  \
+#define GL_CASE(O, W)                                                                     \
+    if (order == O && win == W) {                                                         \
+        if (f32) run_scheme<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats);           \
+        else run_scheme<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats);              \
+        return 0;                                                                         \
     }
     GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 4) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4)
 #undef GL_CASE
     return -1;
+}
+int hostmath_step_guarded(const double* x, const double* u, const double* d, const double* p, int f32, double dt,
+                          int n_sub, int order, int win, double* x_next, double* stats)
+{
+#define GL_CASE(O, W)                                                                            \
+    if (order == O && win == W)                                                                  \
+        return f32 ? run_guarded<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats)              \
+                   : run_guarded<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats);
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(2, 4)
+#undef GL_CASE
+    return -1;
+}
+double hostmath_rate_bound(const double* x, const double* u, const double* d, const double* p, int f32)
+{
+    return f32 ? run_rate<float>(x, u, d, p) : run_rate<double>(x, u, d, p);
 }
 void hostmath_step(const double* x, const double* u, const double* d, const double* p, int f32, int per_env_crop,
                    double dt, int n_sub, double* x_next)

@@ -289,10 +289,11 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
     env.close()
 
 
-def test_stability_guard_in_storm(golden, oracle):
+def test_stability_control_in_storm(golden, oracle):
     """Wind 19.5 m/s with vents and screens open pushes the top-compartment exchange rate past RK4-256's stability
-    limit during the step.  Plain RK4-256 overflows there (kernel and oracle alike); the guard redoes the env-step with
-    2x / 4x sub-steps, so nothing may be flagged as failed and the result must equal the oracle's guarded step."""
+    limit during the step: the plain fixed-step scheme overflows there.  The stability control gives those windows
+    smaller sub-steps (counted in n_refined_substeps), nothing is retried or flagged, and the result equals the oracle's
+    restatement of the controlled scheme."""
     from gl_gym_amd.tomato_env import TomatoVecEnv
     w = golden("rollout_10day")["weather"].copy()
     w[:, 4] = 19.5; w[:, 1] = 2.0; w[:, 0] = 0.0
@@ -305,13 +306,13 @@ def test_stability_guard_in_storm(golden, oracle):
     for k in range(12):
         x_prev = env.x.double().cpu().numpy().copy()
         env.step_raw_control(ctrl)
-        ref, retries = oracle.rk4_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256)
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2)
         plain_failed |= not np.all(np.isfinite(oracle.rk4_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256)))
-        assert np.all(np.isfinite(ref))
+        assert np.all(np.isfinite(ref)) and not failed
         assert scaled_err(env.x[0].double().cpu().numpy(), ref) < 5e-5, k
     m = env.metrics()
     assert plain_failed, "the scenario no longer leaves RK4-256's stability region; pick a harsher one"
-    assert m["n_ode_fail"] == 0 and m["n_substep_retries"] >= B
+    assert m["n_ode_fail"] == 0 and m["n_refined_substeps"] >= B
     env.close()
 
 

@@ -1,0 +1,85 @@
+"""Storm fixture: one-step maps in the regime where a fixed-step explicit scheme returns finite but
+wrong states -- wind 15-38 m/s, tOut -5..15 C, roof vents 0.7-1, screens / lamps random, spun-up states -- against the
+TIGHT truth (Radau 1e-11 cross-checked with RK4 at 32 768 sub-steps; tests/golden/make_golden.py g_storm), NOT against the
+oracle's restatement of the kernels' scheme.  Both sub-steppers, fp32 and fp64, through glgym_evalF and glgym_step.
+
+Bar: scaled error < 1e-4 (conftest.scaled_err: |dx| / max(|x|, 1e-3 max_tuples |x|)), no failed integrations, and the
+stability control must actually have refined some lanes (the fixture holds rate bounds up to 2.3 1/s)."""
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+
+pytestmark = pytest.mark.gpu
+
+SCHEMES = [("rk4", 320), ("rk2", 360)]
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme,n_sub", SCHEMES)
+def test_storm_step_maps_through_evalF(golden, scheme, n_sub, dtype):
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight_storm")
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
+    got = m.evalF_batch(X, U, D)
+    assert np.all(np.isfinite(got))
+    err = scaled_err(got, XT)
+    print(f"storm evalF {scheme} {dtype}: {err:.2e}")
+    assert err < 1e-4, (scheme, dtype, err)
+    one = np.array(m.evalF(X[20], U[20], D[20], golden("params_default")["p"].astype(np.float64)))   # the drop-in call
+    assert scaled_err(one[None], got[20:21]) < 1e-12
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme,n_sub", SCHEMES)
+def test_storm_step_maps_through_step_kernel(golden, oracle, scheme, n_sub, dtype):
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = golden("step_tight_storm")
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+    B = len(X)
+    w = np.repeat(D, 4, axis=0)                                  # env b integrates over row 4 b
+    env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, n_sub=n_sub, season_length=0.02, pred_horizon=0,
+                       auto_reset=False)
+    env.reset()
+    env.w_off_t.copy_(torch.arange(B, dtype=torch.int32, device=env.device) * 4)
+    env.x.copy_(torch.as_tensor(X, dtype=env.tdtype, device=env.device))
+    env.metrics_t.zero_()
+    obs, r, done, infos = env.step_raw_control(U)
+    got = env.x.double().cpu().numpy()
+    m = env.metrics()
+    err = scaled_err(got, XT)
+    print(f"storm step {scheme} {dtype}: {err:.2e}; refined sub-steps {m['n_refined_substeps']:.0f}, "
+          f"retries {m['n_guard_retries']:.0f}, failed {m['n_ode_fail']:.0f}")
+    assert err < 1e-4, (scheme, dtype, err)
+    assert m["n_ode_fail"] == 0 and not done.any()
+    assert m["n_refined_substeps"] > 0                           # lanes in the storm took more than n_sub sub-steps
+    if dtype == "float64":                                       # the oracle's restatement takes the same sub-steps
+        win = 4 if scheme == "rk2" else 1
+        ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, 4 if scheme == "rk4" else 2,
+                                    win) for i in range(B)]
+        assert m["n_refined_substeps"] == sum(r_[2] for r_ in ref)
+        assert scaled_err(got, np.array([r_[0] for r_ in ref])) < 1e-10
+    env.close()
+
+
+def test_unresolvable_lane_is_flagged_not_wrong(golden):
+    """A lane whose rate bound asks for more than 16x the nominal sub-step count (a wet screen pinned to the air
+    temperature within 1e-7 K: local rate ~ 1e3 1/s) is reported as a failed integration -- done = 1 and the state
+    unchanged through glgym_step, GlgymOdeError through evalF (the reference: RuntimeError from CVODES, episode
+    terminated, tomato_env.py:119-123) -- and never as a finite wrong state."""
+    from gl_gym_amd import GreenLight
+    from gl_gym_amd._lib import GlgymOdeError
+    g = golden("step_tight_storm")
+    x, u, d = g["X"][2].copy(), g["U"][2].copy(), g["D"][2].copy()
+    u[2] = 0.9                                                   # thermal screen deployed
+    x[7] = x[2] - 1e-7                                           # ... and 1e-7 K below the air temperature
+    x[15] = 1.4 * 610.78 * np.exp(17.2694 * x[7] / (x[7] + 238.3))    # air far above the screen's dew point
+    p = golden("params_default")["p"].astype(np.float64)
+    for dtype in ("float64", "float32"):
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=320)
+        with pytest.raises(GlgymOdeError):
+            m.evalF(x, u, d, p)
+        m.close()

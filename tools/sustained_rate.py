@@ -26,5 +26,5 @@ for c in range(n_chunks):
     m = env.metrics()
     if c < 6 or c % 4 == 3:
         print(f"t = {time.perf_counter() - t_start:6.2f} s  chunk {c:3d}: {B * 250 / el:.3e} env-steps/s ({el / 250 * 1e3:.3f} ms/step); "
-              f"guard retries so far {m['n_substep_retries']:.0f} of {m['n_env_steps']:.3e} env-steps", flush=True)
+              f"guard retries {m['n_guard_retries']:.0f}, refined sub-steps {m['n_refined_substeps']:.0f}, failed {m['n_ode_fail']:.0f} of {m['n_env_steps']:.3e} env-steps", flush=True)
 print("scheme", scheme, "n_sub", env.n_sub, "ODE failures", env.metrics()["n_ode_fail"])
