@@ -804,6 +804,39 @@ template <> struct FirBlock<float> {
 // (harvest_flow below).
 // PIPE = true: the reference's ODE_pipe (ode.hpp:126-263) -- dxdt(9) follows the measured pipe temperature, dxdt(19) = 0.
 // ---------------------------------------------------------------------------------------------------
+// Second pass of the rate bound (see rhs_fast<RATES>): the relaxation rate of the equilibrium a wet surface is pinned at.
+// Out of line on the device: it runs in a fraction of a percent of the wavefronts, and inlined the compiler executes it
+// speculatively in all of them (measured: +135 instructions per window).
+//   harm: the surface's harm gate;  G = L 6.4e-9 gate(dv) [K];  dT = tAir - tSurface;  ddT = d(dT)/dt;
+//   smooth = the surface's rate without the singular slope;  look = how far ahead [s] the reach of dT is extrapolated.
+template <class T>
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+inline
+#endif
+T sc_pinned_rate(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth, T look)
+{
+    using M = Math<T>;
+    const T one = T(1), f43 = T(4.0 / 3.0);
+    const T G = M::max(Gs, T(0)), kap = iCap * M::abs(hcoef);
+    const T rfree = ddT + iCap * hec * (dT + Gs);
+    const bool pin = harm && (dT > T(0)) && (rfree > T(0)) && (kap > T(0));
+    const T kq = pin ? kap : one, rq = pin ? rfree : one;
+    T sq = M::min(rq * M::rcp(kq * G + T(1e-30)), M::sqrt(M::sqrt(rq * M::rcp(kq))));
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {                      // Newton from above on a convex increasing function
+        const T s3 = sq * sq * sq;
+        sq -= (kq * sq * (s3 + G) - rq) * M::rcp(kq * (T(4) * s3 + G));
+    }
+    // approached from above, the surface cannot come closer to the equilibrium within the next windows than its present
+    // speed allows: the slope that has to be covered is the one at the nearest point it can reach
+    const T reach = dT + M::min(ddT, T(0)) * look;
+    const T sr = (reach > T(1e-12)) ? M::powa(M::max(reach, T(1e-12)), T(1.0 / 3.0)) : T(0);
+    sq = M::max(M::max(sq, sr), T(1e-4));
+    return pin ? smooth + kq * (G * M::rcp(T(3) * sq * sq) + f43 * sq) - iCap * f43 * hec : smooth;
+}
+
 // RATES = true additionally returns in *lam an upper bound on the fastest relaxation rate [1/s] at this state, from
 // quantities the evaluation has in hand anyway (the stability control of rk_delta; derivation at rk_delta).
 template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false, bool RATES = false>
@@ -981,59 +1014,52 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         // d/dT_surface = hec (gate' dsat/dT + gate / (3 |dT|)) -- the second term is unbounded as the surface
         // temperature closes in on the air's.  Validated against the finite-difference Jacobian of the oracle RHS:
         // 1.00 ... 1.25 x lambda_max on tests/golden/step_tight_storm.npz (oracle/gl_oracle.c gl_rate_bound restates it).
-        // *lam holds, on entry, the rate the caller's nominal sub-step covers (see the second pass below).
-        const T lam_nominal = *lam;
+        // *lam holds, on entry, the caller's nominal sub-step [s] (for the harm gate below).
+        const T h_nominal = *lam;
         const T fAir = fScrAbs + fRoofAbs, hTopCovAbs = M::abs(hecTopCov), f43 = T(4.0 / 3.0);
         const T LK = L * T(6.4e-9), kDs = T(1.1 * 17.2694 * 238.3);
-        // smooth part of a surface's exchange slope [W m-2 K-1] and its singular part at the CURRENT dT
         auto wet_smooth = [&](T hec, T sv, T r) { return LK * hec * (kDs * sv * r * r); };
-        auto wet_sing = [&](T hec, T g, T dT) { return LK * hec * M::max(g, T(0)) * M::rcp(T(3) * M::abs(dT) + T(1e-9)); };
         const T r1 = m.iCapCo2Top * fAir;
         const T r3 = m.iCapTop * (m.rhoCp * (fRoofAbs + T(5.0 / 3.0) * fScrAbs) + f43 * (hTopCovAbs + hecThTop + hecBlTop));
         const T r16 = m.kCapVpTop * (kMv * fAir + tTopK * T(6.4e-9 * 1.1) * hTopCovAbs);
         const T base5 = T(2) * m.cCovCond + wet_smooth(hTopCovAbs, svCov, rCov) + s.firCovIn;
         const T base7 = f43 * hecThTop + wet_smooth(hecAirTh, svTh, rTh) + s.firTh;
         const T base20 = f43 * hecBlTop + wet_smooth(hecAirBl, svBl, rBl) + s.firBl;
-        T row5 = m.iCapCov * (base5 + f43 * hTopCovAbs + wet_sing(hTopCovAbs, gCov, dTopCov));
-        T r7 = m.iCapThScr * (base7 + f43 * hecAirTh + wet_sing(hecAirTh, gTh, dATh));
-        T r20 = m.iCapBlScr * (base20 + f43 * hecAirBl + wet_sing(hecAirBl, gBl, dABl));
+        // the singular part of a wet surface's slope: first, can it do harm at all?  With
+        //     d(dT)/dt = rfree - kap |dT|^(1/3) (dT + G)      (kap = hcoef / cap, G = L 6.4e-9 gate(dv) >= 0,
+        //                                                      rfree = everything but the exchange itself)
+        // a step that does not resolve it misplaces the surface by about A = (kap G h)^(3/2) kelvin.  Below
+        // 1e-4 max(|T|, 2 K) that is inside the accuracy bar and the slope is ignored -- the common case: in a hot, humid,
+        // closed greenhouse the screens sit within 0.1 K of the air and cross it as it cools (19 such crossings taken from
+        // the bench workload: the fixed step is as accurate there as anywhere else, 1e-6 ... 1e-4 against a tight solve).
+        // (kap G h)^(3/2) > 1e-4 T   <=>   kap G h > 2.154e-3 T^(2/3);  T^(2/3) >= its chord over 2 ... 40 C (concave)
+        // ... and could the equilibrium it may be pinned at (second pass below) relax faster than 0.1 1/s at all?  With
+        // G >> dT_eq that rate is (kap G)^3 / (3 rfree^2); a condensing cover, for one, is "harmful" by the first test
+        // most of the time but sits on 804 J K-1 m-2: 1e-3 1/s.
+        auto harmful = [&](T iCap, T hcoef, T hec, T g, T tSurf, T dT, T ddT) {
+            const T tc = M::min(M::max(M::abs(tSurf), T(2)), T(40));
+            const T kG = iCap * M::abs(hcoef) * LK * M::max(g, T(0));
+            const T rfree = ddT + iCap * hec * (dT + LK * g);
+            return (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
+                   (kG * kG * kG > T(0.3) * rfree * rfree);
+        };
+        const bool harm5 = harmful(m.iCapCov, m.cTopCov, hTopCovAbs, gCov, tCovIn, dTopCov, dx[3] - dx[5]);
+        const bool harm7 = harmful(m.iCapThScr, s.hTh, hecAirTh, gTh, tThScr, dATh, dx[2] - dx[7]);
+        const bool harm20 = harmful(m.iCapBlScr, s.hBl, hecAirBl, gBl, tBlScr, dABl, dx[2] - dx[20]);
+        T row5 = m.iCapCov * (base5 + f43 * hTopCovAbs);
+        T r7 = m.iCapThScr * (base7 + f43 * hecAirTh);
+        T r20 = m.iCapBlScr * (base20 + f43 * hecAirBl);
         const T rOther = M::max(M::max(r1, r3), M::max(r16, s.rateCovE));
-        // Second pass, only where some lane's singular slope exceeds what its nominal sub-step covers.  The tangent slope
-        // at the current dT also spikes whenever a wet surface merely CROSSES the air temperature (the term itself vanishes
-        // there like |dT|^(1/3)), and that is common: in a hot, humid, closed greenhouse the screens sit within 0.1 K of
-        // the air and change sides as it cools.  Two questions decide whether the singular slope has to be resolved:
-        //  (1) can it do harm?  With  d(dT)/dt = rfree - kap |dT|^(1/3) (dT + G)  (kap = hcoef / cap, G = L 6.4e-9 gate,
-        //      rfree = everything but the exchange itself) an unresolved step misplaces the surface by about
-        //      A = (kap G h)^(3/2) kelvin.  Below 1e-4 max(|T|, 2 K) that is inside the accuracy bar (measured on 19 such
-        //      crossings from the bench workload: the fixed step is as accurate as anywhere else, 1e-6 ... 1e-4) and the
-        //      singular slope is ignored;
-        //  (2) is the surface PINNED?  A stable equilibrium near dT = 0 exists iff dT > 0 and rfree > 0: s = dT_eq^(1/3)
-        //      solves  kap s (s^3 + G) = rfree  and relaxes at  kap (4/3 s + G / (3 s^2)) -- that rate is what the
-        //      sub-step has to cover (a cold, wet screen in a storm: 2 ... 15 1/s).  Otherwise the surface passes through
-        //      dT = 0 at finite speed and only the smooth slope counts.
-        if (GL_WAVE_ANY(M::max(M::max(row5, r7), r20) > lam_nominal)) {
-            const T h_nominal = T(SC_SAFETY * 2.785) * M::rcp(lam_nominal);    // within 30 % for either scheme
-            auto pinned = [&](T iCap, T hcoef, T hec, T g, T dT, T ddT, T base, T tSurf) {
-                const T G = LK * M::max(g, T(0)), kap = iCap * M::abs(hcoef);
-                const T rfree = ddT + iCap * hec * (dT + LK * g);
-                const T tolA = T(1e-4) * M::max(M::abs(tSurf), T(2));
-                const T kGh = kap * G * h_nominal;
-                const bool harm = kGh * M::sqrt(kGh) > tolA;
-                const bool pin = harm && (dT > T(0)) && (rfree > T(0)) && (kap > T(0));
-                const T kq = pin ? kap : one, rq = pin ? rfree : one;
-                T sq = M::min(rq * M::rcp(kq * G + T(1e-30)), M::sqrt(M::sqrt(rq * M::rcp(kq))));
-#pragma unroll
-                for (int it = 0; it < 3; ++it) {                      // Newton from above on a convex increasing function
-                    const T s3 = sq * sq * sq;
-                    sq -= (kq * sq * (s3 + G) - rq) * M::rcp(kq * (T(4) * s3 + G));
-                }
-                sq = M::max(sq, T(1e-4));
-                const T at_eq = kq * (f43 * sq + G * M::rcp(T(3) * sq * sq));
-                return iCap * base + (pin ? at_eq : iCap * f43 * hec);
-            };
-            row5 = pinned(m.iCapCov, m.cTopCov, hTopCovAbs, gCov, dTopCov, dx[3] - dx[5], base5, tCovIn);
-            r7 = pinned(m.iCapThScr, s.hTh, hecAirTh, gTh, dATh, dx[2] - dx[7], base7, tThScr);
-            r20 = pinned(m.iCapBlScr, s.hBl, hecAirBl, gBl, dABl, dx[2] - dx[20], base20, tBlScr);
+        // Second pass, only in wavefronts that hold such a lane: is the surface PINNED?  A stable equilibrium near dT = 0
+        // exists iff dT > 0 and rfree > 0: s = dT_eq^(1/3) solves  kap s (s^3 + G) = rfree  and relaxes at
+        // kap (4/3 s + G / (3 s^2)) -- the rate a sub-step has to cover once the surface is there (a cold, wet screen in
+        // a storm: 2 ... 15 1/s).  Otherwise the surface passes through dT = 0 at finite speed and only the smooth slope
+        // counts.
+        if (GL_WAVE_ANY(harm5 || harm7 || harm20)) {
+            const T look = T(4) * h_nominal;
+            row5 = sc_pinned_rate<T>(harm5, m.iCapCov, m.cTopCov, hTopCovAbs, LK * gCov, dTopCov, dx[3] - dx[5], row5, look);
+            r7 = sc_pinned_rate<T>(harm7, m.iCapThScr, s.hTh, hecAirTh, LK * gTh, dATh, dx[2] - dx[7], r7, look);
+            r20 = sc_pinned_rate<T>(harm20, m.iCapBlScr, s.hBl, hecAirBl, LK * gBl, dABl, dx[2] - dx[20], r20, look);
         }
         T r = M::max(M::max(rOther, row5), M::max(r7, r20));
         if (PIPE) r = (s.pipeTrack != T(0)) ? M::max(r, one) : r;         // dxdt(9) = tPipeSet - x9: rate 1 1/s
@@ -1233,39 +1259,40 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     //   H(hw/2) [RK.. H(hw)]^(n-1) RK.. H(hw/2)
     del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hw2);
     del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hw2);
-    const T lam_nominal = S * M::rcp(hnom);                       // the rate a nominal sub-step covers
-    T lam = lam_nominal;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-    RhsStage<T, PIPE>::slow(y, s, m, cr, q);                      // first window: no previous increment to predict with
-    rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam);
     const int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
-    auto check = [&](T h, int it) {                               // embedded error estimate against the fresh first stage
-        T worst = T(0);
-#pragma unroll
-        for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * T(sc_itol(j)));
-        const T tolmul = (it < n_grace) ? T(SC_GRACE_MUL) : T(1);
-        flags |= (worst * h * T(1.0 / 6.0) <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
-    };
+    T h_last = hnom;
     for (int it = 0; it < n_win; ++it) {
         // A rate beyond SC_MAX_REFINE x the nominal one is followed at the finest sub-step (the seconds before a cold, wet
         // surface crosses the air temperature); only one that PERSISTS is unresolvable: reported as a failed integration
         flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
         if (flags & SC_FLAG_CAP) break;
-        T t_rem = hw, h_last = hnom;
-        bool refined = lam * hnom > S;
+        // ---- window start: tier 2b at the predicted window midpoint  y + (previous window's increment) / 2, then the
+        // first stage of the window's first sub-step together with the rate bound (the only place it is evaluated)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
 #pragma unroll
         for (int i = 0; i < NX; ++i)
-            if (gl_slow_slot(i) >= 0) dwin[gl_slow_slot(i)] = del[i];
-        for (;;) {
-            // ---- this lane's sub-step: as many equal ones as stability asks for, never fewer than the nominal count
-            T hs = refined ? S * M::rcp(lam) : hnom;
-            hs = M::min(hs, hnom);
-            const bool capped = !(hs >= hmin);                 // also true for a NaN rate
-            hs = capped ? hmin : hs;
-            const T n_rem = M::max(T(1), ceil_pos(t_rem * M::rcp(hs) - T(1e-3)));
-            const bool last = n_rem <= T(1);
-            const T h = last ? t_rem : t_rem * M::rcp(n_rem), h2 = T(0.5) * h;
+            if (gl_slow_slot(i) >= 0) { xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)]; dwin[gl_slow_slot(i)] = del[i]; }
+        RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
+        T lam = hnom;                                             // in: nominal sub-step; out: the rate bound
+        rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam);
+        if (it > 0) {                                             // embedded error estimate of the previous sub-step
+            T worst = T(0);
+#pragma unroll
+            for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * T(sc_itol(j)));
+            const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
+            flags |= (worst * h_last * T(1.0 / 6.0) <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
+        }
+        // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
+        T hs = M::min(S * M::rcp(lam), hnom);
+        const bool capped = !(hs >= hmin);                        // also true for a NaN rate
+        hs = capped ? hmin : hs;
+        t_cap += capped ? hw : T(0);
+        T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
+        const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h;
+        h_last = h;
+        // one sub-step from (y, k = f(y)): leaves the increment in del and the scheme's last stage in k
+        auto sub_step = [&]() {
             if (ORDER == 4) {
                 const T h6 = h * T(1.0 / 6.0);
 #pragma unroll
@@ -1278,8 +1305,6 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] = k[sc_fast(j)];
-#pragma unroll
                 for (int i = 0; i < NX; ++i)
                     del[i] += gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);       // k1 = k2 = k3 = k4 for those
             } else {
@@ -1289,45 +1314,29 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) xs[i] = y[i] + h2 * k[i];
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] += T(2) * k[sc_fast(j)];
-#pragma unroll
                 for (int i = 0; i < NX; ++i) del[i] += h * k[i];
             }
             ++n_steps;
-            t_rem -= h;
-            h_last = h;
-            t_cap += capped ? h : T(0);
-            if (last) break;
+        };
+        // the first sub-step uses the stage evaluated above; every further one starts with its own first stage (written
+        // as two loops so that the compiler cannot hoist that evaluation above the exit test of the previous sub-step)
+        sub_step();
+        for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-            // first stage of the next sub-step of this window (same tier 2b); the rate bound only where some lane of the
-            // wavefront is refined -- a nominal lane does not look at it before the window ends
-            if (GL_WAVE_ANY(refined)) {
-                T lam_new = lam_nominal;
-                rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam_new);
-                if (refined) { lam = lam_new; check(h, it); }
-            } else {
-                rhs_stage<T, PIPE>(y, q, s, m, cr, k);
-            }
+            rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
+            sub_step();
         }
-        // ---- window end: increment of the window's RK part (harvest excluded), harvest flow, next tier 2b
+        // the last stage (RK4: k4; midpoint: 2 k2 - k1) of the window's last sub-step, for the estimate at the next start
+#pragma unroll
+        for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+        // ---- window end: increment of the window's RK part (harvest excluded), harvest flow
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dwin[gl_slow_slot(i)];
         const T hh = (it == n_win - 1) ? hw2 : hw;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
-        if (it == n_win - 1) break;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-        // tier 2b at the predicted window midpoint  y + (previous window's increment) / 2
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (gl_slow_slot(i) >= 0) xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)];
-        RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
-        lam = lam_nominal;
-        rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam);
-        check(h_last, it);
     }
     del[NX - 1] = dt * T(1.0 / 86400.0);     // x27 = time [days]: dx = 1/86400 exactly, nothing depends on it
     st.n_steps = n_steps;

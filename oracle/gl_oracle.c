@@ -781,20 +781,27 @@ static double sc_pinned(double iCap, double hcoef, double hec, double g, double 
 {
     const double G = LK * fmax(g, 0.0), kap = iCap * fabs(hcoef);
     const double rfree = ddT + iCap * hec * (dT + LK * g);
-    const double kGh = kap * G * h_nominal;
-    const int harm = kGh * sqrt(kGh) > 1e-4 * fmax(fabs(tSurf), 2.0);    /* (kap G h)^(3/2): misplacement if unresolved */
+    /* harm gate: (kap G h)^(3/2) > 1e-4 max(|T|, 2)  <=>  kap G h > 2.154e-3 T^(2/3), T^(2/3) bounded below by its chord
+     * over 2 ... 40 C (the kernels avoid the fractional power) */
+    const double tc = fmin(fmax(fabs(tSurf), 2.0), 40.0);
+    /* ... and the pinned equilibrium must be able to relax faster than 0.1 1/s: (kap G)^3 / (3 rfree^2) */
+    const double kG = kap * G;
+    const int harm = (kG * h_nominal > 2.154e-3 * (1.5874 + 0.26603 * (tc - 2.0))) && (kG * kG * kG > 0.3 * rfree * rfree);
     if (!(harm && (dT > 0.0) && (rfree > 0.0) && (kap > 0.0))) return iCap * base + iCap * (4.0 / 3.0) * hec;
     double s = fmin(rfree / (kap * G + 1e-30), sqrt(sqrt(rfree / kap)));
     for (int it = 0; it < 3; ++it) {
         const double s3 = s * s * s;
         s -= (kap * s * (s3 + G) - rfree) / (kap * (4.0 * s3 + G));
     }
-    s = fmax(s, 1e-4);
+    /* approached from above, the surface cannot come closer within the next windows than its present speed allows */
+    const double reach = dT + fmin(ddT, 0.0) * (4.0 * h_nominal);
+    const double sr = (reach > 1e-12) ? pow(fmax(reach, 1e-12), 1.0 / 3.0) : 0.0;
+    s = fmax(fmax(s, sr), 1e-4);
     return iCap * base + kap * ((4.0 / 3.0) * s + G / (3.0 * s * s));
 }
 
 double gl_rate_bound_dx(const double *x, const double *u, const double *d, const double *p, const double *dx,
-                        double lam_nominal)
+                        double h_nominal)
 {
     double a[GL_NAUX];
     gl_oracle_aux(x, u, d, p, a);
@@ -839,17 +846,9 @@ double gl_rate_bound_dx(const double *x, const double *u, const double *d, const
     const double base5 = 2.0 * cCov + LK * hecTopCov * 1.1 * dsat_vp(tCovIn) + firCovIn;
     const double base7 = f43 * hecThTop + LK * hecATh * 1.1 * dsat_vp(tTh) + firTh;
     const double base20 = f43 * hecBlTop + LK * hecABl * 1.1 * dsat_vp(tBl) + firBl;
-#define SC_SING(hec, g, dT) (LK * (hec) * fmax(g, 0.0) / (3.0 * fabs(dT) + 1e-9))
-    double row5 = iCapCov * (base5 + f43 * hecTopCov + SC_SING(hecTopCov, gCov, dTopCov));
-    double r7 = iCapTh * (base7 + f43 * hecATh + SC_SING(hecATh, gTh, dATh));
-    double r20 = iCapBl * (base20 + f43 * hecABl + SC_SING(hecABl, gBl, dABl));
-#undef SC_SING
-    if (fmax(fmax(row5, r7), r20) > lam_nominal) {
-        const double h_nominal = SC_SAFETY * 2.785 / lam_nominal;
-        row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, h_nominal);
-        r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, h_nominal);
-        r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, h_nominal);
-    }
+    const double row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, h_nominal);
+    const double r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, h_nominal);
+    const double r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, h_nominal);
     double r = fmax(fmax(r1, r3), fmax(r16, row6));
     r = fmax(fmax(r, row5), fmax(r7, r20));
     return r;
@@ -860,46 +859,53 @@ double gl_rate_bound(const double *x, const double *u, const double *d, const do
 {
     double dx[GL_NX];
     rhs_no_harvest(x, u, d, p, dx, 0);
-    return gl_rate_bound_dx(x, u, d, p, dx, 1e-3);     /* h_nominal = 2 562 s: every wet surface counts as harmful */
+    return gl_rate_bound_dx(x, u, d, p, dx, 1e6);      /* huge nominal sub-step: every wet surface counts as harmful */
 }
 
-/* stats: [0] sub-steps taken, [1] max error-estimate ratio (checked ones), [2] max rate bound, [3] flags (1 refinement
- * cap hit, 2 non-finite, 4 error estimate above tolerance) */
+/* stats: [0] sub-steps taken, [1] max error-estimate ratio (after the grace scaling), [2] max rate bound, [3] flags
+ * (1 rate beyond the refinement cap for more than SC_CAP_S, 2 non-finite, 4 error estimate above tolerance) */
 static void rk_sc_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                        double *x1, int pipe, int order, int window, double *stats)
 {
-    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX], kn[GL_NX];
+    double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX];
+    double est[9] = {0};
     const int n_win = (n_sub + window - 1) / window;
     const double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
     const double S = SC_SAFETY * (order == 4 ? 2.785 : 2.0);
-    double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0;
+    double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0, h_last = hnom;
     int flags = 0;
     const int n_grace = (int)ceil(SC_GRACE_S / hw);
     memcpy(x, x0, sizeof x);
     memset(dprev, 0, sizeof dprev);
     x[23] = harvest_flow_ref(x[23], p[144], 0.5 * hw);
     x[25] = harvest_flow_ref(x[25], p[145], 0.5 * hw);
-    memcpy(ym, x, sizeof ym);
-    const double lam_nominal = S / hnom;
-    rhs_lagged(x, ym, u, d, p, k1, pipe);
-    double lam = gl_rate_bound_dx(x, u, d, p, k1, lam_nominal);
-    if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
-    lmax = lam;
     for (int it = 0; it < n_win; ++it) {
         if (t_cap > SC_CAP_S) flags |= 1;
         if (flags & 1) break;
-        double t_rem = hw;
-        int refined = lam * hnom > S;
+        /* window start: tier 2b at the predicted midpoint, first stage + rate bound, estimate of the previous sub-step */
+        for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
         memcpy(xw, x, sizeof xw);
-        for (;;) {
-            double hs = refined ? S / lam : hnom;
-            hs = fmin(hs, hnom);
-            const int capped = !(hs >= hmin);
-            if (capped) hs = hmin;
-            const double n_rem = fmax(1.0, ceil(t_rem / hs - 1e-3));
-            const int last = n_rem <= 1.0;
-            const double h = last ? t_rem : t_rem / n_rem;
-            double est[9];
+        rhs_lagged(x, ym, u, d, p, k1, pipe);
+        double lam = gl_rate_bound_dx(x, u, d, p, k1, hnom);
+        if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
+        if (lam > lmax) lmax = lam;
+        if (it > 0) {
+            double worst = 0.0;
+            for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - k1[SC_FAST[j]]) / SC_TOL[j]);
+            worst *= h_last / 6.0;
+            if (getenv("SC_TRACE")) fprintf(stderr, "it %d h %.3f ratio %.4f lam %.3f\n", it, h_last, worst, lam);
+            if (it <= n_grace) worst *= 1.0 / SC_GRACE_MUL;
+            if (!(worst <= 1.0)) flags |= 4;
+            if (worst > emax) emax = worst;
+        }
+        double hs = fmin(S / lam, hnom);
+        const int capped = !(hs >= hmin);
+        if (capped) { hs = hmin; t_cap += hw; }
+        const int n = (int)fmax(1.0, ceil(hw / hs - 1e-3));
+        const double h = hw / (double)n;
+        h_last = h;
+        for (int r = 0; r < n; ++r) {
+            if (r > 0) rhs_lagged(x, ym, u, d, p, k1, pipe);
             if (order == 4) {
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
                 rhs_lagged(xs, ym, u, d, p, k2, pipe);
@@ -916,32 +922,11 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                 for (int j = 0; j < 9; ++j) est[j] = 2.0 * k2[SC_FAST[j]] - k1[SC_FAST[j]];
             }
             n_steps += 1.0;
-            t_rem -= h;
-            if (capped) t_cap += h;
-            if (last) {
-                for (int i = 0; i < GL_NX; ++i) dprev[i] = x[i] - xw[i];
-                const double hh = (it == n_win - 1) ? 0.5 * hw : hw;
-                x[23] = harvest_flow_ref(x[23], p[144], hh);
-                x[25] = harvest_flow_ref(x[25], p[145], hh);
-                if (it == n_win - 1) break;
-                for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
-            }
-            rhs_lagged(x, ym, u, d, p, kn, pipe);
-            if (last || refined) {
-                lam = gl_rate_bound_dx(x, u, d, p, kn, lam_nominal);
-                if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
-                if (lam > lmax) lmax = lam;
-                double worst = 0.0;
-                for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - kn[SC_FAST[j]]) / SC_TOL[j]);
-                worst *= h / 6.0;
-                if (getenv("SC_TRACE")) fprintf(stderr, "it %d t_rem %.3f h %.3f ratio %.4f lam %.3f\n", it, t_rem, h, worst, lam);
-                if (it < n_grace) worst *= 1.0 / SC_GRACE_MUL;
-                if (!(worst <= 1.0)) flags |= 4;
-                if (worst > emax) emax = worst;
-            }
-            memcpy(k1, kn, sizeof k1);
-            if (last) break;
         }
+        for (int i = 0; i < GL_NX; ++i) dprev[i] = x[i] - xw[i];
+        const double hh = (it == n_win - 1) ? 0.5 * hw : hw;
+        x[23] = harvest_flow_ref(x[23], p[144], hh);
+        x[25] = harvest_flow_ref(x[25], p[145], hh);
     }
     for (int i = 0; i < GL_NX; ++i) if (!isfinite(x[i])) flags |= 2;
     memcpy(x1, x, sizeof x);

@@ -83,7 +83,7 @@ template <class T> static double run_rate(const double* x, const double* u, cons
 {
     ModelConst<T> m;
     make_model_const<T>(p, m);
-    T x0[NX], uu[NU], dd[7], k[NX], lam = T(1e-3);  // tiny nominal rate: second pass always on, every wet surface counts as harmful
+    T x0[NX], uu[NU], dd[7], k[NX], lam = T(1e6);   // huge nominal sub-step: every wet surface counts as harmful (the pinned analysis always runs)
     for (int i = 0; i < NX; ++i) x0[i] = T(x[i]);
     for (int i = 0; i < NU; ++i) uu[i] = T(u[i]);
     for (int i = 0; i < 7; ++i) dd[i] = T(d[i]);

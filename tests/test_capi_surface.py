@@ -86,7 +86,9 @@ def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
         pytest.skip("hipcc not available")
     csrc = ROOT / "greenlight-gym2_amd" / "csrc"
     out = tmp_path / "glgym.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17",
+    # the optimisation flags of csrc/Makefile (OPT)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                           "--offload-arch=gfx950", "-std=c++17",
                            f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(csrc / "glgym.hip")])
     s = out.read_text()
     assert "v_mfma" not in s
