@@ -138,8 +138,15 @@ template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) ==
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
 // RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by four of them (GLGYM_SCHEME_RK2)
 // instead of classical RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.
-template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, bool RK2 = false>
-__global__ __launch_bounds__(WAVE, GL_STEP_WAVES_PER_SIMD) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
+// OCC = waves per SIMD the kernel is compiled for.  1 (default): up to 512 registers per lane, no scratch -- the right choice
+// when the batch gives every SIMD one wave (B <= 65 536).  2: 256 registers per lane (spills go to scratch) so that two
+// waves share a SIMD -- a lone wave issues a vector instruction only every ~5 cycles, two co-resident waves one every
+// ~2.7 (tools/microbench.hip with verified placement, profiles/r02_microbench_issue_rates.txt).  Measured on this kernel
+// (profiles/r02_occupancy2_variant.txt): the spills eat most of it -- B = 131 072: 5.64e7 vs 5.60e7 env-steps/s,
+// B = 262 144: 6.04e7 vs 5.75e7 -- so it is used from four waves per SIMD on; at B = 65 536 the dispatcher packs the 1 024
+// waves two per SIMD onto half the chip (3.1e7).
+template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, bool RK2 = false, int OCC = GL_STEP_WAVES_PER_SIMD>
+__global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
     __shared__ float sh_act[WAVE * NU];
@@ -697,6 +704,7 @@ struct glgym_handle_s {
     int variant = GLGYM_ODE;            // GLGYM_ODE | GLGYM_ODE_PIPE
     int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
+    int n_simd = 1024;                  // SIMDs of the device (4 per CU)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-pointer entry points
     double* scratch = nullptr;
@@ -748,6 +756,11 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     HIPCHK(hipSetDevice(device));
     glgym_handle h = new (std::nothrow) glgym_handle_s();
     if (!h) return GLGYM_ENOMEM;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->n_simd = 4 * prop.multiProcessorCount;
+    }
     h->device = device; h->dtype = dtype; h->n_sub = n_sub; h->dt = dt; h->nd = nd;
     std::memcpy(h->p, p, sizeof h->p);
     default_reward(h->rcfg);
@@ -977,6 +990,15 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // fp64 (parity configuration) always takes the generic kernel: its RHS is an out-of-line call that receives the
     // constant block by address, and only the kernarg copy has a usable one.
     const bool def = h->use_specialised && sizeof(T) == 4 && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+    // two waves per SIMD pay once the batch holds at least two waves for every SIMD (GLGYM_OCC = 1 | 2 overrides)
+    static const int occ_env = [] { const char* e = std::getenv("GLGYM_OCC"); return e ? std::atoi(e) : 0; }();
+    const bool occ2 = def && !a->crop_p && (occ_env == 2 || (occ_env == 0 && a->B >= 4 * h->n_simd * WAVE));
+    if (occ2) {
+        if (h->scheme == GLGYM_SCHEME_RK2) hipLaunchKernelGGL((step_kernel<T, false, true, false, true, 2>), grid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel<T, false, true, false, false, 2>), grid, block, 0, st, k, m, rw);
+        HIPCHK(hipGetLastError());
+        return GLGYM_OK;
+    }
     if (h->scheme == GLGYM_SCHEME_RK2) {
         if (a->crop_p) {
             if (def) hipLaunchKernelGGL((step_kernel<T, true, true, false, true>), grid, block, 0, st, k, m, rw);

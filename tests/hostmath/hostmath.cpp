@@ -136,7 +136,7 @@ int hostmath_step_guarded(const double* x, const double* u, const double* d, con
     if (order == O && win == W)                                                                  \
         return f32 ? run_guarded<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats)              \
                    : run_guarded<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats);
-    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(2, 4)
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 4) GL_CASE(2, 4)
 #undef GL_CASE
     return -1;
 }

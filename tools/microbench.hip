@@ -4,13 +4,21 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 
 #define CHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 1; } } while (0)
 
 constexpr int ITER = 50000;      // x8 unrolled body     // >= 5 ms per launch: shorter kernels measure the DVFS clock ramp, not the issue rate
 
+// per-wave placement / timing record (round 2): where did the dispatcher put each 64-thread block, and how many shader
+// cycles did its instruction stream take?  HW_ID (hwreg 4): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12]
+// se_id[15:13] ...; XCC_ID (hwreg 20): xcc_id[3:0].
+struct WaveRec { unsigned hw_id, xcc_id; unsigned long long t0, t1; };
+__device__ WaveRec* g_rec = nullptr;
+
 template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const float* in, int n)
 {
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     __shared__ float lds[256];
     float a0 = in[threadIdx.x], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float c = in[64], d = in[65];
@@ -64,6 +72,13 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
       }
     }
     out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    if (g_rec && threadIdx.x == 0) {
+        WaveRec r;
+        r.hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        r.xcc_id = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+        r.t0 = t_begin; r.t1 = __builtin_amdgcn_s_memtime();
+        g_rec[blockIdx.x] = r;
+    }
 }
 
 template <int KIND> int run(const char* name, float* out, float* in, int ops_per_iter)
@@ -71,7 +86,14 @@ template <int KIND> int run(const char* name, float* out, float* in, int ops_per
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     int n_cu = 256;
-    for (int wps : {1, 2, 4}) {               // waves per SIMD
+    static WaveRec* rec_dev = nullptr;
+    static std::vector<WaveRec> rec_host;
+    if (!rec_dev) {
+        CHK(hipMalloc(&rec_dev, sizeof(WaveRec) * 256 * 4 * 8));
+        CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_rec), &rec_dev, sizeof rec_dev));
+        rec_host.resize(256 * 4 * 8);
+    }
+    for (int wps : {1, 2, 4, 8}) {            // waves per SIMD
         const int blocks = n_cu * 4 * wps;
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, in, ITER);     // warm-up at full length
         CHK(hipDeviceSynchronize());
@@ -82,8 +104,25 @@ template <int KIND> int run(const char* name, float* out, float* in, int ops_per
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
         const double wave_instr = (double)ITER * 8 * ops_per_iter;          // per wave
         const double ns_per_instr_per_simd = ms * 1e6 / (wave_instr * wps);  // time per wave-instruction on one SIMD
-        printf("%-34s waves/SIMD=%d  %8.3f ms  -> %.3f ns per wave-instr per SIMD (%.2f cycles @2.27GHz)\n", name, wps, ms,
-               ns_per_instr_per_simd, ns_per_instr_per_simd * 2.27);
+        // placement: how many waves did each (xcc, se, cu, simd) actually get, and shader cycles per own instruction
+        CHK(hipMemcpy(rec_host.data(), rec_dev, sizeof(WaveRec) * blocks, hipMemcpyDeviceToHost));
+        std::vector<int> per_simd(8 * 8 * 16 * 4 * 2, 0);
+        double cyc = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const WaveRec& r = rec_host[b];
+            const int simd = (r.hw_id >> 4) & 3, cu = (r.hw_id >> 8) & 15, sh = (r.hw_id >> 12) & 1, se = (r.hw_id >> 13) & 7;
+            per_simd[(((((r.xcc_id & 7) * 8 + se) * 2 + sh) * 16 + cu) * 4) + simd]++;
+            cyc += (double)(r.t1 - r.t0);
+            if (r.t0 < tmin) tmin = r.t0;
+            if (r.t1 > tmax) tmax = r.t1;
+        }
+        int used = 0, mx = 0, mn = 1 << 30; int hist[17] = {0};
+        for (int v : per_simd) if (v) { ++used; if (v > mx) mx = v; if (v < mn) mn = v; hist[v > 16 ? 16 : v]++; }
+        const double cyc_per_instr = cyc / blocks / wave_instr;          // shader (s_memtime = 100 MHz? see below) ticks
+        printf("%-34s waves/SIMD=%d  %8.3f ms  -> %.3f ns per wave-instr per SIMD (%.2f cycles @2.27GHz) | placement: %d SIMDs used, "
+               "waves per used SIMD min %d max %d (hist 1:%d 2:%d 3:%d 4:%d 5:%d 6:%d 7:%d 8:%d) | s_memtime ticks per own wave-instr "
+               "%.3f, span %.3f ms at 100 MHz\n", name, wps, ms, ns_per_instr_per_simd, ns_per_instr_per_simd * 2.27, used, mn, mx,
+               hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], cyc_per_instr, (double)(tmax - tmin) / 1e5);
     }
     return 0;
 }
@@ -91,7 +130,7 @@ template <int KIND> int run(const char* name, float* out, float* in, int ops_per
 int main()
 {
     float *out, *in;
-    CHK(hipMalloc(&out, 256 * 4 * 8 * 64 * sizeof(float)));
+    CHK(hipMalloc(&out, 256 * 4 * 16 * 64 * sizeof(float)));
     CHK(hipMalloc(&in, 128 * sizeof(float)));
     std::vector<float> h(128, 0.999f); h[64] = 0.9999f; h[65] = 1e-3f;
     CHK(hipMemcpy(in, h.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
@@ -105,7 +144,9 @@ int main()
     run<5>("(ds_read bcast + v_fma) x8", out, in, 16);
     run<6>("(ds_read per-lane + v_fma) x8", out, in, 16);
     run<7>("dependent v_fma chain x8", out, in, 8);
-    run<10>("v_fma_f32 x8, 32 of 64 lanes active", out, in, 8);
-    run<11>("v_fma_f32 x8, 16 of 64 lanes active", out, in, 8);
+    if (getenv("MICROBENCH_ALL")) {
+        run<10>("v_fma_f32 x8, 32 of 64 lanes active", out, in, 8);
+        run<11>("v_fma_f32 x8, 16 of 64 lanes active", out, in, 8);
+    }
     return 0;
 }
