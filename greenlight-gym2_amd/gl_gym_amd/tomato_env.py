@@ -239,6 +239,7 @@ class TomatoVecEnv:
         self.observation_space = _box(lo, hi, (self.obs_dim,), np.float32)
         self.action_space = _box(-1.0, 1.0, (L.NU,), np.float32)
         self._actions = None
+        self._keep_applied_u, self._u_applied_T = False, None
         self.reset_infos: List[dict] = [{} for _ in range(self.B)]
         # pinned host staging for the numpy (SB3) path: the 1 KB/env observation block dominates the D2H traffic
         self._obs_host = [torch.empty(self.B, self.obs_dim, dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -324,6 +325,10 @@ class TomatoVecEnv:
         if want_obs:
             self._launch_obs(self.obs_t)
         if self.auto_reset:      # SB3 semantics: finished envs restart; their last obs goes to term_obs_t
+            if self._keep_applied_u:     # host infos report the control applied in THIS step (tomato_env.py:221), which the
+                if self._u_applied_T is None:                        # reset below zeroes for the finished envs
+                    self._u_applied_T = self.torch.empty_like(self.u_T)
+                self._u_applied_T.copy_(self.u_T)
             self._launch_reset(self.done_t)
             if want_obs:
                 self._launch_obs(self.obs_t, self.done_t, self.term_obs_t)
@@ -342,7 +347,11 @@ class TomatoVecEnv:
         self._actions = np.asarray(actions, dtype=np.float32)
 
     def step_wait(self):
-        return self._host_result(self.step_tensor(self.torch.as_tensor(self._actions, device=self.device)))
+        self._keep_applied_u = True
+        try:
+            return self._host_result(self.step_tensor(self.torch.as_tensor(self._actions, device=self.device)))
+        finally:
+            self._keep_applied_u = False
 
     def _host_result(self, out):
         """(obs, rewards, dones, infos) as SB3 consumes them, from step_tensor's device tensors."""
@@ -358,7 +367,8 @@ class TomatoVecEnv:
         # infos: SB3 wants a list of per-env dicts.  Built from two bulk D2H copies (info block, controls) with
         # zip over Python lists -- the cheapest pure-Python construction (about 1 us per env per key).
         rows = info_T.double().t().cpu().numpy()
-        ctrl = self.u.double().cpu().numpy()
+        applied = self._u_applied_T if (self.auto_reset and self._u_applied_T is not None) else self.u_T
+        ctrl = applied[:, :self.B].t().double().cpu().numpy()
         term = None
         if self.auto_reset and dones.any():
             term = self.term_obs_t.cpu().numpy() if term_obs is None else term_obs

@@ -34,6 +34,7 @@ class VecMonitorGPU:
         self.t_start = time.time()
         self.info_keywords = tuple(info_keywords)
         self._file = None
+        self._actions = None
         if filename is not None:
             if not filename.endswith("monitor.csv"):
                 filename = filename + ".monitor.csv"
@@ -87,12 +88,22 @@ class VecMonitorGPU:
                 self._file.flush()
         return dones, infos
 
-    def step(self, actions):
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32)
+
+    def step_wait(self):
         t = self.torch
-        obs_t, r_t, d_t, info_T = self.step_tensor(t.as_tensor(np.asarray(actions, dtype=np.float32),
-                                                               device=self.venv.device))
+        self.venv._keep_applied_u = True            # infos report the controls applied in this step
+        try:
+            obs_t, r_t, d_t, info_T = self.step_tensor(t.as_tensor(self._actions, device=self.venv.device))
+        finally:
+            self.venv._keep_applied_u = False
         dones, infos = self.host_infos(d_t, info_T)
         return self.venv._obs_to_host(obs_t), r_t.float().cpu().numpy(), dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
 
     def close(self):
         if self._file is not None:
@@ -101,4 +112,6 @@ class VecMonitorGPU:
         self.venv.close()
 
     def __getattr__(self, name):          # everything else (get_attr, obs_t, reward_t, metrics ...) is the wrapped env's
+        if name in ("venv", "step_async", "step_wait", "step", "reset"):      # never the inner env's (unmonitored) ones
+            raise AttributeError(name)
         return getattr(self.venv, name)

@@ -36,6 +36,7 @@ class VecNormalizeGPU:
         self.obs_norm_t = t.zeros(self.num_envs, self.obs_dim, dtype=t.float32, device=dev)
         self.reward_norm_t = t.zeros(self.num_envs, dtype=t.float32, device=dev)
         self.old_obs = self.old_reward = None
+        self._actions = None
 
     # ---- SB3-style views of the statistics -------------------------------------------------------
     @property
@@ -74,10 +75,19 @@ class VecNormalizeGPU:
     def reset(self):
         return self.reset_tensor().cpu().numpy()
 
-    def step(self, actions):
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32)
+
+    def step_wait(self):
         t = self.torch
-        obs_n, rew_n, done, info_T = self.step_tensor(t.as_tensor(np.asarray(actions, dtype=np.float32),
-                                                                  device=self.venv.device))
+        base = self.venv
+        while hasattr(base, "venv"):
+            base = base.venv
+        base._keep_applied_u = True                 # infos report the controls applied in this step
+        try:
+            obs_n, rew_n, done, info_T = self.step_tensor(t.as_tensor(self._actions, device=self.venv.device))
+        finally:
+            base._keep_applied_u = False
         # infos come from the wrapped env (so a VecMonitorGPU underneath keeps its "episode" entries); the terminal
         # observations are handed over normalised, as SB3's VecNormalize does
         term = None
@@ -85,6 +95,10 @@ class VecNormalizeGPU:
             term = self.normalize_obs(self.venv.term_obs_t.cpu().numpy())
         dones, infos = self.venv.host_infos(done, info_T, term)
         return obs_n.cpu().numpy(), rew_n.cpu().numpy(), dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
 
     def normalize_obs(self, obs):
         if not self.norm_obs:
@@ -104,30 +118,91 @@ class VecNormalizeGPU:
     def get_original_reward(self):
         return self.venv.reward_t[:self.num_envs].float().cpu().numpy()
 
+    # ---- persistence: SB3's VecNormalize.save / VecNormalize.load (callbacks.py:292, experiment_manager.py:360,
+    # experiments/evaluate_rl.py:31) --------------------------------------------------------------------------------
     def save(self, path):
+        """Writes the statistics under SB3's attribute names (obs_rms / ret_rms with mean, var, count; clip_obs,
+        clip_reward, gamma, epsilon, norm_obs, norm_reward, training) as a plain dict, so the file needs neither SB3 nor
+        this package to be read.  ``load`` reads this, the round-1 layout, and files written by SB3's own
+        ``VecNormalize.save`` (a pickled VecNormalize object)."""
+        o, r = self.obs_rms, self.ret_rms
         with open(path, "wb") as f:
-            pickle.dump(dict(obs_mean=self.obs_mean.cpu(), obs_var=self.obs_var.cpu(), obs_count=self.obs_count.cpu(),
-                             ret_stats=self.ret_stats.cpu(), clip_obs=self.clip_obs, clip_reward=self.clip_reward,
-                             gamma=self.gamma, epsilon=self.epsilon, norm_obs=self.norm_obs,
-                             norm_reward=self.norm_reward), f)
+            pickle.dump(dict(format="glgym-vecnormalize-2",
+                             obs_rms=dict(mean=o.mean, var=o.var, count=o.count),
+                             ret_rms=dict(mean=r.mean, var=r.var, count=r.count),
+                             clip_obs=self.clip_obs, clip_reward=self.clip_reward, gamma=self.gamma,
+                             epsilon=self.epsilon, norm_obs=self.norm_obs, norm_reward=self.norm_reward,
+                             training=self.training), f)
+
+    @staticmethod
+    def _read_stats(path):
+        """-> dict(obs_mean, obs_var, obs_count, ret_mean, ret_var, ret_count, + settings found) from any of the layouts."""
+        class _Stub:                                   # stands in for classes of packages that are not installed
+            def __init__(self, *a, **k):
+                pass
+
+            def __setstate__(self, state):
+                self.__dict__.update(state if isinstance(state, dict) else {})
+
+        class _Unpickler(pickle.Unpickler):            # an SB3-written file references stable_baselines3 / gymnasium
+            def find_class(self, module, name):        # classes; only their attribute dicts are needed here
+                try:
+                    return super().find_class(module, name)
+                except (ImportError, AttributeError):
+                    return type(name, (_Stub,), {})
+
+        with open(path, "rb") as f:
+            d = _Unpickler(f).load()
+
+        def rms(v):
+            g = (lambda k: v[k]) if isinstance(v, dict) else (lambda k: getattr(v, k))
+            return np.asarray(g("mean"), dtype=np.float64), np.asarray(g("var"), dtype=np.float64), float(g("count"))
+
+        out = {}
+        if isinstance(d, dict) and "obs_mean" in d:    # round-1 layout (torch tensors)
+            out.update(obs_mean=np.asarray(d["obs_mean"]), obs_var=np.asarray(d["obs_var"]),
+                       obs_count=float(np.asarray(d["obs_count"]).reshape(-1)[0]))
+            rs = np.asarray(d["ret_stats"], dtype=np.float64)
+            out.update(ret_mean=float(rs[0]), ret_var=float(rs[1]), ret_count=float(rs[2]))
+            get = d.get
+        else:                                          # SB3 attribute names: our dict, or a VecNormalize object
+            get = d.get if isinstance(d, dict) else (lambda k, default=None: getattr(d, k, default))
+            if get("obs_rms") is None or get("ret_rms") is None:
+                raise ValueError(f"{path}: neither a VecNormalizeGPU file nor an SB3 VecNormalize pickle")
+            m, v, c = rms(get("obs_rms"))
+            out.update(obs_mean=m, obs_var=v, obs_count=c)
+            m, v, c = rms(get("ret_rms"))
+            out.update(ret_mean=float(m), ret_var=float(v), ret_count=c)
+        for k in ("clip_obs", "clip_reward", "gamma", "epsilon", "norm_obs", "norm_reward", "training"):
+            if get(k) is not None:
+                out[k] = get(k)
+        return out
+
+    def _set_stats(self, d):
+        if np.shape(d["obs_mean"]) != (self.obs_dim,):
+            raise ValueError(f"saved statistics are for {np.shape(d['obs_mean'])} observations, the env has {self.obs_dim}")
+        t, dev = self.torch, self.venv.device
+        self.obs_mean.copy_(t.as_tensor(np.asarray(d["obs_mean"], dtype=np.float64), device=dev))
+        self.obs_var.copy_(t.as_tensor(np.asarray(d["obs_var"], dtype=np.float64), device=dev))
+        self.obs_count.fill_(float(d["obs_count"]))
+        self.ret_stats.copy_(t.tensor([d["ret_mean"], d["ret_var"], d["ret_count"]], dtype=t.float64, device=dev))
 
     @classmethod
     def load(cls, load_path, venv):
         """``VecNormalize.load(path, venv)`` (experiments/evaluate_rl.py:31): a wrapper around ``venv`` with the saved
-        statistics and settings (file written by ``save``)."""
-        with open(load_path, "rb") as f:
-            d = pickle.load(f)
-        self = cls(venv, norm_obs=d["norm_obs"], norm_reward=d["norm_reward"], clip_obs=d["clip_obs"],
-                   clip_reward=d["clip_reward"], gamma=d["gamma"], epsilon=d["epsilon"])
-        for k in ("obs_mean", "obs_var", "obs_count", "ret_stats"):
-            getattr(self, k).copy_(d[k])
+        statistics and settings.  Accepts files written by ``save`` and by SB3's ``VecNormalize.save`` (e.g. the
+        reference's ``best_vecnormalize.pkl``, common/callbacks.py:292) -- the latter also where SB3 is not installed."""
+        d = cls._read_stats(load_path)
+        kw = {k: d[k] for k in ("norm_obs", "norm_reward", "clip_obs", "clip_reward", "gamma", "epsilon", "training")
+              if k in d}
+        self = cls(venv, **kw)
+        self._set_stats(d)
         return self
 
     def load_stats(self, path):
-        with open(path, "rb") as f:
-            d = pickle.load(f)
-        for k in ("obs_mean", "obs_var", "obs_count", "ret_stats"):
-            getattr(self, k).copy_(d[k])
+        self._set_stats(self._read_stats(path))
 
     def __getattr__(self, name):          # get_attr / env_method / metrics / close ... fall through to the wrapped env
+        if name in ("venv", "step_async", "step_wait", "step", "reset"):      # never the inner env's (un-normalised) ones
+            raise AttributeError(name)
         return getattr(self.venv, name)

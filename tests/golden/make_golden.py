@@ -419,7 +419,105 @@ def g_storm():
                         truth_kind=np.array(KIND), truth_agreement=np.array(AGREE), lam_max_start=LAM)
 
 
-ALL = dict(storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+def _reference_env(season_length=1, uncertainty_scale=0.0, training=True):
+    """The reference's REAL TomatoEnv (gl_gym/environments/tomato_env.py, base_env.py, observations.py, rewards.py,
+    noise.py, utils.py, parameters.py -- imported from /root/reference, nothing copied) with its two absent third-party
+    dependencies substituted at import time:
+      * `gymnasium`            -> tests/golden/stubs/gymnasium_stub.py (Env seeding + spaces.Box, published semantics);
+      * the CasADi/CVODES pybind module gl_gym.environments.models.greenlight_model -> a class with the same
+        constructor / evalF signature (greenlight_model.cpp:31,96-101) whose step map is a tight stiff solve (Radau 1e-11)
+        of the C oracle RHS, itself pinned bit for bit to the reference's statement text by rhs_kat.
+    Everything ABOVE evalF -- action clipping, noise RNG order, clocks, the six observation modules, the terminal test,
+    reward, info -- is then the reference's own code running unmodified."""
+    import types
+    sys.path.insert(0, str(HERE / "stubs"))
+    import gymnasium_stub
+    gymnasium_stub.install()
+    models = types.ModuleType("gl_gym.environments.models")
+    models.__path__ = []
+    glm = types.ModuleType("gl_gym.environments.models.greenlight_model")
+
+    class GreenLight:                                  # greenlight_model.cpp:130-136
+        def __init__(self, nx, nu, nd, n_params, dt):
+            assert (nx, nu, nd, n_params) == (28, 6, 10, 208)
+            self.dt = float(dt)
+            self.n_calls = 0
+
+        def evalF(self, x, u, d, p):
+            self.n_calls += 1
+            y, _ = tight_step(np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64),
+                              np.asarray(d, dtype=np.float64), np.asarray(p, dtype=np.float64), dt=self.dt)
+            return [float(v) for v in y]               # a Python list, like the pybind return (SURVEY appendix B.8)
+
+    glm.GreenLight = GreenLight
+    sys.modules["gl_gym.environments.models"] = models
+    sys.modules["gl_gym.environments.models.greenlight_model"] = glm
+    import yaml
+    from gl_gym.environments.tomato_env import TomatoEnv            # noqa: E402  (reference)
+    with open("/root/reference/gl_gym/configs/envs/TomatoEnv.yml") as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    base, spec = cfg["GreenLightEnv"], cfg["TomatoEnv"]
+    # the Amsterdam KNMI files are not in the mount: Bleiswijk GL2009, day 0, a short season
+    base.update(weather_data_dir=WEATHER_DIR, location="Bleiswijk", data_source="GL", season_length=season_length,
+                start_train_year=2009, end_train_year=2009, start_train_day=0, end_train_day=0, training=training)
+    spec["eval_options"] = dict(eval_days=[0], eval_years=[2009], location="Bleiswijk", data_source="GL")
+    env = TomatoEnv(base_env_params=base, uncertainty_scale=uncertainty_scale, **spec)
+    return env, base, spec
+
+
+def g_refenv():
+    """G3: the reference's own TomatoEnv under the shims of _reference_env.
+    (a) config 1: RuleBasedController + step_raw_control, seed 666, 1 day (97 steps incl. the terminal one);
+    (b) step() with random actions in [-1, 1], seed 667, 1 day -- action clipping, Delta-u limit, clocks;
+    (c) step() with uncertainty_scale = 0.2, seed 668, 8 steps -- the per-step parameter noise as the env draws it.
+    Per step: applied control, state, the 263-float observation, reward, the 11 info scalars, terminated."""
+    out = {}
+    INFO = ["EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost", "temp_violation",
+            "co2_violation", "rh_violation", "lamp_violation"]
+
+    def record(tag, env, obs0, stepper, n_max):
+        rec = dict(u=[], x=[np.array(env.x, dtype=np.float64)], obs=[np.asarray(obs0, dtype=np.float64)], reward=[],
+                   info=[], done=[], doy=[env.day_of_year], hod=[env.hour_of_day])
+        done, k = False, 0
+        while not done and k < n_max:
+            obs, r, done, trunc, info = stepper(k)
+            assert trunc is False
+            rec["u"].append(np.array(info["controls"], dtype=np.float64)); rec["x"].append(np.array(env.x, dtype=np.float64))
+            rec["obs"].append(np.asarray(obs, dtype=np.float64)); rec["reward"].append(float(r))
+            rec["info"].append([float(info[q]) for q in INFO]); rec["done"].append(bool(done))
+            rec["doy"].append(env.day_of_year); rec["hod"].append(env.hour_of_day)
+            k += 1
+        for q, v in rec.items():
+            out[f"{tag}_{q}"] = np.array(v)
+        return k
+
+    env, base, spec = _reference_env(season_length=1)
+    ctrl = RuleBasedController(**RULE_BASED)
+    obs0, _ = env.reset(seed=666)
+    out["weather"] = np.array(env.weather_data)
+    out["p"] = np.array(env.p)
+    out["obs_names"] = np.array(env.get_obs_names())
+    out["obs_low"], out["obs_high"] = env.observation_space.low, env.observation_space.high
+    out["N"], out["Np"] = env.N, env.Np
+    n = record("rb", env, obs0, lambda k: env.step_raw_control(ctrl.predict(env.x, env.weather_data[env.timestep], env)), 200)
+    print("refenv rule-based: %d steps, obs dim %d, N = %d, sum reward %.5f" % (n, len(obs0), env.N, out["rb_reward"].sum()))
+    assert n == env.N + 1                                   # tests/env_test.py:84-92
+
+    env, _, _ = _reference_env(season_length=1)
+    obs0, _ = env.reset(seed=667)
+    acts = np.random.default_rng(667).uniform(-1, 1, (200, 6)).astype(np.float32)
+    out["ra_actions"] = acts
+    n = record("ra", env, obs0, lambda k: env.step(acts[k]), 200)
+    print("refenv random actions: %d steps, sum reward %.5f" % (n, out["ra_reward"].sum()))
+
+    env, _, _ = _reference_env(season_length=1, uncertainty_scale=0.2)
+    obs0, _ = env.reset(seed=668)
+    out["un_actions"] = acts[:8]
+    record("un", env, obs0, lambda k: env.step(acts[k]), 8)
+    np.savez_compressed(HERE / "refenv_1day.npz", info_keys=np.array(INFO), **out)
+
+
+ALL = dict(refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

@@ -277,3 +277,91 @@ def test_c_abi_rejects_bad_arguments_and_handles_ragged_batches(golden):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
         assert torch.equal(got[3], ref[0]) and torch.equal(got[4], ref[1])       # last lane / last row of the ragged tail
         e.close()
+
+
+def test_gymnasium_vector_env_facade(golden):
+    """gymnasium.vector.VectorEnv surface (north_star; reference base class gl_gym/environments/base_env.py:14):
+    reset(seed=, options=) -> (obs, infos), five-tuple step, dict-of-arrays infos with masks, SAME_STEP autoreset with
+    final_obs / final_info, and the same numbers as the SB3-style TomatoVecEnv on the same seed."""
+    from gl_gym_amd.vector_env import TomatoVectorEnv
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd import INFO_KEYS
+    w = golden("rollout_10day")["weather"]
+    B = 8
+    kw = dict(weather=w, dtype="float32", n_sub=224, season_length=0.05, start_rows=[0, 96], seed=1)
+    venv = TomatoVectorEnv(B, **kw)
+    ref = TomatoVecEnv(B, **kw)
+    assert venv.num_envs == B and venv.single_observation_space.shape == (263,) and venv.single_action_space.shape == (6,)
+    assert venv.observation_space.shape == (B, 263) and venv.action_space.shape == (B, 6)
+    assert venv.metadata["autoreset_mode"] == "same_step"
+    obs, infos = venv.reset(seed=5, options={"ignored": True})
+    ref.reset_tensor(5)
+    assert obs.shape == (B, 263) and obs.dtype == np.float32 and infos == {}
+    assert np.array_equal(obs, ref.obs_t.cpu().numpy())
+    rng = np.random.default_rng(0)
+    for k in range(5):                                               # episode = N + 1 = 5 steps
+        a = rng.uniform(-1, 1, (B, 6)).astype(np.float32)
+        obs, rew, term, trunc, infos = venv.step(a)
+        o2, r2, d2, i2 = ref.step(a)
+        assert obs.shape == (B, 263) and rew.shape == term.shape == trunc.shape == (B,) and not trunc.any()
+        assert np.array_equal(obs, o2) and np.allclose(rew, r2) and np.array_equal(term, d2)
+        for key in INFO_KEYS:
+            assert infos[key].shape == (B,) and infos["_" + key].all()
+            assert np.allclose(infos[key], [i2[b][key] for b in range(B)])
+        assert infos["controls"].shape == (B, 6)
+        # the control applied in THIS step, also for envs that finished and were reset (tomato_env.py:221)
+        assert np.allclose(infos["controls"], [i2[b]["controls"] for b in range(B)])
+        assert (term.all() if k == 4 else not term.any())
+        if k < 4:
+            assert "final_obs" not in infos
+            u_expect = infos["controls"].copy()
+    assert np.abs(infos["controls"]).max() > 0                       # not the zeros the reset wrote
+    assert infos["_final_obs"].all() and infos["_final_info"].all()
+    for b in range(B):
+        assert infos["final_obs"][b][18] == 4.0 and obs[b][18] == 0.0     # terminal "timestep" feature vs fresh episode
+        assert np.array_equal(infos["final_obs"][b], i2[b]["terminal_observation"])
+    assert np.allclose(infos["final_info"]["EPI"], infos["EPI"])
+    assert venv.get_attr("N") == (4,) * B and len(venv.call("get_obs_names")[0]) == 263
+    venv.close(); ref.close()
+
+
+def test_wrappers_follow_the_step_async_step_wait_protocol(golden):
+    """SB3 drives a VecEnv as step_async + step_wait (and the reference's own wrapper relies on it,
+    vec_env_wrappers.py:13-17): the wrappers' own processing must run on that path too -- normalised observations,
+    updated running statistics, infos['episode'] -- not the inner env's raw step."""
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.vec_monitor import VecMonitorGPU
+    from gl_gym_amd.vec_normalize import VecNormalizeGPU
+    w = golden("rollout_10day")["weather"]
+    B = 16
+
+    def stack():
+        return VecNormalizeGPU(VecMonitorGPU(TomatoVecEnv(B, weather=w, dtype="float32", n_sub=224, season_length=0.05,
+                                                          start_rows=[0, 96], seed=3)), clip_obs=10.0, gamma=0.99)
+    a_env, b_env = stack(), stack()
+    oa, ob = a_env.reset(), b_env.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(1)
+    for k in range(6):
+        act = rng.uniform(-1, 1, (B, 6)).astype(np.float32)
+        ra = a_env.step(act)
+        b_env.step_async(act)
+        rb = b_env.step_wait()
+        for x, y in zip(ra[:3], rb[:3]):
+            assert np.array_equal(x, y)
+        assert np.abs(ra[0]).max() <= 10.0 + 1e-6                    # clipped, normalised observations
+        if ra[2].any():
+            assert all("episode" in rb[3][b] and "terminal_observation" in rb[3][b] for b in np.nonzero(rb[2])[0])
+            assert all(np.abs(rb[3][b]["controls"]).max() > 0 for b in np.nonzero(rb[2])[0])
+    assert a_env.obs_rms.count == b_env.obs_rms.count > B
+    assert np.allclose(a_env.obs_rms.mean, b_env.obs_rms.mean)
+    # save / load round trip (SB3 attribute names, see tests/test_make_env.py for SB3-written files)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "vn.pkl")
+        a_env.save(path)
+        c_env = VecNormalizeGPU.load(path, b_env.venv)
+        assert np.array_equal(c_env.obs_rms.mean, a_env.obs_rms.mean) and c_env.ret_rms.var == a_env.ret_rms.var
+        assert c_env.gamma == 0.99 and c_env.clip_obs == 10.0
+    a_env.close(); b_env.close()

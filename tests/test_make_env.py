@@ -103,3 +103,78 @@ def test_make_vec_env_from_reference_style_config(cfg_dir):
     assert done.all() and infos[0]["episode"]["l"] == 49                  # monitor entries survive the VecNormalize layer
     assert np.abs(infos[0]["terminal_observation"]).max() <= 10.0         # ... and terminal observations come normalised
     ev.close()
+
+
+def test_vecnormalize_reads_sb3_written_pickles_without_sb3(tmp_path):
+    """The reference saves / loads SB3's own format (common/callbacks.py:292, experiment_manager.py:360,
+    experiments/evaluate_rl.py:31): a pickled VecNormalize OBJECT whose state holds obs_rms / ret_rms
+    (RunningMeanStd: mean, var, count), clip_obs, clip_reward, gamma, epsilon, norm_obs, norm_reward, training and the
+    gymnasium spaces.  VecNormalizeGPU must read such a file on a box without stable_baselines3 / gymnasium (classes it
+    cannot import are replaced by attribute bags), and its own files must round-trip."""
+    import pickle
+    import sys
+    import types
+    from gl_gym_amd.vec_normalize import VecNormalizeGPU
+    # build an SB3-layout pickle with throw-away modules under SB3's real import paths
+    names = ["stable_baselines3", "stable_baselines3.common", "stable_baselines3.common.vec_env",
+             "stable_baselines3.common.vec_env.vec_normalize", "stable_baselines3.common.running_mean_std",
+             "gymnasium", "gymnasium.spaces", "gymnasium.spaces.box"]
+    mods = {n: types.ModuleType(n) for n in names}
+
+    class RunningMeanStd:
+        def __init__(self, shape=()):
+            self.mean, self.var, self.count = np.zeros(shape), np.ones(shape), 1e-4
+    RunningMeanStd.__module__ = "stable_baselines3.common.running_mean_std"
+    RunningMeanStd.__qualname__ = "RunningMeanStd"
+
+    class Box:
+        def __init__(self):
+            self.low, self.high, self.shape = np.zeros(3), np.ones(3), (3,)
+    Box.__module__, Box.__qualname__ = "gymnasium.spaces.box", "Box"
+
+    class VecNormalize:
+        def __getstate__(self):            # SB3 drops venv / class_attributes / returns
+            return {k: v for k, v in self.__dict__.items() if k not in ("venv", "returns")}
+    VecNormalize.__module__ = "stable_baselines3.common.vec_env.vec_normalize"
+    VecNormalize.__qualname__ = "VecNormalize"
+    mods["stable_baselines3.common.running_mean_std"].RunningMeanStd = RunningMeanStd
+    mods["stable_baselines3.common.vec_env.vec_normalize"].VecNormalize = VecNormalize
+    mods["gymnasium.spaces.box"].Box = Box
+    rng = np.random.default_rng(0)
+    vn = VecNormalize()
+    vn.obs_rms, vn.ret_rms = RunningMeanStd((263,)), RunningMeanStd(())
+    vn.obs_rms.mean, vn.obs_rms.var, vn.obs_rms.count = rng.normal(size=263), rng.uniform(0.5, 2, 263), 12345.0
+    vn.ret_rms.mean, vn.ret_rms.var, vn.ret_rms.count = 0.37, 2.5, 999.0
+    vn.clip_obs, vn.clip_reward, vn.gamma, vn.epsilon = 10.0, 10.0, 0.9631, 1e-8
+    vn.norm_obs, vn.norm_reward, vn.training = True, False, False
+    vn.observation_space, vn.action_space, vn.venv, vn.returns = Box(), Box(), object(), np.zeros(8)
+    saved = {n: sys.modules.get(n) for n in names}
+    sys.modules.update(mods)
+    try:
+        path = tmp_path / "best_vecnormalize.pkl"
+        with open(path, "wb") as f:
+            pickle.dump(vn, f)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m
+    d = VecNormalizeGPU._read_stats(path)            # none of those modules is importable any more
+    np.testing.assert_array_equal(d["obs_mean"], vn.obs_rms.mean)
+    np.testing.assert_array_equal(d["obs_var"], vn.obs_rms.var)
+    assert d["obs_count"] == 12345.0 and (d["ret_mean"], d["ret_var"], d["ret_count"]) == (0.37, 2.5, 999.0)
+    assert d["gamma"] == 0.9631 and d["norm_reward"] is False and d["training"] is False and d["clip_obs"] == 10.0
+    # the file VecNormalizeGPU.save writes: plain dict under the same attribute names
+    own = tmp_path / "own.pkl"
+    with open(own, "wb") as f:
+        pickle.dump(dict(format="glgym-vecnormalize-2", obs_rms=dict(mean=vn.obs_rms.mean, var=vn.obs_rms.var, count=7.0),
+                         ret_rms=dict(mean=0.1, var=0.2, count=3.0), clip_obs=5.0, clip_reward=10.0, gamma=0.99,
+                         epsilon=1e-8, norm_obs=True, norm_reward=True, training=True), f)
+    d2 = VecNormalizeGPU._read_stats(own)
+    np.testing.assert_array_equal(d2["obs_var"], vn.obs_rms.var)
+    assert d2["obs_count"] == 7.0 and d2["ret_var"] == 0.2 and d2["clip_obs"] == 5.0
+    with open(tmp_path / "junk.pkl", "wb") as f:
+        pickle.dump({"something": 1}, f)
+    with pytest.raises(ValueError):
+        VecNormalizeGPU._read_stats(tmp_path / "junk.pkl")

@@ -176,3 +176,50 @@ def test_oracle_ode_pipe_bitwise_and_tight(oracle, golden):
     assert scaled_err(got, XT) < 1.3e-5     # same band as the 900 s one-step fixture (perturbed, harvest-active tuples)
     lag = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 300.0, 256, pipe=True) for i in range(len(XT))])
     assert scaled_err(lag, got) < 5e-6      # the kernels' lagged scheme vs the plain split scheme (1.1e-7 at h = 1.17 s)
+
+
+@pytest.mark.parametrize("tag", ["rb", "ra", "un"])
+def test_env_oracle_against_the_references_own_tomato_env(golden, tag):
+    """G3: fixtures produced by the reference's REAL TomatoEnv / observations.py / rewards.py / noise.py
+    (make_golden.py g_refenv: gymnasium stubbed, evalF = tight solve of the pinned RHS).  The env oracle must reproduce
+    every observation (all 263 entries, observations.py:59-182), reward, info scalar, clock and terminal flag
+    (tomato_env.py:115-146, 193-198) -- free-running with the same tight step map, so the states agree too.
+    rb: RuleBasedController + step_raw_control, ra: step() with random actions, un: step() with parameter noise 0.2."""
+    from oracle.gl_env_oracle import OracleTomatoEnv, INFO_KEYS
+    g = golden("refenv_1day")
+    assert list(g["info_keys"]) == list(INFO_KEYS)
+    U, X, OBS, R, INFO, DONE = (g[f"{tag}_{k}"] for k in ("u", "x", "obs", "reward", "info", "done"))
+    seed = {"rb": 666, "ra": 667, "un": 668}[tag]
+    env = OracleTomatoEnv(weather=g["weather"], p=g["p"], season_length=1, start_day=0, integrator="radau", seed=seed,
+                          train_years=[2009], train_days=[0], uncertainty_scale=0.2 if tag == "un" else 0.0)
+    obs = env.reset()
+    assert obs.shape == (263,) and int(g["N"]) == env.N == 96 and int(g["Np"]) == env.Np == 48
+    np.testing.assert_allclose(obs, OBS[0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(env.x, X[0], rtol=0, atol=0)
+    for k in range(len(U)):
+        if tag == "rb":
+            obs, r, done, info = env.step_raw_control(U[k])
+        else:
+            obs, r, done, info = env.step(g[f"{tag}_actions"][k])
+            np.testing.assert_allclose(info["controls"], U[k], rtol=0, atol=1e-15)      # float32 clip arithmetic
+        assert scaled_err(env.x, X[k + 1]) < 1e-9                 # same tight solver on both sides
+        np.testing.assert_allclose(obs, OBS[k + 1], rtol=1e-9, atol=1e-9)
+        assert abs(r - R[k]) < 1e-10 and done == bool(DONE[k])
+        np.testing.assert_allclose([info[q] for q in INFO_KEYS], INFO[k], rtol=1e-9, atol=1e-12)
+        assert abs(env.day_of_year - g[f"{tag}_doy"][k + 1]) < 1e-12 and abs(env.hour_of_day - g[f"{tag}_hod"][k + 1]) < 1e-12
+    if tag != "un":
+        assert len(U) == 97 and done                              # N + 1 steps (tests/env_test.py:84-92)
+
+
+def test_observation_space_and_names_match_the_reference(golden):
+    """observation_space bounds and get_obs_names() of the reference env (tomato_env.py:83-95, 200-206) against the
+    product's host-side descriptors (no GPU needed: they are plain tables)."""
+    from gl_gym_amd.tomato_env import observation_modules
+    g = golden("refenv_1day")
+    mods = observation_modules(int(g["Np"]))
+    names = [n for m in mods for n in m.obs_names]
+    assert names == list(g["obs_names"])
+    lo = np.concatenate([np.full(m.n_obs, m.low, np.float32) for m in mods])
+    hi = np.concatenate([np.full(m.n_obs, m.high, np.float32) for m in mods])
+    np.testing.assert_array_equal(lo, g["obs_low"])
+    np.testing.assert_array_equal(hi, g["obs_high"])
