@@ -35,14 +35,29 @@ for p in (str(ROOT), str(ROOT / "greenlight-gym2_amd")):
 # strength-reduced.  RK4 does 4 evaluations per sub-step.
 F_RHS = 1502          # add/mul flops
 S_RHS = 219           # quarter-rate special-function ops (rcp, exp, log, sqrt, ...)
-PEAK_VALU_TFLOPS = 157.3 / 2      # fp32 vector peak counts FMA = 2; the path's flops are mostly un-fused -> 78.65
-PEAK_SPECIAL_TOPS = 157.3 / 2 / 4  # quarter rate
+# fp32 vector peaks of MI355X (MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz): 157.3 TFLOP/s counts packed FMA
+# (v_pk_fma_f32: 2 lanes-worth x 2 flops); non-packed FMA code tops out at 78.65, non-FMA (add / mul) code at 39.3.
+PEAKS_TFLOPS = {"packed_fma": 157.3, "fma": 78.65, "non_fma": 39.3}
 PEAK_HBM_GBPS = 8000.0
 BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum, without the obs block
-# HBM bytes per step_kernel launch from rocprofv3 PMC passes on the DEFAULT workload (B = 65 536, fp32):
-# FETCH_SIZE 5 820 KB (x2: gfx950 reports half of the fetched bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 12 384 KB;
-# profiles/r01_v12_rk4_pmc_summary.csv.  bench.py cannot collect counters itself, so this is a recorded measurement.
-PMC_TRAFFIC_DEFAULT = (2 * 5822.73 + 12384.0) * 1024
+N_SIMD = 1024
+# Issue cost of one wave64 vector instruction on a SIMD, in cycles (tools/microbench.hip with verified wave placement,
+# profiles/r02_microbench_issue_rates.txt): with >= 2 co-resident waves a SIMD issues a plain fp32 op every 2.3-2.7 cycles
+# and a transcendental every 7.7; a LONE wave -- all this kernel can have at B = 65 536 = 1 024 waves on 1 024 SIMDs, and all
+# its ~320 registers allow -- gets one issued only every 5.0 / 8.4 cycles.
+CYC_PLAIN, CYC_TRANS = 2.3, 7.7                   # the SIMD's issue roof (what `frac` is measured against)
+CYC_PLAIN_1WAVE, CYC_TRANS_1WAVE = 5.0, 8.4       # the ceiling of one wave per SIMD
+# Recorded rocprofv3 PMC measurements of step_kernel on the DEFAULT workload (B = 65 536, fp32, RK4 n_sub 320), per launch:
+# bench.py cannot collect counters itself.  Written by tools/pmc_summary.py from the separate --pmc passes of
+# tools/profile_round.sh; the summary they come from is committed next to it.
+PMC_FILE = ROOT / "profiles" / "r02_pmc_constants.json"
+
+
+def load_pmc():
+    try:
+        return json.loads(PMC_FILE.read_text())
+    except (OSError, ValueError):
+        return None
 
 
 DEFAULT_SCHEME = "rk4"
@@ -232,18 +247,60 @@ def main():
     # final metric gather: the only collective on this path (RCCL all_gather of 6 doubles per rank)
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
-                           m.get("n_done", 0.0), kern_ms], device=None if share_gpu else dev)
+                           m.get("n_done", 0.0), kern_ms, m.get("n_guard_retries", 0.0), m.get("n_refined_substeps", 0.0),
+                           float(rank), float(666 + rank)], device=None if share_gpu else dev)
     if rank == 0:
         agg = aggregate(rows)
         t_max, value, kern_ms_max = agg["t_max"], agg["value"], agg["kernel_ms_max"]
         per_gpu_kernel_rate = B / (kern_ms_max * 1e-3)
         flops = STAGES[args.scheme] * args.n_sub * F_RHS
         specials = STAGES[args.scheme] * args.n_sub * S_RHS
-        ach_tflops = per_gpu_kernel_rate * flops / 1e12
-        ach_tops = per_gpu_kernel_rate * specials / 1e12
-        frac = ach_tflops / PEAK_VALU_TFLOPS + ach_tops / PEAK_SPECIAL_TOPS
+        alg_tflops = per_gpu_kernel_rate * flops / 1e12
+        alg_tops = per_gpu_kernel_rate * specials / 1e12
+        algorithmic_ratio = alg_tflops / PEAKS_TFLOPS["non_fma"] + alg_tops / (PEAKS_TFLOPS["non_fma"] / 4)
         obs_bytes = 0 if args.no_obs else 4 * env.obs_dim
         hbm_gbps = per_gpu_kernel_rate * BYTES_PER_ENV_STEP * (2 if args.dtype == "f64" else 1) / 1e9
+        # executed work: the recorded PMC instruction counts of the default workload, scaled to this run's batch / n_sub,
+        # over the kernel time measured live with HIP events on the launch stream
+        pmc = load_pmc()
+        is_default = args.dtype == "f32" and args.scheme == "rk4" and not args.uncertainty
+        roof = {"bound": "valu", "kernel": "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["packed_fma"],
+                "unit": "TFLOP/s", "frac": None, "traffic": None}
+        if pmc is not None and is_default:
+            scale = (B / 65536.0) * (args.n_sub / 320.0)
+            valu, trans = pmc["SQ_INSTS_VALU"] * scale, pmc["SQ_INSTS_VALU_TRANS_F32"] * scale
+            fma, mul, add = (pmc[k] * scale for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32",
+                                                      "SQ_INSTS_VALU_ADD_F32"))
+            clock_hz = pmc["clock_ghz"] * 1e9
+            avail = N_SIMD * kern_ms_max * 1e-3 * clock_hz                 # SIMD-cycles in one launch
+            roof.update({
+                # executed fp32 flops (64 lanes; FMA = 2; packed ops are counted once by the PMC, so this is a lower bound)
+                "achieved": 64 * (2 * fma + mul + add) / (kern_ms_max * 1e-3) / 1e12,
+                "frac": ((valu - trans) * CYC_PLAIN + trans * CYC_TRANS) / avail,
+                "frac_note": "executed issue slots / available: ((INSTS_VALU - TRANS) x 2.3 + TRANS x 7.7 cycles) / (1024 "
+                             "SIMDs x kernel time x clock), the per-instruction costs being what a SIMD sustains with >= 2 "
+                             "co-resident waves (profiles/r02_microbench_issue_rates.txt); <= 1 by construction",
+                "frac_one_wave_per_simd": ((valu - trans) * CYC_PLAIN_1WAVE + trans * CYC_TRANS_1WAVE) / avail,
+                "frac_one_wave_note": "the same with the costs a LONE wave pays (5.0 / 8.4 cycles): B = 65 536 is exactly "
+                                      "one wave per SIMD, so this is the ceiling the launch geometry allows; ~1 means the "
+                                      "wave issues whenever the hardware lets a single wave issue",
+                "traffic": pmc["traffic_bytes"] * (B / 65536.0),
+                "valu_insts_per_launch": valu, "trans_insts_per_launch": trans, "clock_ghz": pmc["clock_ghz"],
+                "valu_busy": pmc.get("valu_busy"), "pmc_source": pmc.get("source"),
+            })
+        roof.update({
+            "peaks_TFLOPs": PEAKS_TFLOPS,
+            "algorithmic_ratio": algorithmic_ratio,
+            "algorithmic_note": "SURVEY 8d figure: reference expression graph without CSE (stages x n_sub x (1502 flops + 219 "
+                                "special ops) per env-step) / kernel time, against the non-FMA peak and its quarter rate; > 1 "
+                                "because the kernel executes far less than that graph (hoisting, CSE, slow sub-expressions "
+                                "once per window)",
+            "algorithmic_TFLOPs": alg_tflops, "algorithmic_special_Tops": alg_tops,
+            "kernel_ms": kern_ms_max, "kernel_env_steps_per_s": per_gpu_kernel_rate,
+            "note": "path is VALU / transcendental bound, not HBM or MFMA (SURVEY 8d)",
+            "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE",
+            "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
+                    "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "obs_bytes_per_env_step": obs_bytes}})
         out = {
             "metric": "TomatoEnv env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K, "higher_is_better": True, "scaling": "weak",
@@ -255,31 +312,19 @@ def main():
                        "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True, "hip_graph": bool(args.graph),
                        "vecnormalize": bool(args.vecnorm),
                        "uncertainty_scale": args.uncertainty, "parallelism": f"env-shard x{world} (no data-path collective)",
-                       "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE (floor 224); the default "
-                                    "n_sub keeps the stability guard idle under sustained random actions (DESIGN.md 2)",
-                       "scheme": "classical RK4, Strang-split exact harvest flow, slow sub-expressions (LAI optics, crop "
-                                 "block, soil chain) evaluated once per sub-step at the predicted midpoint (DESIGN.md 2)"},
-            "roofline": {"bound": "valu", "kernel": "step_kernel", "achieved": ach_tflops, "peak": PEAK_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": frac,
-                         "traffic": PMC_TRAFFIC_DEFAULT if (B == 65536 and args.dtype == "f32" and not args.uncertainty
-                                                            and args.scheme == "rk4")
-                         else None,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                         "WRITE_SIZE, recorded in profiles/r01_v12_rk4_pmc_summary.csv (default workload only)",
-                         "note": "path is VALU/transcendental-bound, not HBM/MFMA (SURVEY 8d): achieved = algorithmic "
-                                 "add/mul flops (stages*n_sub*1502 per env-step, stages = 4 rk4 / 2 rk2) / mean "
-                                 "step_kernel time; frac adds the quarter-rate special-op term (stages*n_sub*219)",
-                         "executed_note": "frac > 1 because the kernel executes far less than the reference expression "
-                                          "graph (hoisting, CSE, slow sub-expressions once per sub-step): PMC on the "
-                                          "default workload (profiles/r01_v12_rk4_pmc_summary.csv) counts 4.90e8 VALU wave-"
-                                          "instructions per launch (1 496 per RK4 sub-step per wave, 169 of them "
-                                          "transcendental) and SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.883 VALU-busy "
-                                          "at one wave per SIMD -- the issue roof that actually binds",
-                         "special_ops_achieved_Tops": ach_tops, "special_ops_peak_Tops": PEAK_SPECIAL_TOPS,
-                         "kernel_ms": kern_ms_max, "kernel_env_steps_per_s": per_gpu_kernel_rate,
-                         "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                 "frac": hbm_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                                 "obs_bytes_per_env_step": obs_bytes}},
+                       "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE (floor 224); n_sub is "
+                                    "the nominal count of the stability-controlled sub-stepper (DESIGN.md 2)",
+                       "scheme": "classical RK4, stability-controlled per environment (rate bound per window -> more, smaller "
+                                 "sub-steps where needed; embedded error estimate as safety net), Strang-split exact harvest "
+                                 "flow, slow sub-expressions once per window at the predicted midpoint (DESIGN.md 2)"},
+            "roofline": roof,
+            "integrator_events": {"failed_integrations": agg["ode_failures"], "guard_retries": agg["guard_retries"],
+                                  "refined_substeps": agg["refined_substeps"],
+                                  "note": "failed integrations = env-steps reported like a failed CVODES call (done = 1, "
+                                          "state unchanged); guard retries = env-steps redone with 2x / 4x n_sub after a "
+                                          "non-finite result or an error estimate above tolerance; refined sub-steps = "
+                                          "sub-steps beyond n_sub inserted by the stability control"},
+            "ranks": agg["ranks"],
             "other_scheme": None if alt is None else {
                 "integrator": alt[0], "n_sub": alt[1], "value": B * world * K / alt[2], "unit": "env-steps/s",
                 "ms_per_step": 1e3 * alt[2] / K,

@@ -28,10 +28,15 @@ def gather_metrics(local: Sequence[float], device=None) -> List[List[float]]:
 
 
 def aggregate(rows: List[List[float]]) -> Dict[str, float]:
-    """rows[r] = [elapsed_s, env_steps, sum_reward, ode_failures, episodes_done, kernel_ms].
+    """rows[r] = [elapsed_s, env_steps, sum_reward, failed integrations, episodes_done, kernel_ms,
+    (optional:) guard retries, refined sub-steps, rank, seed].
     Whole-job throughput = all env-steps / the slowest rank's wall time."""
     t_max = max(r[0] for r in rows)
     steps = sum(r[1] for r in rows)
+    col = lambda i: [r[i] if len(r) > i else 0.0 for r in rows]  # noqa: E731
     return {"value": steps / t_max, "t_max": t_max, "env_steps": steps, "sum_reward": sum(r[2] for r in rows),
             "ode_failures": sum(r[3] for r in rows), "episodes_finished": sum(r[4] for r in rows),
-            "kernel_ms_max": max(r[5] for r in rows)}
+            "kernel_ms_max": max(r[5] for r in rows), "guard_retries": sum(col(6)), "refined_substeps": sum(col(7)),
+            "ranks": [{"rank": int(r[8]) if len(r) > 8 else i, "seed": int(r[9]) if len(r) > 9 else None,
+                       "elapsed_s": r[0], "env_steps": r[1], "sum_reward": r[2], "kernel_ms": r[5]}
+                      for i, r in enumerate(rows)]}

@@ -18,6 +18,38 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- two-rank bench on ONE GPU (tests/test_gpu_multiproc.py) ---------------------------------------------------------
+# The launcher (python -m torch.distributed.run ... bench.py --gpus 2) has to be a fresh child process started BEFORE this
+# process touches the GPU, so it is started here, at session start, and the test only collects its output.
+# torch.cuda.device_count() does not initialise the GPU.
+TWO_RANK = {"proc": None, "log": None}
+
+
+def pytest_sessionstart(session):
+    import os
+    markexpr = getattr(session.config.option, "markexpr", "") or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr or os.environ.get("GLGYM_SKIP_TWO_RANK") == "1":
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    import socket
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    log = tempfile.NamedTemporaryFile(prefix="glgym_two_rank_", suffix=".log", delete=False)
+    env = dict(os.environ, GLGYM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch", "4096", "--no-cpu-baseline", "--no-alt-scheme"]
+    TWO_RANK["proc"] = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=str(ROOT))
+    TWO_RANK["log"] = log.name
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -12,5 +12,22 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "SQ_ACTIVE_INST_V
 done
 f=$(ls $OUT/stats/*/*kernel_stats.csv | head -1); python tools/condense_stats.py $f $OUT/kernel_stats.csv
 python tools/pmc_summary.py $OUT/pmc*/*/*counter_collection.csv > $OUT/pmc_summary.csv
+# kernel duration under the counter passes -> clock = GRBM_GUI_ACTIVE / duration; constants for bench.py's roofline block
+python - <<PY
+import csv, glob, json, subprocess, sys
+subprocess.check_call([sys.executable, "tools/pmc_summary.py", "--constants", "$OUT/pmc_constants.json",
+                       "profiles/${TAG:-v9}_${SCHEME}_pmc_summary.csv"] + glob.glob("$OUT/pmc*/*/*counter_collection.csv"))
+d = json.load(open("$OUT/pmc_constants.json"))
+durs = []
+for f in glob.glob("$OUT/pmc7/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "step_kernel<float, false, true, false, false" in r["Kernel_Name"]:
+            durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+if durs and "GRBM_GUI_ACTIVE" in d:
+    d["kernel_ns_under_pmc"] = sum(durs) / len(durs)
+    d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / d["kernel_ns_under_pmc"]
+json.dump(d, open("$OUT/pmc_constants.json", "w"), indent=1)
+print(d)
+PY
 cat $OUT/kernel_stats.csv | head -8
 grep step_kernel $OUT/pmc_summary.csv
