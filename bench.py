@@ -46,7 +46,6 @@ N_SIMD = 1024
 # and a transcendental every 7.7; a LONE wave -- all this kernel can have at B = 65 536 = 1 024 waves on 1 024 SIMDs, and all
 # its ~320 registers allow -- gets one issued only every 5.0 / 8.4 cycles.
 CYC_PLAIN, CYC_TRANS = 2.3, 7.7                   # the SIMD's issue roof (what `frac` is measured against)
-CYC_PLAIN_1WAVE, CYC_TRANS_1WAVE = 5.0, 8.4       # the ceiling of one wave per SIMD
 # Recorded rocprofv3 PMC measurements of step_kernel on the DEFAULT workload (B = 65 536, fp32, RK4 n_sub 320), per launch:
 # bench.py cannot collect counters itself.  Written by tools/pmc_summary.py from the separate --pmc passes of
 # tools/profile_round.sh; the summary they come from is committed next to it.
@@ -62,7 +61,7 @@ def load_pmc():
 
 DEFAULT_SCHEME = "rk4"
 STAGES = {"rk4": 4, "rk2": 2}
-N_SUB = {"rk4": 320, "rk2": 360}
+N_SUB = {"rk4": 320, "rk2": 376}
 
 
 def cpu_baseline(n_sub: int, budget_s: float = 10.0):
@@ -123,8 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
     ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2"],
-                    help="sub-stepper: classical RK4 (n_sub 320) or explicit midpoint (n_sub 360); include/glgym.h")
-    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 320 rk4 / 360 rk2)")
+                    help="sub-stepper: classical RK4 (n_sub 320) or explicit midpoint (n_sub 376); include/glgym.h")
+    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 320 rk4 / 376 rk2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -280,13 +279,14 @@ def main():
                 "frac_note": "executed issue slots / available: ((INSTS_VALU - TRANS) x 2.3 + TRANS x 7.7 cycles) / (1024 "
                              "SIMDs x kernel time x clock), the per-instruction costs being what a SIMD sustains with >= 2 "
                              "co-resident waves (profiles/r02_microbench_issue_rates.txt); <= 1 by construction",
-                "frac_one_wave_per_simd": ((valu - trans) * CYC_PLAIN_1WAVE + trans * CYC_TRANS_1WAVE) / avail,
-                "frac_one_wave_note": "the same with the costs a LONE wave pays (5.0 / 8.4 cycles): B = 65 536 is exactly "
-                                      "one wave per SIMD, so this is the ceiling the launch geometry allows; ~1 means the "
-                                      "wave issues whenever the hardware lets a single wave issue",
+                "valu_busy_one_wave_per_simd": pmc.get("valu_busy"),
+                "valu_busy_note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the recorded profile: B = 65 536 is exactly one "
+                                  "wave per SIMD and a lone wave is issued a vector instruction only every ~5 cycles "
+                                  "(transcendental 8.4), so this -- not `frac` -- is how close the kernel is to the ceiling "
+                                  "its launch geometry allows",
                 "traffic": pmc["traffic_bytes"] * (B / 65536.0),
                 "valu_insts_per_launch": valu, "trans_insts_per_launch": trans, "clock_ghz": pmc["clock_ghz"],
-                "valu_busy": pmc.get("valu_busy"), "pmc_source": pmc.get("source"),
+                "pmc_source": pmc.get("source"),
             })
         roof.update({
             "peaks_TFLOPs": PEAKS_TFLOPS,

@@ -17,9 +17,9 @@ SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2}
 # NOMINAL sub-steps per 900 s env-step.  The floor is the 0.67-0.72 1/s cover mode (RK4: 224, midpoint: 302).  The kernels
 # are stability-controlled per environment (gl_model.hpp rk_delta): a lane whose local rate bound exceeds what the nominal
 # sub-step covers (0.91 1/s at 320) takes more, smaller sub-steps in that window -- and at one wave per SIMD the whole
-# launch waits for it.  320 / 360 keep that rare on the bench workload (rate bound above 0.85 1/s in 5e-6 of random-action
+# launch waits for it.  320 / 376 keep that rare on the bench workload (rate bound above 0.85 1/s in 5e-6 of random-action
 # env-steps on the synthetic weather year, never above 0.91 in 1.9e5); lower counts refine in most launches and end up slower.
-DEFAULT_N_SUB = {"rk4": 320, "rk2": 360}
+DEFAULT_N_SUB = {"rk4": 320, "rk2": 376}
 
 
 def default_n_sub(scheme: str, dt: float) -> int:

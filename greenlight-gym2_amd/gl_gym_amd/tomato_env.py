@@ -137,7 +137,7 @@ class TomatoVecEnv:
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
                  auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None,
                  model_variant: str = "ode", scheme: str = "rk4"):
-        """scheme / n_sub: "rk4" (classical RK4, default n_sub 320) or "rk2" (explicit midpoint, default n_sub 360);
+        """scheme / n_sub: "rk4" (classical RK4, default n_sub 320) or "rk2" (explicit midpoint, default n_sub 376);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()

@@ -73,7 +73,7 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *   GLGYM_SCHEME_RK4: classical RK4 (stability interval 2.785): n_sub >= 224 at dt = 900; use n_sub 320 (nominal lanes
  *     then cover rates up to 0.91 1/s without refinement).  The slow sub-expressions and the harvest flow are evaluated
  *     once per nominal sub-step in fp64, once per two in fp32 (n_sub is then rounded up to even).
- *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 360.  Same stability margin with 30 % fewer
+ *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 376.  Same stability margin with 30 % fewer
  *     right-hand sides; the slow sub-expressions and the harvest flow are shared by four nominal sub-steps (n_sub is
  *     rounded up to a multiple of 4).  Second order: 1e-4 one-step errors occur after abrupt control changes. */
 typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1 } glgym_scheme;

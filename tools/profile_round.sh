@@ -25,7 +25,7 @@ for f in glob.glob("$OUT/pmc7/*/*kernel_trace.csv"):
             durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 if durs and "GRBM_GUI_ACTIVE" in d:
     d["kernel_ns_under_pmc"] = sum(durs) / len(durs)
-    d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / d["kernel_ns_under_pmc"]
+    d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["kernel_ns_under_pmc"]      # the counter is summed over the 8 XCDs
 json.dump(d, open("$OUT/pmc_constants.json", "w"), indent=1)
 print(d)
 PY
