@@ -194,6 +194,9 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         make_crop_const<T, T>(pc, a.gasR, a.tCanMin, crLocal);
     }
     const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
+    // (fp64: keeping this block in LDS instead -- 79 doubles x 64 lanes = 40 KB per wave -- was built and measured: the
+    // generic kernel still needs 494 registers + 2 512 B of scratch, against 512 + 3 016 B, because the six 28-entry stage
+    // arrays alone are 336 registers in fp64; not kept)
     StepCoef<T> s;
     precompute(u, d, m, cr, s);
     if (PIPE) {                                                           // ode.hpp:184-189
@@ -993,11 +996,13 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // two waves per SIMD pay once the batch holds at least two waves for every SIMD (GLGYM_OCC = 1 | 2 overrides)
     static const int occ_env = [] { const char* e = std::getenv("GLGYM_OCC"); return e ? std::atoi(e) : 0; }();
     const bool occ2 = def && !a->crop_p && (occ_env == 2 || (occ_env == 0 && a->B >= 4 * h->n_simd * WAVE));
-    if (occ2) {
-        if (h->scheme == GLGYM_SCHEME_RK2) hipLaunchKernelGGL((step_kernel<T, false, true, false, true, 2>), grid, block, 0, st, k, m, rw);
-        else hipLaunchKernelGGL((step_kernel<T, false, true, false, false, 2>), grid, block, 0, st, k, m, rw);
-        HIPCHK(hipGetLastError());
-        return GLGYM_OK;
+    if constexpr (sizeof(T) == 4) {      // fp64 never takes the specialised kernels (def is false), so no fp64 OCC = 2 build
+        if (occ2) {
+            if (h->scheme == GLGYM_SCHEME_RK2) hipLaunchKernelGGL((step_kernel<T, false, true, false, true, 2>), grid, block, 0, st, k, m, rw);
+            else hipLaunchKernelGGL((step_kernel<T, false, true, false, false, 2>), grid, block, 0, st, k, m, rw);
+            HIPCHK(hipGetLastError());
+            return GLGYM_OK;
+        }
     }
     if (h->scheme == GLGYM_SCHEME_RK2) {
         if (a->crop_p) {
