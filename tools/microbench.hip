@@ -67,6 +67,16 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
             a4 = __builtin_amdgcn_rcpf(a4); a5 = __builtin_amdgcn_rcpf(a5); a6 = __builtin_amdgcn_rcpf(a6); a7 = __builtin_amdgcn_rcpf(a7);
         } else if (KIND == 9) {   // 8 x v_mul_f32 with an SGPR operand (uniform constant resident in SGPR)
             a0 *= c; a1 *= c; a2 *= c; a3 *= c; a4 *= c; a5 *= c; a6 *= c; a7 *= c;
+        } else if (KIND == 12) {  // 8 x (cross-lane move from the neighbouring lane + v_fma): what splitting one env over two lanes pays
+            a0 = fmaf(a0, c, __shfl_xor(a7, 1)); a1 = fmaf(a1, c, __shfl_xor(a0, 1)); a2 = fmaf(a2, c, __shfl_xor(a1, 1));
+            a3 = fmaf(a3, c, __shfl_xor(a2, 1)); a4 = fmaf(a4, c, __shfl_xor(a3, 1)); a5 = fmaf(a5, c, __shfl_xor(a4, 1));
+            a6 = fmaf(a6, c, __shfl_xor(a5, 1)); a7 = fmaf(a7, c, __shfl_xor(a6, 1));
+        } else if (KIND == 13) {  // the same exchange as a DPP move (quad_perm [1,0,3,2]: lane ^ 1), the cheapest cross-lane path
+            auto nb = [](float v) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+            };
+            a0 = fmaf(a0, c, nb(a7)); a1 = fmaf(a1, c, nb(a0)); a2 = fmaf(a2, c, nb(a1)); a3 = fmaf(a3, c, nb(a2));
+            a4 = fmaf(a4, c, nb(a3)); a5 = fmaf(a5, c, nb(a4)); a6 = fmaf(a6, c, nb(a5)); a7 = fmaf(a7, c, nb(a6));
         }
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
       }
@@ -79,6 +89,57 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
         r.t0 = t_begin; r.t1 = __builtin_amdgcn_s_memtime();
         g_rec[blockIdx.x] = r;
     }
+}
+
+// Role split over two waves of one workgroup (upper / lower compartment): per stage each wave publishes 8 values per lane in
+// LDS, both meet at a barrier, each reads the partner's 8 values.  Time per exchange round, with `work` dependent FMAs between
+// rounds standing in for the half stage each wave would compute.
+__global__ __launch_bounds__(128) void exch(float* out, const float* in, int rounds, int work)
+{
+    __shared__ float box[2][8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float v[8];
+    for (int j = 0; j < 8; ++j) v[j] = in[lane] + j;
+    const float c = in[64], d = in[65];
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = 0; i < work; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], c, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) box[w][j][lane] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += box[1 - w][j][lane];
+        __syncthreads();
+    }
+    float acc = 0;
+    for (int j = 0; j < 8; ++j) acc += v[j];
+    out[blockIdx.x * 128 + threadIdx.x] = acc;
+}
+
+int run_exchange(float* out, float* in)
+{
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const int rounds = 20000;
+    for (int wps : {2, 4}) {
+        const int blocks = 256 * 4 * wps / 2;
+        float t[2];
+        for (int k = 0; k < 2; ++k) {
+            const int work = k == 0 ? 0 : 20;                      // 160 dependent FMAs per wave per round ~ half a stage
+            hipLaunchKernelGGL(exch, dim3(blocks), dim3(128), 0, 0, out, in, rounds, work);
+            CHK(hipDeviceSynchronize());
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(exch, dim3(blocks), dim3(128), 0, 0, out, in, rounds, work);
+            CHK(hipEventRecord(e1));
+            CHK(hipEventSynchronize(e1));
+            CHK(hipEventElapsedTime(&t[k], e0, e1));
+        }
+        printf("two-wave LDS exchange (8 values/lane each way + 2 barriers) waves/SIMD=%d: %.1f ns = %.0f cycles @2.27GHz per round bare; "
+               "with 160 FMAs of work per wave per round %.1f ns = %.0f cycles (the work alone: 160 x issue cost)\n", wps,
+               t[0] * 1e6 / rounds, t[0] * 1e6 / rounds * 2.27, t[1] * 1e6 / rounds, t[1] * 1e6 / rounds * 2.27);
+    }
+    return 0;
 }
 
 template <int KIND> int run(const char* name, float* out, float* in, int ops_per_iter)
@@ -144,6 +205,9 @@ int main()
     run<5>("(ds_read bcast + v_fma) x8", out, in, 16);
     run<6>("(ds_read per-lane + v_fma) x8", out, in, 16);
     run<7>("dependent v_fma chain x8", out, in, 8);
+    run<12>("(ds_bpermute lane^1 + v_fma) x8", out, in, 16);
+    run<13>("(DPP quad_perm lane^1 + v_fma) x8", out, in, 16);
+    run_exchange(out, in);
     if (getenv("MICROBENCH_ALL")) {
         run<10>("v_fma_f32 x8, 32 of 64 lanes active", out, in, 8);
         run<11>("v_fma_f32 x8, 16 of 64 lanes active", out, in, 8);
