@@ -13,11 +13,14 @@
 //                             computed once per env-step and amortised over 4*n_sub RHS evaluations.
 //   tier 2b SlowCoef<T>    -- state-dependent sub-expressions whose outputs drive only slow balances (LAI optics and
 //                             canopy FIR coefficients, the crop block, the soil chain, the grow pipes): once per
-//                             window of 1-4 sub-steps at the predicted window midpoint (slow_coef()).
+//                             window of 1-4 nominal sub-steps at the predicted window midpoint (slow_coef()).
 //   tier 3  rhs_fast()     -- the remainder that follows the fast states, one lane per environment, four (RK4) or two
 //                             (explicit midpoint) evaluations per sub-step; its FIR block runs on register pairs in fp32.
+//                             rhs_fast<RATES> also returns an upper bound on the fastest local relaxation rate.
 //   rhs() = slow_coef() + rhs_fast() at one state = the reference's right-hand side (test hook, glgym_rhs).
-//   rk_delta<T, PIPE, ORDER, WIN>() -- the sub-stepper, in delta form, with the exact harvest sub-flow.
+//   rk_delta<T, PIPE, ORDER, WIN>() -- the sub-stepper: delta form, exact harvest sub-flow, and STABILITY CONTROL per
+//                             environment (the rate bound picks the number of sub-steps per window; an embedded error
+//                             estimate is the safety net; rk4_delta_guarded() retries / reports a failed integration).
 //
 // fp32-specific measures (hard part 2), all algebraically identical to the reference:
 //   * harvest switch as a logistic instead of (tanh z + 1)/2      (aux_states.hpp:75-79)

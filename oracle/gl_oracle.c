@@ -614,7 +614,8 @@ static void rk4_split_impl(const double *x0, const double *u, const double *d, c
     memcpy(x1, x, sizeof x);
 }
 
-/* The kernels' production scheme ("lagged slow auxiliaries").  Within one RK4 sub-step
+/* The round-1 production scheme ("lagged slow auxiliaries", fixed step) -- still the building block of the controlled
+ * scheme below (rk_sc_impl calls rhs_lagged), and what the controlled scheme reduces to for a nominal lane.  Within one RK4 sub-step
  *  (i)  the auxiliaries see the three slowest states that feed expensive sub-expressions -- x23 cLeaf (-> LAI -> all
  *       canopy optics and canopy FIR view factors), x21 tCan24 (1-day filter) and x26 tCanSum -- and
  *  (ii) the whole crop block a[191..216] (photosynthesis, carbohydrate flows, respiration), which feeds only dx22..25
@@ -964,7 +965,8 @@ int gl_oracle_rk_sc_guarded(const double *x0, const double *u, const double *d, 
     return ok ? extra : (extra > 2 ? 2 : extra);
 }
 
-/* Stability guard of the kernels: redo the env-step from x0 with 2x, then 4x sub-steps while the result is not finite.
+/* ROUND-1 guard (kept for regression comparisons; the kernels now run rk_sc_impl + gl_oracle_rk_sc_guarded above): redo the
+ * fixed-step env-step from x0 with 2x, then 4x sub-steps while the result is not finite.
  * Returns the number of extra attempts (0 normally; 2 with a non-finite result = failed integration). */
 int gl_oracle_rk4_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                           double *x1)

@@ -155,8 +155,8 @@ def rate_bound(x, u, d, p):
 
 
 def rk4_guarded(x, u, d, p, dt=900.0, n_sub=256):
-    """rk4_lagged (the kernels' scheme) with their stability guard (retry with 2x / 4x sub-steps).
-    Returns (x_next, retries)."""
+    """ROUND-1 scheme: fixed-step rk4_lagged with the non-finite-only guard (retry with 2x / 4x sub-steps); kept for
+    regression comparisons -- the kernels run rk_sc_guarded.  Returns (x_next, retries)."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
     out = np.empty(NX)
     r = lib().gl_oracle_rk4_guarded(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), _p(out))

@@ -92,3 +92,42 @@ def test_pinned_wet_screen_is_resolved_or_flagged_never_wrong(golden, oracle):
                 print(f"pinned screen tuple {i} {dtype}: {err:.2e}")
                 assert err < 1e-4, (i, dtype, err)
             m.close()
+
+
+def test_ragged_batch_and_mixed_lanes_are_independent(golden):
+    """Lanes that refine (storm tuples) next to nominal lanes in the same wavefront, in a batch that is not a multiple of
+    64: every lane's result must equal what it gets alone (the sub-step count is per lane; only the wave's duration is
+    shared)."""
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight_storm")
+    t = golden("step_tight")
+    X = np.concatenate([g["X"][:40], t["X"][:37]]); U = np.concatenate([g["U"][:40], t["U"][:37]])
+    D = np.concatenate([g["D"][:40], t["D"][:37]])
+    order = np.random.default_rng(0).permutation(len(X))          # interleave storm and nominal tuples: 77 lanes = 64 + 13
+    X, U, D = X[order], U[order], D[order]
+    for dtype in ("float64", "float32"):
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=320)
+        batch = m.evalF_batch(X, U, D)
+        p = golden("params_default")["p"].astype(np.float64)
+        for i in (0, 5, 40, 63, 64, 76):
+            assert np.array_equal(np.array(m.evalF(X[i], U[i], D[i], p)), batch[i]), (dtype, i)
+        m.close()
+
+
+def test_ode_pipe_tracking_at_dt_900_is_refined_not_unstable(golden, oracle):
+    """ODE_pipe's tracking term dxdt(9) = d10 - x9 has rate 1 1/s: beyond RK4's stability limit at the nominal sub-step of
+    dt = 900 s (2.785 / 2.81 s = 0.99 1/s).  The rate bound includes it, so the tracking lanes take smaller sub-steps
+    instead of oscillating; against plain RK4 of ODE_pipe with 16 384 sub-steps."""
+    from gl_gym_amd import GreenLight
+    g = golden("pipe_kat")
+    X, U, D14, P = g["X"], g["U"], g["D14"], g["P"]
+    track = np.nonzero((D14[:, 10] >= 1) & (D14[:, 12] <= 0))[0][:6]
+    m = GreenLight(28, 6, 14, 208, 900.0, dtype="float64", variant="ode_pipe", n_sub=320)
+    scale = 1e-3 * np.abs(X).max(axis=0)
+    for i in track:
+        got = np.array(m.evalF(X[i], U[i], D14[i], P[i]))
+        ref = oracle.rk4_split_pipe(X[i], U[i], D14[i], P[i], 900.0, 16384)
+        e = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), scale)))
+        assert e < 1e-4, (i, e)
+        assert abs(got[9] - D14[i, 10]) < 1e-6                      # after 900 s the pipe sits on the measured temperature
+    m.close()
