@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Wide random stress of the stability-controlled sub-stepper (oracle restatement = the kernels' arithmetic to 1e-12)
+against fine-RK4 truth.  TEST INFRASTRUCTURE.   python oracle/studies/stress_sc.py N [seed0]
+Distributions: spun-up states under (nearly) the same inputs, off-trajectory random states, extreme weather, corner
+controls, raw control jumps.  A tuple counts only if plain RK4 with 16 384 and 32 768 sub-steps agree to 2e-7."""
+import sys, time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "greenlight-gym2_amd"))
+from oracle import gl_oracle as O  # noqa: E402
+from gl_gym_amd.parameters import init_default_params  # noqa: E402
+from gl_gym_amd.utils import synthetic_weather, init_state  # noqa: E402
+
+p = init_default_params().astype(np.float64)
+w = synthetic_weather(n_rows=35040)
+COLMAX = np.array([1500, 1500, 30, 30, 30, 30, 30, 30, 30, 60, 30, 30, 30, 30, 30, 3000, 3000, 60, 30, 30, 30, 30, 2e4, 1e5,
+                   2.6e5, 6e4, 3.2e3, 60.])
+
+
+def sce(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * COLMAX)
+
+
+def sat(t):
+    return 610.78 * np.exp(17.2694 * t / (t + 238.3))
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    kind = seed % 5
+    d = w[int(rng.integers(0, 35040))].copy()
+    if kind in (1, 3):                                   # extreme weather
+        d[4] = rng.uniform(0, 40); d[1] = rng.uniform(-15, 35); d[5] = d[1] - rng.uniform(0, 25)
+        d[2] = rng.uniform(0.3, 1.0) * sat(d[1]); d[0] = rng.uniform(0, 1000) if rng.uniform() < 0.5 else 0.0
+    u = rng.uniform(0, 1, 6)
+    if kind == 2:                                        # corner controls
+        u = rng.choice([0.0, 1.0], 6)
+    if kind == 4:                                        # raw jump: spun up under very different controls
+        u_prev = rng.uniform(0, 1, 6)
+    else:
+        u_prev = np.clip(u - 0.1 * rng.uniform(-1, 1, 6), 0, 1)
+    x0 = init_state(d)
+    if kind == 3:                                        # off-trajectory random state
+        x0[0:2] = rng.uniform(400, 2500, 2); x0[2:10] += rng.normal(0, 4, 8); x0[17:21] += rng.normal(0, 4, 4)
+        x0[9] = rng.uniform(10, 70); x0[15:17] = rng.uniform(0.3, 1.05, 2) * sat(x0[2]); x0[21] = rng.uniform(12, 28)
+        x0[22] = rng.uniform(0, 2.5e4); x0[23] = rng.uniform(3e4, 1.1e5); x0[25] = rng.uniform(1e4, 3e5)
+        xs = x0
+    else:
+        xs = O.rk4(x0, u_prev, d, p, float(rng.uniform(300, 5400)), 8192)
+    if not np.all(np.isfinite(xs)):
+        return None
+    a = O.rk4(xs, u, d, p, 900., 16384); b = O.rk4(xs, u, d, p, 900., 32768)
+    if not np.all(np.isfinite(b)) or sce(a, b).max() > 2e-7:
+        return ("notruth", seed, kind)
+    res = []
+    for (n, o, wn) in ((320, 4, 2), (320, 4, 1), (376, 2, 4)):
+        y, r, ex, f = O.rk_sc_guarded(xs, u, d, p, 900., n, o, wn)
+        e = sce(y, b) if np.all(np.isfinite(y)) else np.full(28, np.inf)
+        res.append((float(e.max()), int(e.argmax()), r, ex, f))
+    return (seed, kind, float(d[4]), res)
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]); s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    with ThreadPoolExecutor(8) as ex:
+        R = [r for r in ex.map(one, range(s0, s0 + N)) if r is not None]
+    nt = [r for r in R if r[0] == "notruth"]; R = [r for r in R if r[0] != "notruth"]
+    print(f"{len(R)} tuples with truth, {len(nt)} without (kinks), {time.time() - t0:.0f} s")
+    for k, name in enumerate(("rk4-320 win2 (fp32 kernels' scheme)", "rk4-320 win1 (fp64 kernels')", "midpoint-376 win4")):
+        E = np.array([r[3][k][0] for r in R]); fails = sum(r[3][k][4] for r in R); ref = sum(r[3][k][3] > 0 for r in R)
+        ret = sum(r[3][k][2] for r in R)
+        print(f"{name}: err median {np.median(E):.1e} 99% {np.quantile(E, .99):.1e} max {E.max():.1e}; > 1e-4 (not flagged): "
+              f"{int(np.sum((E > 1e-4) & np.array([not r[3][k][4] for r in R])))}; flagged failed {fails}; refined {ref}; retries {ret}")
+        for r in R:
+            if r[3][k][0] > 1e-4 and not r[3][k][4]:
+                print("   WRONG seed", r[0], "kind", r[1], "wind %.1f" % r[2], r[3][k])
