@@ -1224,6 +1224,7 @@ constexpr int GL_N_SLOW = 16;
 #define SC_GRACE_S 60.0
 #define SC_GRACE_MUL 64.0
 #define SC_CAP_S 120.0
+#define SC_MOVE 32.0
 constexpr int SC_FLAG_CAP = 1, SC_FLAG_NONFINITE = 2, SC_FLAG_ERR = 4;
 constexpr int SC_NFAST = 9;
 GL_HD constexpr int sc_fast(int j) { return j == 0 ? 1 : j == 1 ? 3 : j == 2 ? 5 : j == 3 ? 6 : j == 4 ? 7 : j == 5 ? 15 : j == 6 ? 16 : j == 7 ? 17 : 20; }
@@ -1288,6 +1289,16 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         }
         // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
         T hs = M::min(S * M::rcp(lam), hnom);
+        {   // accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by
+            // more than SC_MOVE x its tolerance scale -- 4 K, 400 Pa, 400 mg m-3 -- in one sub-step.  Idle on trajectories;
+            // it keeps violent transients from far-off-equilibrium states accurate, where the rate bound of the window
+            // start goes stale within the window (oracle/studies/stress_sc.py)
+            T mv = T(0);
+#pragma unroll
+            for (int j = 0; j < SC_NFAST; ++j)
+                if (j != 7) mv = M::max(mv, M::abs(k[sc_fast(j)]) * T(sc_itol(j)));
+            hs = (mv * hs > T(SC_MOVE)) ? T(SC_MOVE) * M::rcp(mv) : hs;
+        }
         const bool capped = !(hs >= hmin);                        // also true for a NaN rate
         hs = capped ? hmin : hs;
         t_cap += capped ? hw : T(0);

@@ -763,6 +763,7 @@ void gl_oracle_rk4_lagged_pipe(const double *x0, const double *u, const double *
  * ---------------------------------------------------------------------------------- */
 #define SC_SAFETY 0.92
 #define SC_MAX_REFINE 16.0
+#define SC_MOVE 32.0
 #define SC_CAP_S 120.0       /* a rate beyond the cap may last this long within one env-step before the lane is failed */
 #define SC_GRACE_S 60.0      /* after a control jump the fast states legitimately move by K within seconds: */
 #define SC_GRACE_MUL 64.0    /* looser estimate tolerance during the first SC_GRACE_S of the env-step */
@@ -900,6 +901,16 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
             if (worst > emax) emax = worst;
         }
         double hs = fmin(S / lam, hnom);
+        {   /* accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by more
+             * than SC_MOVE x its tolerance scale -- 4 K, 400 Pa, 400 mg m-3 -- in one sub-step.  Idle on trajectories (10-day
+             * rollout: never; rule-based 0 -> 1 jumps: 2 extra sub-steps in the worst env-step; bench workload: 1e-5 of the
+             * env-steps, 1 extra sub-step); it is what keeps violent
+             * transients from far-off-equilibrium states accurate, where the rate bound of the window start goes stale
+             * within the window (oracle/studies/stress_sc.py: 270 of 3 970 such tuples wrong without it, 4 with it). */
+            double mv = 0.0;
+            for (int j = 0; j < 9; ++j) if (j != 7) mv = fmax(mv, fabs(k1[SC_FAST[j]]) / SC_TOL[j]);
+            if (mv * hs > SC_MOVE) hs = SC_MOVE / mv;
+        }
         const int capped = !(hs >= hmin);
         if (capped) { hs = hmin; t_cap += hw; }
         const int n = (int)fmax(1.0, ceil(hw / hs - 1e-3));
