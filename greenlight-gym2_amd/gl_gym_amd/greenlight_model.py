@@ -47,6 +47,7 @@ class GreenLight:
 
     def set_n_sub(self, n_sub):
         L.check(self._lib.glgym_set_n_sub(self._h, int(n_sub)), "glgym_set_n_sub")
+        self.n_sub = int(n_sub)
 
     def _as(self, a, n, B):
         a = np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1)

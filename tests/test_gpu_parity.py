@@ -487,3 +487,21 @@ def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, sche
         assert np.max(np.abs(env.x[0].double().cpu().numpy() - ref) / sc) < 1e-11, (scheme, k, "glgym_step")
         assert np.max(np.abs(np.array(m.evalF(x_prev, u, W[k], p)) - ref) / sc) < 1e-11, (scheme, k, "glgym_evalF")
     env.close(); m.close()
+
+
+def test_default_n_sub_scales_with_dt(golden, oracle):
+    """Without an explicit n_sub the nominal sub-step stays 2.81 s for any dt (108 sub-steps at the dt = 300 s of the
+    reference's experiments/run_time.py, 640 at 1 800 s); accuracy against plain RK4 with 8 192 sub-steps."""
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight")
+    X, U, D, P = g["X"], g["U"], g["D"], g["P"].astype(np.float64)
+    scale = 1e-3 * np.abs(X).max(axis=0)
+    for dt, n_expect in ((300.0, 108), (1800.0, 640)):
+        for dtype in ("float64", "float32"):
+            m = GreenLight(28, 6, 10, 208, dt, dtype=dtype)
+            assert m.n_sub == n_expect
+            for i in (0, 7, 19, 33):
+                got = np.array(m.evalF(X[i], U[i], D[i], P[i]))
+                ref = oracle.rk4_split(X[i], U[i], D[i], P[i], dt, 8192)
+                assert float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), scale))) < 5e-5, (dt, dtype, i)
+            m.close()
