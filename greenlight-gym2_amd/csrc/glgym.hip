@@ -684,6 +684,151 @@ __global__ void vecnorm_reward_kernel(const T* __restrict__ reward, float* __res
     if (done && done[b]) returns[b] = 0.0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Weather pipeline on the device (gl_gym/environments/utils.py:48-125): raw 300-s samples -> unit
+// conversions -> daily light sum / daylight flags -> PCHIP resample to the env's grid.  fp64 throughout (it runs once per
+// season table, not per step); the result is written in the handle's dtype.  Mirrors gl_gym_amd/utils.py
+// (weather_from_raw), itself checked bit for bit against the reference's loader.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double w_sat_vp(double t) { return 610.78 * exp(17.2694 * t / (t + 238.3)); }
+
+// columns 0..6 of the raw-grid table W[10][n] (SoA)
+__global__ void weather_convert_kernel(int n, const double* __restrict__ time, const double* __restrict__ i_glob,
+                                       const double* __restrict__ t_out, const double* __restrict__ rh,
+                                       const double* __restrict__ wind, const double* __restrict__ t_sky, double co2_ppm,
+                                       double* __restrict__ W)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double R = 8.3144598, C2K = 273.15, M_CO2 = 44.01e-3, M_H2O = 18.01528e-3, P_ATM = 101325.0;
+    const double t = t_out[k];
+    const double rho_v = (rh[k] / 100.0) * w_sat_vp(t) * M_H2O / (R * (t + C2K));              // rh2vaporDens
+    const double rho_sat = (100.0 / 100.0) * w_sat_vp(t) * M_H2O / (R * (t + C2K));
+    W[0 * (size_t)n + k] = i_glob[k];
+    W[1 * (size_t)n + k] = t;
+    W[2 * (size_t)n + k] = w_sat_vp(t) * (rho_v / rho_sat);                                    // vaporDens2pres
+    W[3 * (size_t)n + k] = (P_ATM * 1e-6 * co2_ppm * M_CO2 / (R * (t + C2K))) * 1e6;           // co2ppm2dens * 1e6
+    W[4 * (size_t)n + k] = wind[k];
+    W[5 * (size_t)n + k] = t_sky[k];
+    const double year = 3600.0 * 24.0 * 365.0;
+    W[6 * (size_t)n + k] = 10.0 + 5.0 * sin(2.0 * 3.14159265358979323846 * (time[k] + 0.625 * year) / year);   // soilTempNl
+}
+
+// columns 7..9: the two sequential passes of the loader (dailLightSum: utils.py:216-250; computeisDay: :177-214, whose
+// later tests see the ramps written by earlier ones).  One lane: O(n) work, n ~ 3e4.
+__global__ void weather_scan_kernel(int n, const double* __restrict__ time, double* __restrict__ W)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0 || n < 2) return;
+    const double* rad = W;
+    double* dli = W + 7 * (size_t)n;
+    double* is_day = W + 8 * (size_t)n;
+    double* smooth = W + 9 * (size_t)n;
+    const double c = 86400.0, interval = time[1] - time[0];
+    auto next_jump = [&](int from) {
+        for (int k = from < 0 ? 0 : from; k + 1 < n; ++k)
+            if (floor(time[k + 1] / c) - floor(time[k] / c) == 1.0) return k;
+        return -1;
+    };
+    int before = 0, j = next_jump(0), after = j >= 0 ? j + 1 : n, i = 0;
+    while (i < n) {
+        const int seg_end = after < n ? after : n;
+        double sum = 0.0;
+        for (int k = before; k <= after && k < n; ++k) sum += rad[k];
+        for (int k = i; k < seg_end; ++k) dli[k] = sum * interval * 1e-6;
+        i = seg_end;
+        if (i >= n) break;
+        before = after;
+        j = next_jump(before + 2);
+        after = j >= 0 ? j : n;
+    }
+    double dt_mean = (time[n - 1] - time[0]) / (double)(n - 1);
+    for (int k = 0; k < n; ++k) { is_day[k] = rad[k] > 0.0 ? 1.0 : 0.0; smooth[k] = is_day[k]; }
+    const int n_tr = (int)(3600.0 / dt_mean), half = n_tr / 2;
+    if (n_tr < 2) return;
+    const double step = 1.0 / (double)(n_tr - 1);
+    bool in_sunset = false;
+    for (int k = n_tr; k < n - n_tr; ++k) {
+        const double cur = is_day[k], nxt = is_day[k + 1];
+        if (cur == 0.0) {
+            in_sunset = false;
+            if (nxt == 1.0)
+                for (int q = 0; q < 2 * half && q < n_tr; ++q) {
+                    const double r = (q == n_tr - 1) ? 1.0 : (double)q * step;
+                    is_day[k - half + q] = r;
+                    smooth[k - half + q] = 1.0 / (1.0 + exp(-10.0 * (r - 0.5)));
+                }
+        } else if (cur == 1.0 && nxt == 0.0 && !in_sunset) {
+            for (int q = 0; q < 2 * half && q < n_tr; ++q) {
+                const double r = (q == n_tr - 1) ? 1.0 : (double)q * step;
+                is_day[k - half + q] = 1.0 - r;
+                smooth[k - half + q] = 1.0 - 1.0 / (1.0 + exp(-10.0 * (r - 0.5)));
+            }
+            in_sunset = true;
+        }
+    }
+}
+
+// PCHIP slopes (Fritsch-Carlson as scipy.interpolate.PchipInterpolator): D[c][k]
+__device__ __forceinline__ double w_sign(double v) { return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
+__device__ __forceinline__ double pchip_edge(double h0, double h1, double m0, double m1)
+{
+    double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+    if (w_sign(d) != w_sign(m0)) d = 0.0;
+    else if (w_sign(m0) != w_sign(m1) && fabs(d) > 3.0 * fabs(m0)) d = 3.0 * m0;
+    return d;
+}
+__global__ void pchip_slopes_kernel(int n, int n_col, const double* __restrict__ x, const double* __restrict__ W,
+                                    double* __restrict__ D)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (k >= n || col >= n_col) return;
+    const double* y = W + (size_t)col * n;
+    auto h = [&](int i) { return x[i + 1] - x[i]; };
+    auto m = [&](int i) { return (y[i + 1] - y[i]) / h(i); };
+    double d;
+    if (n == 2) d = m(0);
+    else if (k == 0) d = pchip_edge(h(0), h(1), m(0), m(1));
+    else if (k == n - 1) d = pchip_edge(h(n - 2), h(n - 3), m(n - 2), m(n - 3));
+    else {
+        const double m0 = m(k - 1), m1 = m(k), h0 = h(k - 1), h1 = h(k);
+        if (w_sign(m0) != w_sign(m1) || m0 == 0.0 || m1 == 0.0) d = 0.0;
+        else {
+            const double w1 = 2.0 * h1 + h0, w2 = h1 + 2.0 * h0;
+            d = 1.0 / ((w1 / m0 + w2 / m1) / (w1 + w2));
+        }
+    }
+    D[(size_t)col * n + k] = d;
+}
+
+// evaluation on linspace(x[0], x[n-1], n_out) in the power-series order of scipy's PPoly; iGlob < 1e-10 -> 0
+template <class T>
+__global__ void pchip_eval_kernel(int n, int n_col, int n_out, int nd, const double* __restrict__ x,
+                                  const double* __restrict__ W, const double* __restrict__ D, T* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (i >= n_out || col >= n_col) return;
+    const double start = x[0], stop = x[n - 1];
+    const double stepo = n_out > 1 ? (stop - start) / (double)(n_out - 1) : 0.0;
+    const double t = (i == n_out - 1 && n_out > 1) ? stop : (double)i * stepo + start;
+    int lo = 0, hi = n - 1;                         // last k with x[k] <= t, clipped to n - 2
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (x[mid] <= t) lo = mid; else hi = mid; }
+    const int k = lo > n - 2 ? n - 2 : lo;
+    const double* y = W + (size_t)col * n;
+    const double* d = D + (size_t)col * n;
+    const double dx = x[k + 1] - x[k], slope = (y[k + 1] - y[k]) / dx;
+    const double tt = (d[k] + d[k + 1] - 2.0 * slope) / dx;
+    const double c0 = tt / dx, c1 = (slope - d[k]) / dx - tt, c2 = d[k], c3 = y[k];
+    const double sdx = t - x[k];
+    double res = 0.0, z = 1.0;
+    res += c3 * z; z *= sdx;
+    res += c2 * z; z *= sdx;
+    res += c1 * z; z *= sdx;
+    res += c0 * z;
+    if (col == 0 && res < 1e-10) res = 0.0;
+    out[(size_t)i * nd + col] = T(res);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -1053,6 +1198,36 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     return GLGYM_OK;
 }
 
+
+
+extern "C" int glgym_weather(glgym_handle h, const glgym_weather_args* a, void* stream)
+{
+    if (!h || !a || a->n_raw < 3 || a->n_out < 1 || a->nd < ND || !a->time || !a->i_glob || !a->t_out || !a->rh || !a->wind ||
+        !a->t_sky || !a->out || !a->workspace) {
+        g_err = "glgym_weather: bad arguments (>= 3 raw samples, nd >= 10, non-null device pointers)";
+        return GLGYM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int n = a->n_raw;
+    double* W = a->workspace;                       // [10][n] converted columns on the raw grid
+    double* D = a->workspace + (size_t)10 * n;      // [10][n] PCHIP slopes
+    hipLaunchKernelGGL(weather_convert_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, a->time, a->i_glob, a->t_out,
+                       a->rh, a->wind, a->t_sky, a->co2_ppm, W);
+    hipLaunchKernelGGL(weather_scan_kernel, dim3(1), dim3(64), 0, st, n, a->time, W);
+    hipLaunchKernelGGL(pchip_slopes_kernel, dim3((n + 255) / 256, 10), dim3(256), 0, st, n, 10, a->time, W, D);
+    if (a->nd > ND) {                               // extra columns (ODE_pipe rows) are the caller's: start from zero
+        HIPCHK(hipMemsetAsync(a->out, 0, (size_t)a->n_out * a->nd * (h->dtype == GLGYM_F32 ? 4 : 8), st));
+    }
+    const dim3 grid((a->n_out + 255) / 256, 10);
+    if (h->dtype == GLGYM_F32)
+        hipLaunchKernelGGL((pchip_eval_kernel<float>), grid, dim3(256), 0, st, n, 10, a->n_out, a->nd, a->time, W, D,
+                           (float*)a->out);
+    else
+        hipLaunchKernelGGL((pchip_eval_kernel<double>), grid, dim3(256), 0, st, n, 10, a->n_out, a->nd, a->time, W, D,
+                           (double*)a->out);
+    HIPCHK(hipGetLastError());
+    return GLGYM_OK;
+}
 
 extern "C" int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* stream)
 {

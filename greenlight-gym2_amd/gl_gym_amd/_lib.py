@@ -98,6 +98,12 @@ class RuleArgs(C.Structure):
                 ("hour", C.c_void_p), ("doy", C.c_void_p), ("control", C.c_void_p)]
 
 
+class WeatherArgs(C.Structure):
+    _fields_ = [("n_raw", C.c_int32), ("time", C.c_void_p), ("i_glob", C.c_void_p), ("t_out", C.c_void_p),
+                ("rh", C.c_void_p), ("wind", C.c_void_p), ("t_sky", C.c_void_p), ("co2_ppm", C.c_double),
+                ("n_out", C.c_int32), ("nd", C.c_int32), ("out", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 # every symbol include/glgym.h declares, with its prototype
 _DP = C.POINTER(C.c_double)
 PROTOTYPES = {
@@ -121,6 +127,7 @@ PROTOTYPES = {
                                    C.c_void_p]),
     "glgym_rule_based": (C.c_int, [C.c_void_p, C.POINTER(RuleCfg), C.POINTER(RuleArgs), C.c_void_p]),
     "glgym_vecnorm": (C.c_int, [C.c_void_p, C.POINTER(VecNormArgs), C.c_void_p]),
+    "glgym_weather": (C.c_int, [C.c_void_p, C.POINTER(WeatherArgs), C.c_void_p]),
     "glgym_timer_start": (C.c_int, [C.c_void_p, C.c_void_p]),
     "glgym_timer_stop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
 }

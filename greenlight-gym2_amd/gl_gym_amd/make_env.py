@@ -42,22 +42,25 @@ def load_env_params(env_id: str, path: str) -> Tuple[Dict, Dict]:
 
 
 def season_table(weather_data_dir: str, location: str, data_source: str, years: Sequence[int], days: Sequence[float],
-                 season_length: float, pred_horizon: float, dt: float, nd: int):
+                 season_length: float, pred_horizon: float, dt: float, nd: int, pipeline=None):
     """One table holding the season window of every (year, start_day) pair, each loaded exactly as ``TomatoEnv.reset``
     does (tomato_env.py:249-259: ``load_weather_data(dir, location, source, year, start_day, season_length, Np + 1, dt, nd)``
     -- note the reference passes Np + 1 *steps* in the loader's *days* slot; kept, it only lengthens the window).
-    Returns (table [rows, nd], start_rows, start_days, start_years)."""
+    Returns (table [rows, nd], start_rows, start_days, start_years).  With ``pipeline`` (a
+    ``weather_device.WeatherPipeline``) the array work runs on the device and the table is a device tensor."""
     Np = int(pred_horizon * 86400 / dt)
     blocks, start_rows, start_days, start_years, row = [], [], [], [], 0
     for y in years:
         for d in days:
-            w = load_weather_data(weather_data_dir, location, data_source, int(y), d, season_length, Np + 1, dt, nd)
+            load = load_weather_data if pipeline is None else pipeline.load_weather_data
+            w = load(weather_data_dir, location, data_source, int(y), d, season_length, Np + 1, dt, nd)
             blocks.append(w)
             start_rows.append(row)
             start_days.append(float(d))
             start_years.append(int(y))
             row += len(w)
-    return np.concatenate(blocks, axis=0), start_rows, start_days, start_years
+    table = np.concatenate(blocks, axis=0) if pipeline is None else pipeline.torch.cat(blocks, dim=0)
+    return table, start_rows, start_days, start_years
 
 
 def _check_supported(reward_function, observation_modules, base):
@@ -80,7 +83,8 @@ def tomato_vec_env_from_config(n_envs: int, reward_function: str, observation_mo
                                base_env_params: Optional[Dict[str, Any]] = None, uncertainty_scale: float = 0.0,
                                seed: int = 0, **device_kw):
     """``TomatoEnv(**env_specific_params, base_env_params=env_base_params)`` for n_envs environments at once.
-    device_kw: dtype, n_sub, device, auto_reset, lazy_infos, model_variant (TomatoVecEnv keyword arguments)."""
+    device_kw: dtype, n_sub, device, auto_reset, lazy_infos, model_variant (TomatoVecEnv keyword arguments);
+    weather_on_device=True builds the weather table with the device pipeline (weather_device.py)."""
     from .tomato_env import TomatoVecEnv
     base = dict(base_env_params or {})
     _check_supported(reward_function, observation_modules, base)
@@ -93,8 +97,14 @@ def tomato_vec_env_from_config(n_envs: int, reward_function: str, observation_mo
         years, days = list(eval_options["eval_years"]), list(eval_options["eval_days"])
         location, source = eval_options["location"], eval_options["data_source"]
     dt, season, horizon = float(base.get("dt", 900)), base.get("season_length", 60), base.get("pred_horizon", 0.5)
+    pipeline = None
+    if device_kw.pop("weather_on_device", False):        # unit conversions, DLI / daylight flags, PCHIP in HIP kernels
+        from .weather_device import WeatherPipeline
+        pipeline = WeatherPipeline(device=device_kw.get("device", "cuda:0"), dtype="float64", nd=int(base.get("nd", 10)))
     table, rows, sdays, syears = season_table(base["weather_data_dir"], location, source, years, days, season, horizon,
-                                              dt, int(base.get("nd", 10)))
+                                              dt, int(base.get("nd", 10)), pipeline)
+    if pipeline is not None:
+        pipeline.close()
     env = TomatoVecEnv(n_envs, weather=table, dt=dt, season_length=season, pred_horizon=horizon, seed=seed,
                        start_rows=rows, start_days=sdays, reward_params=reward_params, constraints=constraints,
                        uncertainty_scale=uncertainty_scale, **device_kw)

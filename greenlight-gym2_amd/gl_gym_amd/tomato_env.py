@@ -153,7 +153,8 @@ class TomatoVecEnv:
         self.dt = float(dt)
         self.c = 86400
         self.nx, self.nu, self.num_params = L.NX, L.NU, L.NP
-        self.nd = L.ND if weather is None else int(np.asarray(weather).shape[1])
+        weather_is_tensor = weather is not None and hasattr(weather, "data_ptr")          # a torch tensor (device table)
+        self.nd = L.ND if weather is None else int(weather.shape[1])
         if model_variant not in ("ode", "ode_pipe"):
             raise ValueError("model_variant must be 'ode' or 'ode_pipe'")
         self.model_variant = model_variant
@@ -196,7 +197,8 @@ class TomatoVecEnv:
         # ---- weather tensor (shared by all envs) and the admissible episode start rows
         if weather is None:
             weather = synthetic_weather(dt=self.dt)
-        self.weather_data = np.ascontiguousarray(weather, dtype=np.float64)
+        self.weather_data = (weather.detach().double().cpu().numpy() if weather_is_tensor
+                             else np.ascontiguousarray(weather, dtype=np.float64))
         self.weather_rows = int(self.weather_data.shape[0])
         need = self.N + 1 + self.Np + 1
         if self.weather_rows < need:
@@ -211,7 +213,8 @@ class TomatoVecEnv:
 
         dev, T = self.device, self.tdtype
         z = lambda *s, dtype=T: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
-        self.weather_t = torch.as_tensor(self.weather_data, dtype=T, device=dev).contiguous()
+        self.weather_t = (weather.to(device=dev, dtype=T).contiguous() if weather_is_tensor
+                          else torch.as_tensor(self.weather_data, dtype=T, device=dev).contiguous())
         self.x_T, self.u_T = z(L.NX, self.ld), z(L.NU, self.ld)
         self.ctrl_T = z(L.NU, self.ld)
         self.info_T = z(L.NINFO, self.ld)

@@ -23,6 +23,7 @@
  *   glgym_crop_noise <- parametric_crop_uncertainty               gl_gym/environments/noise.py:3-23
  *   glgym_rule_based <- RuleBasedController.predict              gl_gym/environments/baseline.py:68-227
  *                     (constants gl_gym/configs/agents/rule_based.yml; caller experiments/evaluate_baseline.py:22)
+ *   glgym_weather  <- load_weather_data (array part)              gl_gym/environments/utils.py:48-125
  *   glgym_rhs      <- ODE(x,u,d,p) (test hook; no reference binding) gl_gym/environments/models/ode.hpp:6-124
  *
  * Layouts.  "SoA [n][ld]" = n planes of ld elements, element (i, b) at base[i*ld + b]; lane b of a
@@ -235,6 +236,30 @@ typedef struct {
 } glgym_vecnorm_args;
 
 int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* stream);
+
+/* ---- weather pipeline on the device -----------------------------------------------------------------------
+ * Replaces the array part of load_weather_data (gl_gym/environments/utils.py:48-125; called per reset at
+ * tomato_env.py:249-259): raw samples (the CSV columns, already sliced to the season window) -> vpOut / co2Out / tSoOut
+ * unit conversions (:281-444, :262-279), daily light sum (:216-250), daylight flags with their one-hour ramps (:177-214),
+ * PCHIP resample (scipy PchipInterpolator, Fritsch-Carlson slopes) onto linspace(time[0], time[n_raw-1], n_out), and the
+ * iGlob < 1e-10 -> 0 clean-up.  fp64 arithmetic, output in the handle's dtype, row-major [n_out][nd] -- the table
+ * glgym_step / glgym_obs / glgym_reset read.  Parsing the CSV stays with the caller. */
+typedef struct {
+    int32_t n_raw;             /* raw samples (>= 3), uniformly spaced in time */
+    const double* time;        /* [n_raw] device: seconds */
+    const double* i_glob;      /* [n_raw] device: global radiation [W m-2]      ("global radiation") */
+    const double* t_out;       /* [n_raw] device: outdoor temperature [C]       ("air temperature") */
+    const double* rh;          /* [n_raw] device: relative humidity [%]         ("RH") */
+    const double* wind;        /* [n_raw] device: wind speed [m s-1]            ("wind speed") */
+    const double* t_sky;       /* [n_raw] device: sky temperature [C]           ("sky temperature") */
+    double co2_ppm;            /* outdoor CO2 (the reference uses 400) */
+    int32_t n_out;             /* rows of the resampled table: int(dt_raw / dt_env * n_raw) */
+    int32_t nd;                /* row stride of out (>= 10; columns 10.. are zeroed) */
+    void* out;                 /* [n_out][nd] T device */
+    double* workspace;         /* [20 * n_raw] device scratch */
+} glgym_weather_args;
+
+int glgym_weather(glgym_handle h, const glgym_weather_args* a, void* stream);
 
 /* Kernel timing on the stream the kernels are launched on (bench.py's roofline leg). */
 int glgym_timer_start(glgym_handle h, void* stream);

@@ -103,6 +103,19 @@ def test_make_vec_env_from_reference_style_config(cfg_dir):
     assert done.all() and infos[0]["episode"]["l"] == 49                  # monitor entries survive the VecNormalize layer
     assert np.abs(infos[0]["terminal_observation"]).max() <= 10.0         # ... and terminal observations come normalised
     ev.close()
+    # weather_on_device=True: the same table from the device pipeline (glgym_weather), never materialised on the host
+    host_env = make_vec_env("TomatoEnv", base, spec, seed=666, n_envs=64, dtype="float64")
+    dev_env = make_vec_env("TomatoEnv", base, spec, seed=666, n_envs=64, dtype="float64", weather_on_device=True)
+    assert dev_env.weather_t.shape == host_env.weather_t.shape
+    sc = host_env.weather_t.abs().amax(dim=0).clamp_min(1e-30)
+    assert float(((dev_env.weather_t - host_env.weather_t).abs() / sc).max()) < 1e-12
+    oh, od = host_env.reset(), dev_env.reset()
+    np.testing.assert_allclose(od, oh, rtol=1e-6, atol=1e-6)
+    for _ in range(3):
+        rh_, rd_ = host_env.step(a[:64]), dev_env.step(a[:64])
+        np.testing.assert_allclose(rd_[0], rh_[0], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(rd_[1], rh_[1], rtol=0, atol=1e-9)
+    host_env.close(); dev_env.close()
 
 
 def test_vecnormalize_reads_sb3_written_pickles_without_sb3(tmp_path):
