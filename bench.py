@@ -10,8 +10,9 @@ A "step" is one batched TomatoEnv.step(): crop-noise-free control update, fused 
 independent environments resident in HBM.  Workload = BASELINE.json configs[2]: batch 65 536, fp32, one
 synthetic weather year (the Amsterdam KNMI files are not in the reference mount), random actions.
 Deviation from the config text: "RK4 with 4 sub-steps" diverges (stiff ODE, lambda_max ~ 0.67 1/s needs
->= 224 sub-steps, tests/test_gpu_parity.py::test_n_sub_4_is_unstable_and_flagged); n_sub = 320 is run -- the count at
-which the stability guard stays idle under sustained random actions.  The defaults time 2 000
+>= 224 sub-steps, tests/test_gpu_parity.py::test_n_sub_4_is_unstable_and_flagged); n_sub = 320 is run -- the NOMINAL count of
+the stability-controlled sub-stepper: environments whose local rate bound needs more take more, smaller sub-steps, and 320 is
+the count at which that stays rare under sustained random actions.  The defaults time 2 000
 steps so that `value` is the sustained rate, not the first milliseconds after a reset.  A second, informational leg
 times the library's explicit-midpoint sub-stepper on the same workload (`other_scheme`).
 
