@@ -320,6 +320,7 @@ template <class T> struct ObsArgsT {
     int Np; float* obs; double doy_inc, hod_inc;     // (dt/86400) mod 365 [days], dt/3600 [h] per env-step
     const unsigned char* mask; float* term_obs;
     int nd;                                          // weather row stride
+    int moff[6], dim;                                // first column of each observation module (-1 = absent), row width
 };
 
 // OBS_ROWS (16) consecutive env rows = one contiguous, 32-byte aligned span of the row-major output.  The span is
@@ -342,7 +343,7 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
     extern __shared__ float4 span4[];               // ROWS * dim floats (dynamic: 8.4 KB at Np = 48), 16-byte aligned
     float* span = reinterpret_cast<float*>(span4);
     const int tid = threadIdx.x;
-    const int dim = NCORE + 5 * a.Np;
+    const int dim = a.dim;
     const float kPpm = (float)(8.3144598 / (101325.0 * 44.01e-3));
     for (int rb = blockIdx.x * ROWS; rb < a.B; rb += gridDim.x * ROWS) {
         const int nrows = min(ROWS, a.B - rb);
@@ -394,10 +395,14 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
             v = (j == 2 || j == 15) ? rh : v;
             v = (j == 18) ? (float)k : v;
             v = (j > 18) ? clk : v;
-            if (r < nrows) span[r * dim + j] = v;
+            // column of feature j in the configured module order (TomatoEnv._get_obs concatenates the modules in
+            // the order of the yml list, tomato_env.py:193-198)
+            const int mo = j < 4 ? a.moff[0] : j < 7 ? a.moff[1] : j < 13 ? a.moff[2] : j < 18 ? a.moff[3] : a.moff[4];
+            const int jl = j < 4 ? j : j < 7 ? j - 4 : j < 13 ? j - 7 : j < 18 ? j - 13 : j - 18;
+            if (r < nrows && mo >= 0) span[r * dim + mo + jl] = v;
         }
         // raw forecast rows, no unit conversion (:175-182): element q of the block = weather[base+1 + q/5][q%5]
-        const int nf = 5 * a.Np;
+        const int nf = a.moff[5] >= 0 ? 5 * a.Np : 0;
         for (int q = tid; q < nf; q += 256) {
             const int i = q / 5, c = q - i * 5;              // division by a constant: mul + shift
             float v[ROWS];
@@ -409,7 +414,7 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
             }
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
-                if (r < nrows) span[r * dim + NCORE + q] = v[r];
+                if (r < nrows) span[r * dim + a.moff[5] + q] = v[r];
         }
         __syncthreads();
         float* out = a.obs + (size_t)rb * dim;
@@ -853,6 +858,8 @@ struct glgym_handle_s {
     int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
+    int obs_modules[6] = {0, 1, 2, 3, 4, 5};   // observation modules in output order (glgym_set_obs_modules)
+    int n_obs_modules = 6;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the host-pointer entry points
     double* scratch = nullptr;
@@ -1183,6 +1190,8 @@ extern "C" int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream
                                  : launch_step<double>(h, a, h->md, h->rd, st);
 }
 
+static const int OBS_MODULE_SIZE[6] = {4, 3, 6, 5, 5, 0};      // observations.py:64,84,102,123,143; forecast = 5 * Np (:168)
+
 template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a, hipStream_t st)
 {
     ObsArgsT<T> k;
@@ -1192,7 +1201,14 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
     int blocks = (a->B + OBS_ROWS - 1) / OBS_ROWS;   // OBS_ROWS env rows per block-iteration
     static const int cap = [] { const char* e = std::getenv("GLGYM_OBS_BLOCKS"); return e ? std::atoi(e) : 4096; }();
     if (blocks > cap) blocks = cap;              // grid-stride beyond that
-    const size_t lds = (size_t)OBS_ROWS * (OBS_NCORE + 5 * a->Np) * sizeof(float);
+    for (int m = 0; m < 6; ++m) k.moff[m] = -1;
+    k.dim = 0;
+    for (int i = 0; i < h->n_obs_modules; ++i) {
+        const int m = h->obs_modules[i];
+        k.moff[m] = k.dim;
+        k.dim += m == GLGYM_OBS_FORECAST ? 5 * a->Np : OBS_MODULE_SIZE[m];
+    }
+    const size_t lds = (size_t)OBS_ROWS * k.dim * sizeof(float);
     hipLaunchKernelGGL((obs_kernel<T>), dim3(blocks), dim3(256), lds, st, k);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
@@ -1299,6 +1315,31 @@ int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream)
     }
     hipStream_t st = (hipStream_t)stream;
     return h->dtype == GLGYM_F32 ? launch_obs<float>(h, a, st) : launch_obs<double>(h, a, st);
+}
+
+int glgym_set_obs_modules(glgym_handle h, const int32_t* modules, int n)
+{
+    if (!h || !modules || n < 1 || n > 6) { g_err = "glgym_set_obs_modules: 1..6 module ids expected"; return GLGYM_EINVAL; }
+    int seen = 0;
+    for (int i = 0; i < n; ++i) {
+        if (modules[i] < 0 || modules[i] > 5 || (seen >> modules[i] & 1)) {
+            g_err = "glgym_set_obs_modules: ids must be distinct GLGYM_OBS_* values";
+            return GLGYM_EINVAL;
+        }
+        seen |= 1 << modules[i];
+    }
+    for (int i = 0; i < n; ++i) h->obs_modules[i] = modules[i];
+    h->n_obs_modules = n;
+    return GLGYM_OK;
+}
+
+int glgym_obs_dim(glgym_handle h, int Np)
+{
+    if (!h || Np < 0 || Np > OBS_MAX_NP) return GLGYM_EINVAL;
+    int dim = 0;
+    for (int i = 0; i < h->n_obs_modules; ++i)
+        dim += h->obs_modules[i] == GLGYM_OBS_FORECAST ? 5 * Np : OBS_MODULE_SIZE[h->obs_modules[i]];
+    return dim;
 }
 
 int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)

@@ -122,6 +122,8 @@ PROTOTYPES = {
     "glgym_rhs": (C.c_int, [C.c_void_p, _DP, _DP, _DP, C.c_int, _DP]),
     "glgym_step": (C.c_int, [C.c_void_p, C.POINTER(StepArgs), C.c_void_p]),
     "glgym_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsArgs), C.c_void_p]),
+    "glgym_set_obs_modules": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
+    "glgym_obs_dim": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_reset": (C.c_int, [C.c_void_p, C.POINTER(ResetArgs), C.c_void_p]),
     "glgym_crop_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                                    C.c_void_p]),

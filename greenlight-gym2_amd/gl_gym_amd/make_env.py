@@ -67,9 +67,8 @@ def _check_supported(reward_function, observation_modules, base):
     if reward_function != "GreenhouseReward":
         raise NotImplementedError(f"reward_function {reward_function!r}: the step kernel implements GreenhouseReward "
                                   "(rewards.py:47-231) only")
-    if list(observation_modules) != OBSERVATION_MODULES:
-        raise NotImplementedError("observation_modules must be the reference's six modules in TomatoEnv.yml order: "
-                                  f"{OBSERVATION_MODULES} (layout of glgym_obs)")
+    from .tomato_env import observation_modules as _modules
+    _modules(0, observation_modules)      # any order / subset of the six live modules; raises for unknown names
     if (base.get("nx", 28), base.get("nu", 6), base.get("num_params", 208)) != (28, 6, 208) or not 10 <= base.get("nd", 10) <= 16:
         raise NotImplementedError("GreenLight sizes are nx=28, nu=6, nd=10..16, num_params=208")
     u_min, u_max = np.asarray(base.get("u_min", [0] * 6), float), np.asarray(base.get("u_max", [1] * 6), float)
@@ -107,7 +106,7 @@ def tomato_vec_env_from_config(n_envs: int, reward_function: str, observation_mo
         pipeline.close()
     env = TomatoVecEnv(n_envs, weather=table, dt=dt, season_length=season, pred_horizon=horizon, seed=seed,
                        start_rows=rows, start_days=sdays, reward_params=reward_params, constraints=constraints,
-                       uncertainty_scale=uncertainty_scale, **device_kw)
+                       uncertainty_scale=uncertainty_scale, observation_modules=list(observation_modules), **device_kw)
     env.training, env.eval_options = training, eval_options
     env.location, env.data_source, env.weather_data_dir = location, source, base["weather_data_dir"]
     env.train_years, env.train_days = years, days

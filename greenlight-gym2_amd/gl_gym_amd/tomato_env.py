@@ -69,6 +69,10 @@ def _torch():
     return torch
 
 
+def _observation_modules(Np, names):
+    return observation_modules(Np, names)
+
+
 class ObservationModule:
     """Descriptor of one of the reference's observation modules (observations.py:59-182): what the experiment manager
     reads through ``env.get_attr("observation_modules")`` (RL/experiment_manager.py:43-45).  The values themselves are
@@ -81,16 +85,33 @@ class ObservationModule:
         return f"{self.name}({self.n_obs})"
 
 
-def observation_modules(Np: int):
-    """The six modules in configs/envs/TomatoEnv.yml order = the column layout of glgym_obs."""
+OBSERVATION_MODULE_IDS = {"IndoorClimateObservations": 0, "BasicCropObservations": 1, "ControlObservations": 2,
+                          "WeatherObservations": 3, "TimeObservations": 4, "WeatherForecastObservations": 5}   # GLGYM_OBS_*
+DEFAULT_OBSERVATION_MODULES = ["IndoorClimateObservations", "BasicCropObservations", "ControlObservations",
+                               "WeatherObservations", "TimeObservations", "WeatherForecastObservations"]  # TomatoEnv.yml:25-32
+
+
+def observation_modules(Np: int, names: Optional[Sequence[str]] = None):
+    """Descriptors of the configured modules, in the order of the list = the column layout of glgym_obs
+    (tomato_env.py:77-81, 193-198).  Default: the six of configs/envs/TomatoEnv.yml."""
     wx = ["glob_rad", "temp_out", "rh_out", "co2_out", "wind_speed"]
-    return [ObservationModule("IndoorClimateObservations", ["co2_air", "temp_air", "rh_air", "pipe_temp"]),
-            ObservationModule("BasicCropObservations", ["24CanTemp", "cFruit", "tSum"]),
-            ObservationModule("ControlObservations", ["uBoil", "uCo2", "uThScr", "uVent", "uLamp", "uBlScr"], 0.0, 1.0),
-            ObservationModule("WeatherObservations", wx),
-            ObservationModule("TimeObservations", ["timestep", "day of year sin", "day of year cos", "hour of day sin",
-                                                   "hour of day cos"]),
-            ObservationModule("WeatherForecastObservations", wx * Np)]
+    table = {"IndoorClimateObservations": (["co2_air", "temp_air", "rh_air", "pipe_temp"],),
+             "BasicCropObservations": (["24CanTemp", "cFruit", "tSum"],),
+             "ControlObservations": (["uBoil", "uCo2", "uThScr", "uVent", "uLamp", "uBlScr"], 0.0, 1.0),
+             "WeatherObservations": (wx,),
+             "TimeObservations": (["timestep", "day of year sin", "day of year cos", "hour of day sin",
+                                   "hour of day cos"],),
+             "WeatherForecastObservations": (wx * Np,)}
+    names = DEFAULT_OBSERVATION_MODULES if names is None else list(names)
+    for n in names:
+        if n == "StateObservations":
+            raise NotImplementedError("StateObservations cannot be built by the reference's TomatoEnv either "
+                                      "(observations.py:42: __init__ takes no env) and returns random numbers (:57)")
+        if n not in table:
+            raise KeyError(f"unknown observation module {n!r}; known: {sorted(table)}")
+    if len(set(names)) != len(names) or not names:
+        raise ValueError("observation_modules must be a non-empty list without repeats")
+    return [ObservationModule(n, *table[n]) for n in names]
 
 
 class LazyInfos:
@@ -136,8 +157,10 @@ class TomatoVecEnv:
                  start_rows: Optional[Sequence[int]] = None, start_days: Optional[Sequence[float]] = None,
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
                  auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None,
-                 model_variant: str = "ode", scheme: str = "rk4"):
-        """scheme / n_sub: "rk4" (classical RK4, default n_sub 320) or "rk2" (explicit midpoint, default n_sub 376);
+                 model_variant: str = "ode", scheme: str = "rk4",
+                 observation_modules: Optional[Sequence[str]] = None):
+        """observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
+        scheme / n_sub: "rk4" (classical RK4, default n_sub 320) or "rk2" (explicit midpoint, default n_sub 376);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
@@ -161,7 +184,13 @@ class TomatoVecEnv:
         self.season_length = season_length
         self.N = int(season_length * self.c / self.dt)                     # base_env.py:88
         self.Np = int(pred_horizon * self.c / self.dt)                     # base_env.py:80
-        self.obs_dim = 23 + 5 * self.Np
+        self.observation_modules = _observation_modules(self.Np, observation_modules)
+        if self.observation_modules[0].name != "IndoorClimateObservations":
+            # GreenhouseReward reads its constraint inputs positionally, obs[[0, 1, 2]] = co2_air, temp_air, rh_air
+            # (rewards.py:192-194): with another module first the reference penalises whatever lands in those slots
+            raise NotImplementedError("observation_modules must start with IndoorClimateObservations: the reference's "
+                                      "GreenhouseReward takes co2 / temperature / humidity from obs[0:3]")
+        self.obs_dim = sum(m.n_obs for m in self.observation_modules)
         self.f64 = str(dtype) in ("float64", "f64", "double")
         self.tdtype = torch.float64 if self.f64 else torch.float32
         if scheme not in L.SCHEMES:
@@ -182,6 +211,9 @@ class TomatoVecEnv:
         if model_variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
+        ids = (C.c_int32 * len(self.observation_modules))(*[OBSERVATION_MODULE_IDS[m.name] for m in self.observation_modules])
+        L.check(self._lib.glgym_set_obs_modules(self._h, ids, len(ids)), "glgym_set_obs_modules")
+        assert self._lib.glgym_obs_dim(self._h, self.Np) == self.obs_dim
         rp = dict(DEFAULT_REWARD, **(reward_params or {}))
         cs = dict(DEFAULT_CONSTRAINTS, **(constraints or {}))
         self.reward_params, self.constraints = rp, cs
@@ -236,7 +268,6 @@ class TomatoVecEnv:
 
         # observation space = concatenation of the modules' bounds (tomato_env.py:83-95; the reference's lower bound
         # really is -1e-4)
-        self.observation_modules = observation_modules(self.Np)
         lo = np.concatenate([np.full(m.n_obs, m.low, np.float32) for m in self.observation_modules])
         hi = np.concatenate([np.full(m.n_obs, m.high, np.float32) for m in self.observation_modules])
         self.observation_space = _box(lo, hi, (self.obs_dim,), np.float32)
@@ -557,8 +588,9 @@ class TomatoEnv:
     def __init__(self, weather=None, params=None, dt=900.0, season_length=60, pred_horizon=0.5, dtype="float64",
                  n_sub=None, device="cuda:0", uncertainty_scale=0.0, start_day=0.0, growth_year=2010,
                  reward_params=None, constraints=None, location="synthetic", training=True, model_variant="ode",
-                 scheme="rk4"):
-        self.vec = TomatoVecEnv(1, model_variant=model_variant, scheme=scheme, weather=weather, params=params, dt=dt, season_length=season_length,
+                 scheme="rk4", observation_modules=None):
+        self.vec = TomatoVecEnv(1, model_variant=model_variant, scheme=scheme, observation_modules=observation_modules,
+                                weather=weather, params=params, dt=dt, season_length=season_length,
                                 pred_horizon=pred_horizon, dtype=dtype, n_sub=n_sub, device=device,
                                 uncertainty_scale=uncertainty_scale, start_rows=[0], start_days=[start_day],
                                 reward_params=reward_params, constraints=constraints, auto_reset=False)

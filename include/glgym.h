@@ -127,8 +127,8 @@ typedef struct {
     const int32_t* w_off;      /* [B] */
     const int32_t* timestep;   /* [B] value AFTER the step's increment; 0 = freshly reset env */
     const float* start_day;    /* [B] day of year at reset */
-    int32_t Np;                /* forecast rows (int(pred_horizon*86400/dt)); obs_dim = 23 + 5*Np */
-    float* obs;                /* [B][23 + 5*Np] row-major f32 out */
+    int32_t Np;                /* forecast rows (int(pred_horizon*86400/dt)); obs_dim = 23 + 5*Np with the default modules */
+    float* obs;                /* [B][glgym_obs_dim(h, Np)] row-major f32 out */
     const uint8_t* mask;       /* NULL: every row.  Else only rows with mask[b] != 0 are recomputed ...            */
     float* term_obs;           /* ... after their CURRENT content was saved here ([B][dim], SB3 "terminal_observation");
                                   may be NULL */
@@ -173,6 +173,20 @@ int glgym_get_reward_scale(glgym_handle h, double* max_profit, double* min_profi
 int glgym_evalF(glgym_handle h, const double* x, const double* u, const double* d, const double* p, int p_rows,
                 int B, double* x_next);
 int glgym_rhs(glgym_handle h, const double* x, const double* u, const double* d, int B, double* dx);
+
+/* Observation modules (gl_gym/environments/observations.py:59-182), concatenated per row in the order of
+ * TomatoEnv's `observation_modules` list (tomato_env.py:77-81, 193-198).  Default: all six in configs/envs/TomatoEnv.yml
+ * order.  glgym_set_obs_modules takes 1..6 distinct ids; glgym_obs_dim returns the resulting row width (< 0 on error).
+ * The reference's seventh entry, StateObservations (:35-57), cannot be constructed by TomatoEnv (its __init__ takes no env)
+ * and returns random numbers; it is not offered. */
+enum { GLGYM_OBS_INDOOR = 0,    /* IndoorClimateObservations  co2_air [ppm], temp_air, rh_air, pipe_temp          (4) */
+       GLGYM_OBS_CROP = 1,      /* BasicCropObservations      24CanTemp (x21), cFruit (x25), tSum (x26)            (3) */
+       GLGYM_OBS_CONTROL = 2,   /* ControlObservations        uBoil, uCo2, uThScr, uVent, uLamp, uBlScr            (6) */
+       GLGYM_OBS_WEATHER = 3,   /* WeatherObservations        glob_rad, temp_out, rh_out, co2_out [ppm], wind      (5) */
+       GLGYM_OBS_TIME = 4,      /* TimeObservations           timestep, sin/cos day of year, sin/cos hour of day   (5) */
+       GLGYM_OBS_FORECAST = 5   /* WeatherForecastObservations raw weather columns 0..4 of the next Np rows    (5 Np) */ };
+int glgym_set_obs_modules(glgym_handle h, const int32_t* modules, int n);
+int glgym_obs_dim(glgym_handle h, int Np);
 
 /* Device pointers; asynchronous on `stream` (a hipStream_t, NULL = default stream). */
 int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream);

@@ -123,7 +123,8 @@ class OracleTomatoEnv:
 
     def __init__(self, weather, p, season_length=60, start_day=59, growth_year=2010, dt=900.0,
                  pred_horizon=0.5, uncertainty_scale=0.0, integrator="rk4", n_sub=256, seed=None,
-                 train_years=(2010,), train_days=(59,), reward_params=None, constraints=None):
+                 train_years=(2010,), train_days=(59,), reward_params=None, constraints=None,
+                 observation_modules=None):
         self.c = 86400
         self.nx, self.nu, self.nd, self.num_params = 28, 6, 10, 208
         self.dt = dt
@@ -140,6 +141,10 @@ class OracleTomatoEnv:
         self.train_years, self.train_days = list(train_years), list(train_days)
         self.start_day, self.growth_year = start_day, growth_year
         self.seed = seed
+        # tomato_env.py:77-81: modules are concatenated in the order of the yml list
+        self.observation_modules = list(observation_modules or ["IndoorClimateObservations", "BasicCropObservations",
+                                                                "ControlObservations", "WeatherObservations",
+                                                                "TimeObservations", "WeatherForecastObservations"])
         c = constraints or {}
         lo = [c.get("co2_min", 300.0), c.get("temp_min", 15.0), c.get("rh_min", 50.0)]
         hi = [c.get("co2_max", 1600.0), c.get("temp_max", 34.0), c.get("rh_max", 85.0)]
@@ -228,4 +233,7 @@ class OracleTomatoEnv:
         tm = np.array([k, np.sin(2 * np.pi * self.day_of_year / 365.0), np.cos(2 * np.pi * self.day_of_year / 365.0),
                        np.sin(2 * np.pi * self.hour_of_day / 24.0), np.cos(2 * np.pi * self.hour_of_day / 24.0)])
         forecast = w[k + 1:k + 1 + self.Np, 0:5].reshape(-1)      # raw rows, no unit conversion
-        return np.concatenate([climate, crop, np.asarray(self.u, dtype=np.float64), weather, tm, forecast])
+        parts = {"IndoorClimateObservations": climate, "BasicCropObservations": crop,
+                 "ControlObservations": np.asarray(self.u, dtype=np.float64), "WeatherObservations": weather,
+                 "TimeObservations": tm, "WeatherForecastObservations": forecast}
+        return np.concatenate([parts[m] for m in self.observation_modules])        # tomato_env.py:193-198

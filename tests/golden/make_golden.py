@@ -419,7 +419,7 @@ def g_storm():
                         truth_kind=np.array(KIND), truth_agreement=np.array(AGREE), lam_max_start=LAM)
 
 
-def _reference_env(season_length=1, uncertainty_scale=0.0, training=True):
+def _reference_env(season_length=1, uncertainty_scale=0.0, training=True, observation_modules=None):
     """The reference's REAL TomatoEnv (gl_gym/environments/tomato_env.py, base_env.py, observations.py, rewards.py,
     noise.py, utils.py, parameters.py -- imported from /root/reference, nothing copied) with its two absent third-party
     dependencies substituted at import time:
@@ -461,6 +461,8 @@ def _reference_env(season_length=1, uncertainty_scale=0.0, training=True):
     base.update(weather_data_dir=WEATHER_DIR, location="Bleiswijk", data_source="GL", season_length=season_length,
                 start_train_year=2009, end_train_year=2009, start_train_day=0, end_train_day=0, training=training)
     spec["eval_options"] = dict(eval_days=[0], eval_years=[2009], location="Bleiswijk", data_source="GL")
+    if observation_modules is not None:
+        spec["observation_modules"] = list(observation_modules)
     env = TomatoEnv(base_env_params=base, uncertainty_scale=uncertainty_scale, **spec)
     return env, base, spec
 
@@ -517,7 +519,44 @@ def g_refenv():
     np.savez_compressed(HERE / "refenv_1day.npz", info_keys=np.array(INFO), **out)
 
 
-ALL = dict(refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+def g_refobs():
+    """G3b: the reference's TomatoEnv built with OTHER observation-module lists (tomato_env.py:77-81 concatenates the
+    modules in list order).  Observations are a function of (x, u, weather, clocks) only, so the env is teacher-forced
+    from the recorded rule-based episode of refenv_1day.npz at a few steps and _get_obs() (tomato_env.py:193-198) is
+    read: no integration involved.  Per layout: names, Box bounds, the observation rows."""
+    g = np.load(HERE / "refenv_1day.npz")
+    X, U, DOY, HOD = g["rb_x"], g["rb_u"], g["rb_doy"], g["rb_hod"]
+    ks = np.array([0, 1, 7, 40, 95, 96])
+    layouts = [["IndoorClimateObservations", "WeatherForecastObservations", "TimeObservations", "ControlObservations"],
+               ["IndoorClimateObservations", "TimeObservations", "WeatherObservations", "BasicCropObservations",
+                "ControlObservations", "WeatherForecastObservations"],
+               ["IndoorClimateObservations", "BasicCropObservations"]]
+    out = dict(k=ks)
+    for i, mods in enumerate(layouts):
+        env, _, _ = _reference_env(season_length=1, observation_modules=mods)
+        env.reset(seed=666)
+        assert np.array_equal(env.weather_data, g["weather"])
+        rows = []
+        for k in ks:
+            env.x = np.array(X[k]); env.u = np.array(U[k - 1]) if k > 0 else np.zeros(6)
+            env.timestep, env.day_of_year, env.hour_of_day = max(int(k) - 1, 0), float(DOY[k]), float(HOD[k])   # obs precede `timestep += 1` (tomato_env.py:130-138)
+            rows.append(np.asarray(env._get_obs(), dtype=np.float64))
+        out[f"l{i}_modules"] = np.array(mods)
+        out[f"l{i}_obs"] = np.array(rows)
+        out[f"l{i}_names"] = np.array(env.get_obs_names())
+        out[f"l{i}_low"], out[f"l{i}_high"] = env.observation_space.low, env.observation_space.high
+        print("layout", i, mods, "->", out[f"l{i}_obs"].shape)
+    # the default list must reproduce the recorded observations (checks the teacher forcing itself)
+    env, _, _ = _reference_env(season_length=1)
+    env.reset(seed=666)
+    for k in ks:
+        env.x = np.array(X[k]); env.u = np.array(U[k - 1]) if k > 0 else np.zeros(6)
+        env.timestep, env.day_of_year, env.hour_of_day = max(int(k) - 1, 0), float(DOY[k]), float(HOD[k])   # obs precede `timestep += 1` (tomato_env.py:130-138)
+        assert np.array_equal(np.asarray(env._get_obs(), dtype=np.float64), g["rb_obs"][k]), k
+    np.savez_compressed(HERE / "refenv_obs_layouts.npz", n_layouts=len(layouts), **out)
+
+
+ALL = dict(refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

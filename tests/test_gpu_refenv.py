@@ -58,3 +58,54 @@ def test_step_obs_reward_info_against_reference_env(golden, tag, dtype):
     assert np.max(np.abs(info_gpu[:, 7:11] - INFO[:, 7:11]) / viol_sc) < 2e-4
     print(f"refenv {tag} {dtype}: state {e_x:.2e}, reward {np.max(np.abs(r - R)):.2e}")
     env.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_observation_module_layouts_against_reference_env(golden, dtype):
+    """G3b: obs_kernel with other observation-module lists (glgym_set_obs_modules) against the reference's TomatoEnv built
+    with the same lists; teacher-forced from the rule-based episode, so no integration error is involved.  Also the masked
+    (auto-reset) path of the kernel with a non-default row width, and the boundary's argument checks."""
+    import ctypes as C
+    import torch
+    from gl_gym_amd import _lib as L
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g, e = golden("refenv_obs_layouts"), golden("refenv_1day")
+    X, U, ks = e["rb_x"], e["rb_u"], g["k"]
+    B = len(ks)
+    for i in range(int(g["n_layouts"])):
+        mods = [str(m) for m in g[f"l{i}_modules"]]
+        ref = g[f"l{i}_obs"]
+        env = TomatoVecEnv(B, weather=e["weather"], params=e["p"], dtype=dtype, season_length=1, pred_horizon=0.5,
+                           start_rows=[0], start_days=[0.0], auto_reset=False, observation_modules=mods)
+        env.reset()
+        assert env.obs_dim == ref.shape[1] == env.observation_space.shape[0]
+        assert env.get_obs_names() == [str(n) for n in g[f"l{i}_names"]]
+        np.testing.assert_array_equal(env.observation_space.low, g[f"l{i}_low"])
+        np.testing.assert_array_equal(env.observation_space.high, g[f"l{i}_high"])
+        dev, T = env.device, env.tdtype
+        env.x.copy_(torch.as_tensor(X[ks], dtype=T, device=dev))
+        env.u.copy_(torch.as_tensor(np.array([U[k - 1] if k > 0 else np.zeros(6) for k in ks]), dtype=T, device=dev))
+        env.timestep_t.copy_(torch.as_tensor(ks, dtype=torch.int32, device=dev))   # value after the step's increment
+        env._launch_obs(env.obs_t)
+        obs = env.obs_t.cpu().numpy()
+        np.testing.assert_allclose(obs, ref, rtol=3e-6, atol=3e-6)               # float32 observation block
+        # masked mode: only row 2 is recomputed, its previous content goes to term_obs
+        env.obs_t.fill_(-7.0)
+        mask = torch.zeros(B, dtype=torch.uint8, device=dev); mask[2] = 1
+        env._launch_obs(env.obs_t, mask, env.term_obs_t)
+        got, term = env.obs_t.cpu().numpy(), env.term_obs_t.cpu().numpy()
+        np.testing.assert_allclose(got[2], ref[2], rtol=3e-6, atol=3e-6)
+        assert (np.delete(got, 2, axis=0) == -7.0).all() and (term[2] == -7.0).all()
+        env.close()
+    env = TomatoVecEnv(4, weather=e["weather"], dtype=dtype, season_length=1, auto_reset=False)
+    lib, h = env._lib, env._h
+    assert lib.glgym_obs_dim(h, env.Np) == 263 and lib.glgym_obs_dim(h, 0) == 23 and lib.glgym_obs_dim(h, 129) == L.EINVAL
+    for bad in ([], [0, 0], [6], [0, -1], [0, 1, 2, 3, 4, 5, 0]):
+        arr = (C.c_int32 * max(len(bad), 1))(*bad)
+        assert lib.glgym_set_obs_modules(h, arr, len(bad)) == L.EINVAL, bad
+    assert lib.glgym_obs_dim(h, env.Np) == 263                                   # a refused call changes nothing
+    env.close()
+    with pytest.raises(NotImplementedError):       # GreenhouseReward reads obs[0:3] positionally (rewards.py:192-194)
+        TomatoVecEnv(4, weather=e["weather"], observation_modules=["TimeObservations", "IndoorClimateObservations"])
+    with pytest.raises(NotImplementedError):
+        TomatoVecEnv(4, weather=e["weather"], observation_modules=["IndoorClimateObservations", "StateObservations"])

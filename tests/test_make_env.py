@@ -40,8 +40,12 @@ def test_load_env_params_and_season_table(cfg_dir):
     # unsupported configurations are refused, not approximated
     with pytest.raises(NotImplementedError):
         _check_supported("SomeOtherReward", OBSERVATION_MODULES, base)
-    with pytest.raises(NotImplementedError):
-        _check_supported("GreenhouseReward", OBSERVATION_MODULES[:-1], base)
+    _check_supported("GreenhouseReward", OBSERVATION_MODULES[:-1], base)           # subsets / other orders are laid out
+    _check_supported("GreenhouseReward", OBSERVATION_MODULES[:1] + OBSERVATION_MODULES[:0:-1], base)
+    with pytest.raises(KeyError):
+        _check_supported("GreenhouseReward", ["IndoorClimateObservations", "NoSuchObservations"], base)
+    with pytest.raises(NotImplementedError):       # the reference cannot construct it either (observations.py:42)
+        _check_supported("GreenhouseReward", ["IndoorClimateObservations", "StateObservations"], base)
     with pytest.raises(NotImplementedError):
         _check_supported("GreenhouseReward", OBSERVATION_MODULES, dict(base, delta_u_max=0.2))
 

@@ -223,3 +223,25 @@ def test_observation_space_and_names_match_the_reference(golden):
     hi = np.concatenate([np.full(m.n_obs, m.high, np.float32) for m in mods])
     np.testing.assert_array_equal(lo, g["obs_low"])
     np.testing.assert_array_equal(hi, g["obs_high"])
+
+
+def test_env_oracle_observation_module_layouts_against_reference(golden):
+    """G3b: the reference's TomatoEnv built with other observation-module lists (tests/golden/make_golden.py g_refobs);
+    the oracle env and the host descriptors (names, Box bounds) must follow the list order (tomato_env.py:77-95, 193-207)."""
+    from oracle.gl_env_oracle import OracleTomatoEnv
+    from gl_gym_amd.tomato_env import observation_modules
+    g, e = golden("refenv_obs_layouts"), golden("refenv_1day")
+    X, U, DOY, HOD = e["rb_x"], e["rb_u"], e["rb_doy"], e["rb_hod"]
+    for i in range(int(g["n_layouts"])):
+        mods = [str(m) for m in g[f"l{i}_modules"]]
+        env = OracleTomatoEnv(weather=e["weather"], p=e["p"], season_length=1, start_day=0, seed=666, train_years=[2009],
+                              train_days=[0], observation_modules=mods)
+        env.reset()
+        for row, k in zip(g[f"l{i}_obs"], g["k"]):
+            env.x, env.u = X[k].copy(), (U[k - 1].copy() if k > 0 else np.zeros(6))
+            env.timestep, env.day_of_year, env.hour_of_day = max(int(k) - 1, 0), float(DOY[k]), float(HOD[k])
+            np.testing.assert_allclose(env._get_obs(), row, rtol=1e-12, atol=1e-12)
+        desc = observation_modules(int(e["Np"]), mods)
+        assert [n for m in desc for n in m.obs_names] == [str(n) for n in g[f"l{i}_names"]]
+        np.testing.assert_array_equal(np.concatenate([np.full(m.n_obs, m.low, np.float32) for m in desc]), g[f"l{i}_low"])
+        np.testing.assert_array_equal(np.concatenate([np.full(m.n_obs, m.high, np.float32) for m in desc]), g[f"l{i}_high"])
