@@ -106,6 +106,7 @@ template <class T> struct StepArgsT {
     T dt; int n_sub;
     T gasR, tCanMin;
     int nd;                     // weather row stride (10, or 14 with the measured-pipe columns of ODE_pipe)
+    float du, u_min[NU], u_max[NU];      // action_to_control: clip(u + action * delta_u_max, u_min, u_max)
 };
 
 template <class T> __device__ __forceinline__ T wave_sum(T v)
@@ -165,9 +166,9 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         const int l = live ? lane : (a.B - 1 - b0);
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
-            const float inc = sh_act[l * NU + j] * 0.1f;                     // f32 product, as tomato_env.py:113
+            const float inc = sh_act[l * NU + j] * a.du;                     // f32 product, as tomato_env.py:113
             const T v = a.u[(size_t)j * a.ld + bb] + T(inc);
-            u[j] = Math<T>::min(Math<T>::max(v, T(0)), T(1));
+            u[j] = Math<T>::min(Math<T>::max(v, T(a.u_min[j])), T(a.u_max[j]));
         }
     } else {
 #pragma unroll
@@ -204,10 +205,17 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         s.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
         s.tPipeSet = tPipe;
     }
+    // the applied control is final here (self.u is set before evalF and survives a failed integration, tomato_env.py:117-123):
+    // store it now and re-read the three entries the reward needs afterwards, so that no u[] stays live across the integrator
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
+    }
     T del[NX];
     bool bad;
     int extra_steps;
     const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps);
+    const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         viol[i] = Math<T>::max(rw.lo[i] - o3[i], T(0)) + Math<T>::max(o3[i] - rw.hi[i], T(0));
         pen += viol[i] * rw.invMaxViol[i];
     }
-    const T heat = u[0] * rw.heatK, elec = u[4] * rw.elecK, co2c = u[1] * rw.co2K;
+    const T heat = uBoil * rw.heatK, elec = uLamp * rw.elecK, co2c = uCo2 * rw.co2K;
     const T varc = heat + co2c + elec;
     const T gains = (bad ? T(0) : del[25]) * rw.gainK;
     const T profit = gains - varc;
@@ -241,8 +249,6 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
     if (live) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) a.x[(size_t)i * a.ld + b] = x1[i];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
         a.timestep[b] = ts + 1;
         a.reward[b] = reward;
         a.done[b] = term ? 1 : 0;
@@ -858,6 +864,7 @@ struct glgym_handle_s {
     int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
+    float du = 0.1f, u_min[NU] = {0, 0, 0, 0, 0, 0}, u_max[NU] = {1, 1, 1, 1, 1, 1};   // glgym_set_control_limits
     int obs_modules[6] = {0, 1, 2, 3, 4, 5};   // observation modules in output order (glgym_set_obs_modules)
     int n_obs_modules = 6;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -975,6 +982,16 @@ int glgym_set_scheme(glgym_handle h, int scheme)
         return GLGYM_EINVAL;
     }
     h->scheme = scheme;
+    return GLGYM_OK;
+}
+
+int glgym_set_control_limits(glgym_handle h, const double* u_min, const double* u_max, double delta_u_max)
+{
+    if (!h || !u_min || !u_max || !(delta_u_max >= 0)) { g_err = "glgym_set_control_limits: bad arguments"; return GLGYM_EINVAL; }
+    for (int j = 0; j < NU; ++j)
+        if (!(u_min[j] <= u_max[j])) { g_err = "glgym_set_control_limits: u_min > u_max"; return GLGYM_EINVAL; }
+    for (int j = 0; j < NU; ++j) { h->u_min[j] = (float)u_min[j]; h->u_max[j] = (float)u_max[j]; }    // float32 arrays,
+    h->du = (float)delta_u_max;                                                                       // base_env.py:72-74
     return GLGYM_OK;
 }
 
@@ -1132,6 +1149,8 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     k.w_off = a->w_off; k.timestep = a->timestep; k.crop_p = (const T*)a->crop_p; k.N = a->N;
     k.reward = (T*)a->reward; k.info = (T*)a->info; k.done = a->done; k.metrics = a->metrics;
     k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]); k.nd = h->nd;
+    k.du = h->du;
+    for (int j = 0; j < NU; ++j) { k.u_min[j] = h->u_min[j]; k.u_max[j] = h->u_max[j]; }
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
     if (h->variant == GLGYM_ODE_PIPE) {
         if (a->crop_p || h->scheme != GLGYM_SCHEME_RK4) {

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "glgym_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsArgs), C.c_void_p]),
     "glgym_set_obs_modules": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "glgym_obs_dim": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_control_limits": (C.c_int, [C.c_void_p, _DP, _DP, C.c_double]),
     "glgym_reset": (C.c_int, [C.c_void_p, C.POINTER(ResetArgs), C.c_void_p]),
     "glgym_crop_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                                    C.c_void_p]),

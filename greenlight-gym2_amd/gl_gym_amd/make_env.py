@@ -13,9 +13,9 @@ What changes versus the reference: every (growth_year, start_day) the env may dr
 into one weather table resident in HBM, and an episode start becomes a row offset drawn on the device by
 ``glgym_reset``.  The reference re-reads and re-samples the CSV in every env at every reset.
 
-The kernels implement exactly the configuration the reference ships (configs/envs/TomatoEnv.yml): GreenhouseReward, the
-six observation modules in their yml order, controls in [0, 1] with delta_u_max = 0.1.  Anything else is refused with
-NotImplementedError instead of being silently approximated.
+The kernels implement the reference's GreenhouseReward, any list of its six live observation modules that starts with
+IndoorClimateObservations (the reward reads obs[0:3]), and the yml's control limits (u_min, u_max, delta_u_max).  Anything
+else (another reward class, other model sizes) is refused with NotImplementedError instead of being silently approximated.
 """
 from __future__ import annotations
 
@@ -72,8 +72,8 @@ def _check_supported(reward_function, observation_modules, base):
     if (base.get("nx", 28), base.get("nu", 6), base.get("num_params", 208)) != (28, 6, 208) or not 10 <= base.get("nd", 10) <= 16:
         raise NotImplementedError("GreenLight sizes are nx=28, nu=6, nd=10..16, num_params=208")
     u_min, u_max = np.asarray(base.get("u_min", [0] * 6), float), np.asarray(base.get("u_max", [1] * 6), float)
-    if np.any(u_min != 0) or np.any(u_max != 1) or np.float32(base.get("delta_u_max", 0.1)) != np.float32(0.1):
-        raise NotImplementedError("the step kernel clips controls to [0, 1] with delta_u_max = 0.1 (TomatoEnv.yml:12-14)")
+    if u_min.shape != (6,) or u_max.shape != (6,) or np.any(u_min > u_max) or not float(base.get("delta_u_max", 0.1)) >= 0:
+        raise ValueError("u_min / u_max need 6 entries with u_min <= u_max, delta_u_max >= 0")
 
 
 def tomato_vec_env_from_config(n_envs: int, reward_function: str, observation_modules: List[str],
@@ -106,7 +106,8 @@ def tomato_vec_env_from_config(n_envs: int, reward_function: str, observation_mo
         pipeline.close()
     env = TomatoVecEnv(n_envs, weather=table, dt=dt, season_length=season, pred_horizon=horizon, seed=seed,
                        start_rows=rows, start_days=sdays, reward_params=reward_params, constraints=constraints,
-                       uncertainty_scale=uncertainty_scale, observation_modules=list(observation_modules), **device_kw)
+                       uncertainty_scale=uncertainty_scale, observation_modules=list(observation_modules),
+                       u_min=base.get("u_min"), u_max=base.get("u_max"), delta_u_max=base.get("delta_u_max", 0.1), **device_kw)
     env.training, env.eval_options = training, eval_options
     env.location, env.data_source, env.weather_data_dir = location, source, base["weather_data_dir"]
     env.train_years, env.train_days = years, days

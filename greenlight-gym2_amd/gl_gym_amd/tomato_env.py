@@ -158,8 +158,10 @@ class TomatoVecEnv:
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
                  auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None,
                  model_variant: str = "ode", scheme: str = "rk4",
-                 observation_modules: Optional[Sequence[str]] = None):
-        """observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
+                 observation_modules: Optional[Sequence[str]] = None, u_min: Optional[Sequence[float]] = None,
+                 u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
+        """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
+        observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
         scheme / n_sub: "rk4" (classical RK4, default n_sub 320) or "rk2" (explicit midpoint, default n_sub 376);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
@@ -211,6 +213,14 @@ class TomatoVecEnv:
         if model_variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
+        self.u_min = np.asarray([0.0] * L.NU if u_min is None else u_min, dtype=np.float32)            # base_env.py:72-74
+        self.u_max = np.asarray([1.0] * L.NU if u_max is None else u_max, dtype=np.float32)
+        self.delta_u_max = np.ones(L.NU, dtype=np.float32) * np.float32(delta_u_max)
+        if self.u_min.shape != (L.NU,) or self.u_max.shape != (L.NU,):
+            raise ValueError("u_min / u_max must have 6 entries")
+        lo64, hi64 = self.u_min.astype(np.float64), self.u_max.astype(np.float64)
+        L.check(self._lib.glgym_set_control_limits(self._h, lo64.ctypes.data_as(L._DP), hi64.ctypes.data_as(L._DP),
+                                                   float(delta_u_max)), "glgym_set_control_limits")
         ids = (C.c_int32 * len(self.observation_modules))(*[OBSERVATION_MODULE_IDS[m.name] for m in self.observation_modules])
         L.check(self._lib.glgym_set_obs_modules(self._h, ids, len(ids)), "glgym_set_obs_modules")
         assert self._lib.glgym_obs_dim(self._h, self.Np) == self.obs_dim
@@ -588,8 +598,9 @@ class TomatoEnv:
     def __init__(self, weather=None, params=None, dt=900.0, season_length=60, pred_horizon=0.5, dtype="float64",
                  n_sub=None, device="cuda:0", uncertainty_scale=0.0, start_day=0.0, growth_year=2010,
                  reward_params=None, constraints=None, location="synthetic", training=True, model_variant="ode",
-                 scheme="rk4", observation_modules=None):
+                 scheme="rk4", observation_modules=None, u_min=None, u_max=None, delta_u_max=0.1):
         self.vec = TomatoVecEnv(1, model_variant=model_variant, scheme=scheme, observation_modules=observation_modules,
+                                u_min=u_min, u_max=u_max, delta_u_max=delta_u_max,
                                 weather=weather, params=params, dt=dt, season_length=season_length,
                                 pred_horizon=pred_horizon, dtype=dtype, n_sub=n_sub, device=device,
                                 uncertainty_scale=uncertainty_scale, start_rows=[0], start_days=[start_day],
@@ -600,8 +611,7 @@ class TomatoEnv:
         self.weather_data = v.weather_data
         self.observation_space, self.action_space = v.observation_space, v.action_space
         self.start_day, self.growth_year, self.location, self.training = start_day, growth_year, location, training
-        self.u_min, self.u_max = np.zeros(6, np.float32), np.ones(6, np.float32)
-        self.delta_u_max = np.ones(6, np.float32) * 0.1
+        self.u_min, self.u_max, self.delta_u_max = v.u_min, v.u_max, v.delta_u_max
         self.terminated = False
 
     x = property(lambda self: self.vec.x[0].double().cpu().numpy())

@@ -165,6 +165,10 @@ int glgym_destroy(glgym_handle h);
 int glgym_set_params(glgym_handle h, const double* p);
 int glgym_set_n_sub(glgym_handle h, int n_sub);
 int glgym_set_scheme(glgym_handle h, int scheme);            /* GLGYM_SCHEME_RK4 (default) | GLGYM_SCHEME_RK2 */
+/* action_to_control (tomato_env.py:109-113): u = clip(u_prev + action * delta_u_max, u_min, u_max), held in float32 like
+ * base_env.py:72-74.  Default: the yml's [0, 1] bounds and 0.1 (configs/envs/TomatoEnv.yml:12-14).  The `control` input
+ * of glgym_step (step_raw_control) is applied unclipped, as the reference does (tomato_env.py:148-149). */
+int glgym_set_control_limits(glgym_handle h, const double* u_min /*[6]*/, const double* u_max /*[6]*/, double delta_u_max);
 int glgym_set_model_variant(glgym_handle h, int variant);   /* GLGYM_ODE_PIPE needs a handle created with nd >= 14 */
 int glgym_set_reward(glgym_handle h, const glgym_reward_cfg* cfg);
 int glgym_get_reward_scale(glgym_handle h, double* max_profit, double* min_profit, double* fixed_costs);

@@ -124,13 +124,13 @@ class OracleTomatoEnv:
     def __init__(self, weather, p, season_length=60, start_day=59, growth_year=2010, dt=900.0,
                  pred_horizon=0.5, uncertainty_scale=0.0, integrator="rk4", n_sub=256, seed=None,
                  train_years=(2010,), train_days=(59,), reward_params=None, constraints=None,
-                 observation_modules=None):
+                 observation_modules=None, u_min=None, u_max=None, delta_u_max=0.1):
         self.c = 86400
         self.nx, self.nu, self.nd, self.num_params = 28, 6, 10, 208
         self.dt = dt
-        self.u_min = np.zeros(6, dtype=np.float32)                 # base_env.py:72-74
-        self.u_max = np.ones(6, dtype=np.float32)
-        self.delta_u_max = np.ones(6, dtype=np.float32) * 0.1
+        self.u_min = np.array([0.0] * 6 if u_min is None else u_min, dtype=np.float32)       # base_env.py:72-74
+        self.u_max = np.array([1.0] * 6 if u_max is None else u_max, dtype=np.float32)
+        self.delta_u_max = np.ones(6, dtype=np.float32) * delta_u_max
         self.Np = int(pred_horizon * self.c / dt)                  # base_env.py:80
         self.N = int(season_length * self.c / dt)                  # base_env.py:88
         self.weather_data = np.asarray(weather, dtype=np.float64)

@@ -553,6 +553,30 @@ def g_refobs():
         env.x = np.array(X[k]); env.u = np.array(U[k - 1]) if k > 0 else np.zeros(6)
         env.timestep, env.day_of_year, env.hour_of_day = max(int(k) - 1, 0), float(DOY[k]), float(HOD[k])   # obs precede `timestep += 1` (tomato_env.py:130-138)
         assert np.array_equal(np.asarray(env._get_obs(), dtype=np.float64), g["rb_obs"][k]), k
+    # action_to_control (tomato_env.py:109-113) of a reference env built with OTHER control limits (base_env.py:72-74),
+    # teacher-forced on random (previous control, action) pairs: a pure function, no integration
+    import yaml
+    from gl_gym.environments.tomato_env import TomatoEnv
+    with open("/root/reference/gl_gym/configs/envs/TomatoEnv.yml") as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    base, spec = cfg["GreenLightEnv"], cfg["TomatoEnv"]
+    lim = dict(u_min=[0.0, 0.1, 0.0, 0.05, 0.0, 0.2], u_max=[0.8, 1.0, 0.5, 1.0, 1.0, 0.9], delta_u_max=0.25)
+    base.update(weather_data_dir=WEATHER_DIR, location="Bleiswijk", data_source="GL", season_length=1, start_train_year=2009,
+                end_train_year=2009, start_train_day=0, end_train_day=0, training=True, **lim)
+    env = TomatoEnv(base_env_params=base, uncertainty_scale=0.0, **spec)
+    env.reset(seed=1)
+    rng = np.random.default_rng(11)
+    u_prev = rng.uniform(np.array(lim["u_min"]), np.array(lim["u_max"]), (64, 6)).astype(np.float32)
+    act = rng.uniform(-1, 1, (64, 6)).astype(np.float32)
+    u_next = []
+    for a, b in zip(u_prev, act):
+        env.u = a.copy()
+        u_next.append(env.action_to_control(b))
+    u_next = np.array(u_next)
+    assert u_next.dtype == np.float32
+    out.update(ctl_u_min=np.array(lim["u_min"]), ctl_u_max=np.array(lim["u_max"]), ctl_delta_u_max=lim["delta_u_max"],
+               ctl_u_prev=u_prev, ctl_action=act, ctl_u=u_next)
+    print("control limits: clipped low/high", int((u_next == env.u_min).sum()), int((u_next == env.u_max).sum()))
     np.savez_compressed(HERE / "refenv_obs_layouts.npz", n_layouts=len(layouts), **out)
 
 

@@ -505,3 +505,53 @@ def test_default_n_sub_scales_with_dt(golden, oracle):
                 ref = oracle.rk4_split(X[i], U[i], D[i], P[i], dt, 8192)
                 assert float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), scale))) < 5e-5, (dt, dtype, i)
             m.close()
+
+
+@pytest.mark.parametrize("scheme", ["rk4", "rk2"])
+def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
+    """From B = 4 x SIMDs x 64 = 262 144 on, float32 default-parameter launches take the `__launch_bounds__(64, 2)` build of
+    step_kernel (256 registers, the rest spilled to scratch).  Same source, other register allocation: its results must
+    equal those of the one-wave build (B = 4 096 takes it) environment by environment, over several steps with
+    observations, auto-reset bookkeeping and metrics."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.utils import synthetic_weather
+    w = synthetic_weather(n_rows=4000)
+    starts = list(range(0, 2000, 37))
+    Bs, Bl = 4096, 262144
+    small = TomatoVecEnv(Bs, weather=w, dtype="float32", scheme=scheme, season_length=1, start_rows=starts, seed=5,
+                         auto_reset=False)
+    large = TomatoVecEnv(Bl, weather=w, dtype="float32", scheme=scheme, season_length=1, start_rows=starts, seed=5,
+                         auto_reset=False)
+    small.reset(); large.reset()
+    # the large batch = 64 copies of the small one (same start rows, states and actions per copy)
+    rep = Bl // Bs
+    large.w_off_t.copy_(small.w_off_t.repeat(rep)); large.start_day_t.copy_(small.start_day_t.repeat(rep))
+    large.x_T[:, :Bl] = small.x_T[:, :Bs].repeat(1, rep); large.u_T[:, :Bl] = small.u_T[:, :Bs].repeat(1, rep)
+    g = torch.Generator(device=small.device); g.manual_seed(3)
+    worst = 0.0
+    for k in range(4):
+        a = torch.rand(Bs, 6, generator=g, device=small.device) * 2 - 1
+        o_s, r_s, d_s, i_s = small.step_tensor(a)
+        o_l, r_l, d_l, i_l = large.step_tensor(a.repeat(rep, 1))
+        # column-scaled differences (conftest.scaled_err's metric): rounding-level, the two builds order a few float32
+        # operations differently; measured 2e-7 ... 1e-6, against 1e-5 ... 2e-5 of either build to the float64 kernel
+        # (reward and the profit entries of info are differences that pass through zero: scaled by the column maximum)
+        for name, got, ref, env_major, floor in (("x", large.x_T[:, :Bl], small.x_T[:, :Bs].repeat(1, rep), False, 1e-3),
+                                                 ("u", large.u_T[:, :Bl], small.u_T[:, :Bs].repeat(1, rep), False, 1e-3),
+                                                 ("reward", r_l[None, :], r_s.repeat(rep)[None, :], False, 1.0),
+                                                 ("info", i_l[:, :Bl], i_s[:, :Bs].repeat(1, rep), False, 1.0),
+                                                 ("obs", o_l, o_s.repeat(rep, 1), True, 1e-3)):
+            assert torch.isfinite(got).all()
+            dim = 0 if env_major else 1
+            scale = torch.maximum(ref.abs(), floor * ref.abs().amax(dim=dim, keepdim=True)).clamp_min(1e-30)
+            err = float(((got - ref).abs() / scale).max())
+            worst = max(worst, err)
+            assert err < 5e-6, (name, k, err)
+        assert torch.equal(large.x_T[:, :Bs], large.x_T[:, Bl - Bs:Bl])            # copies agree bit for bit
+        assert torch.equal(d_l, d_s.repeat(rep))
+    ms, ml = small.metrics(), large.metrics()
+    assert ml["n_env_steps"] == rep * ms["n_env_steps"] and ml["n_ode_fail"] == 0
+    assert abs(ml["sum_reward"] - rep * ms["sum_reward"]) < 1e-4 * abs(rep * ms["sum_reward"]) + 1.0
+    print(f"occupancy-2 build vs occupancy-1 build ({scheme}): worst relative difference {worst:.1e}")
+    small.close(); large.close()

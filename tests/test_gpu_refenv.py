@@ -109,3 +109,32 @@ def test_observation_module_layouts_against_reference_env(golden, dtype):
         TomatoVecEnv(4, weather=e["weather"], observation_modules=["TimeObservations", "IndoorClimateObservations"])
     with pytest.raises(NotImplementedError):
         TomatoVecEnv(4, weather=e["weather"], observation_modules=["IndoorClimateObservations", "StateObservations"])
+
+
+@pytest.mark.parametrize("dtype,atol", [("float32", 0.0), ("float64", 1.2e-7)])
+def test_control_limits_against_reference_env(golden, dtype, atol):
+    """glgym_set_control_limits: u = clip(u_prev + action * delta_u_max, u_min, u_max) against the reference env built with
+    other limits (fixture refenv_obs_layouts.npz, 64 teacher-forced pairs).  float32 handles reproduce the reference's float32
+    arithmetic bit for bit; float64 handles keep the unrounded sum (<= 1 float32 ulp away)."""
+    import ctypes as C
+    import torch
+    from gl_gym_amd import _lib as L
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g, e = golden("refenv_obs_layouts"), golden("refenv_1day")
+    B = len(g["ctl_u"])
+    env = TomatoVecEnv(B, weather=e["weather"], params=e["p"], dtype=dtype, season_length=1, start_rows=[0], start_days=[0.0],
+                       auto_reset=False, u_min=g["ctl_u_min"], u_max=g["ctl_u_max"], delta_u_max=float(g["ctl_delta_u_max"]))
+    env.reset()
+    env.u.copy_(torch.as_tensor(g["ctl_u_prev"], dtype=env.tdtype, device=env.device))
+    obs, r, done, infos = env.step(g["ctl_action"])
+    u = env.u.double().cpu().numpy()
+    np.testing.assert_allclose(u, g["ctl_u"].astype(np.float64), rtol=0, atol=atol)
+    assert (u >= g["ctl_u_min"].astype(np.float32) - 1e-12).all() and (u <= g["ctl_u_max"].astype(np.float32) + 1e-12).all()
+    np.testing.assert_allclose(np.array([infos[b]["controls"] for b in range(B)]), u, rtol=0, atol=1e-7)
+    lib, h = env._lib, env._h
+    lo, hi = np.zeros(6), np.ones(6)
+    P = lambda a: a.ctypes.data_as(L._DP)
+    assert lib.glgym_set_control_limits(h, P(hi), P(lo), 0.1) == L.EINVAL           # u_min > u_max
+    assert lib.glgym_set_control_limits(h, P(lo), P(hi), -0.1) == L.EINVAL
+    assert lib.glgym_set_control_limits(h, None, P(hi), 0.1) == L.EINVAL
+    env.close()

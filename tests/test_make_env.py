@@ -46,8 +46,9 @@ def test_load_env_params_and_season_table(cfg_dir):
         _check_supported("GreenhouseReward", ["IndoorClimateObservations", "NoSuchObservations"], base)
     with pytest.raises(NotImplementedError):       # the reference cannot construct it either (observations.py:42)
         _check_supported("GreenhouseReward", ["IndoorClimateObservations", "StateObservations"], base)
-    with pytest.raises(NotImplementedError):
-        _check_supported("GreenhouseReward", OBSERVATION_MODULES, dict(base, delta_u_max=0.2))
+    _check_supported("GreenhouseReward", OBSERVATION_MODULES, dict(base, delta_u_max=0.2))     # glgym_set_control_limits
+    with pytest.raises(ValueError):
+        _check_supported("GreenhouseReward", OBSERVATION_MODULES, dict(base, u_min=[0.5] * 6, u_max=[0.4] * 6))
 
 
 @pytest.mark.gpu

@@ -245,3 +245,15 @@ def test_env_oracle_observation_module_layouts_against_reference(golden):
         assert [n for m in desc for n in m.obs_names] == [str(n) for n in g[f"l{i}_names"]]
         np.testing.assert_array_equal(np.concatenate([np.full(m.n_obs, m.low, np.float32) for m in desc]), g[f"l{i}_low"])
         np.testing.assert_array_equal(np.concatenate([np.full(m.n_obs, m.high, np.float32) for m in desc]), g[f"l{i}_high"])
+
+
+def test_env_oracle_control_limits_against_reference(golden):
+    """action_to_control of the reference env built with other u_min / u_max / delta_u_max (float32, base_env.py:72-74)."""
+    from oracle.gl_env_oracle import OracleTomatoEnv
+    g, e = golden("refenv_obs_layouts"), golden("refenv_1day")
+    env = OracleTomatoEnv(weather=e["weather"], p=e["p"], season_length=1, start_day=0, seed=1, train_years=[2009],
+                          train_days=[0], u_min=g["ctl_u_min"], u_max=g["ctl_u_max"], delta_u_max=float(g["ctl_delta_u_max"]))
+    for up, a, u in zip(g["ctl_u_prev"], g["ctl_action"], g["ctl_u"]):
+        env.u = up.copy()
+        got = env.action_to_control(a)
+        assert got.dtype == np.float32 and np.array_equal(got, u)
