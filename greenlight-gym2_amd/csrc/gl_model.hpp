@@ -71,7 +71,13 @@ template <> struct Math<double> {
     static GL_HD double log(double v) { return ::log(v); }
     static GL_HD double rcp(double v) { return 1.0 / v; }
     static GL_HD double sqrt(double v) { return ::sqrt(v); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_F64_LIBM_POW)
+    // av^e as exp(e ln av), av >= 1e-8: |e ln av| < 7, so the result is within ~3 ulp of pow() at less than half its
+    // instructions (ocml's pow carries a double-double logarithm for arbitrary exponents: 8 calls were 40 % of an fp64 stage)
+    static GL_HD double powa(double av, double e) { return ::exp(e * ::log(av)); }
+#else
     static GL_HD double powa(double av, double e) { return ::pow(av, e); }   // av >= 0
+#endif
     static GL_HD double abs(double v) { return ::fabs(v); }
     static GL_HD double min(double a, double b) { return ::fmin(a, b); }
     static GL_HD double max(double a, double b) { return ::fmax(a, b); }
@@ -1079,6 +1085,17 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
     rhs_fast<T, HARVEST_IN_RHS, PIPE>(x, q, s, m, cr, dx);
 }
 
+// slot of state i in the integrator's "previous increment" array, -1 if tier 2b does not read the state
+GL_HD constexpr int gl_slow_slot(int i)
+{
+    return i == 0 ? 0 : i == 2 ? 1 : i == 4 ? 2 : i == 8 ? 3 : (i >= 10 && i <= 14) ? i - 6 : i == 19 ? 9
+           : (i >= 21 && i <= 26) ? i - 11 : -1;
+}
+// states whose derivative tier 2b holds constant over a sub-step (soil layers, grow pipes, crop pools): RK4 degenerates
+// to  h * dx
+GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || i == 19 || (i >= 22 && i <= 25); }
+constexpr int GL_N_SLOW = 16;
+
 // ---------------------------------------------------------------------------------------------------
 // rhs_stage: how the integrator calls rhs().  fp32: inlined (4 copies per sub-step, everything in registers).
 // fp64 on the device: ONE out-of-line copy.  The fully inlined fp64 step kernel needs > 512 registers per lane and
@@ -1086,21 +1103,84 @@ GL_HD void rhs(const T* x, const StepCoef<T>& s, const ModelConst<T>& m, const C
 // optimisation level (fp32 and the host build were unaffected).  Out of line, each function fits its register budget.
 // ---------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
-template <bool PIPE, bool RATES>
-__device__ __noinline__ inline void rhs_stage_f64(const double* x, const SlowCoef<double>* q, const StepCoef<double>* s,
-                                                  const ModelConst<double>* m, const CropConst<double>* cr, double* dx,
-                                                  double* lam)
+// What crosses the call lives in LDS, not on the stack: a per-wave "mailbox" of 8-byte slots, slot j of lane l at
+// gl_lds64[j * 64 + l] (conflict-free ds_read_b64 / ds_write_b64), plus one uniform copy of ModelConst behind it.  With
+// pointer arguments to the caller's locals every stage made ~90 flat loads from scratch and ~40 dependent waits on them:
+// 26 000 cycles per stage for 1 800 instructions.  The kernels that integrate in fp64 are launched with
+// gl_f64_lds_bytes() of dynamic LDS: 73 KB (two waves per CU), 91 KB with per-env crop parameters.
+extern __shared__ double gl_lds64[];
+#endif
+// per-lane slots: stage state in / derivative out (shared), rate bound, StepCoef, SlowCoef; then three uniform slots (ModelConst
+// + the per-env-crop flag); then, only for kernels with per-env crop parameters, the per-lane CropConst
+constexpr int GL_F64_X = 0, GL_F64_K = 0, GL_F64_LAM = NX, GL_F64_S = NX + 1;
+constexpr int GL_F64_NS = (int)(sizeof(StepCoef<double>) / 8), GL_F64_NQ = (int)(sizeof(SlowCoef<double>) / 8),
+              GL_F64_NCR = (int)(sizeof(CropConst<double>) / 8), GL_F64_NM = (int)(sizeof(ModelConst<double>) / 8);
+constexpr int GL_F64_Q = GL_F64_S + GL_F64_NS, GL_F64_MSLOT = GL_F64_Q + GL_F64_NQ;
+constexpr int GL_F64_M = GL_F64_MSLOT * 64;                       // uniform block: element f at gl_lds64[GL_F64_M + f]
+constexpr int GL_F64_MSLOTS = (GL_F64_NM + 1 + 63) / 64, GL_F64_CR = GL_F64_MSLOT + GL_F64_MSLOTS;
+constexpr size_t gl_f64_lds_bytes(bool per_env_crop) { return (size_t)(GL_F64_CR + (per_env_crop ? GL_F64_NCR : 0)) * 64 * 8; }
+static_assert(sizeof(StepCoef<double>) % 8 == 0 && sizeof(SlowCoef<double>) % 8 == 0 && sizeof(CropConst<double>) % 8 == 0 &&
+              sizeof(ModelConst<double>) % 8 == 0, "mailbox slots are 8 bytes");
+#if defined(__HIP_DEVICE_COMPILE__)
+
+template <class S> __device__ __forceinline__ void f64_put(const S& v, int slot0)
 {
-    rhs_fast<double, false, PIPE, RATES>(x, *q, *s, *m, *cr, dx, lam);
+    constexpr int N = (int)(sizeof(S) / 8);
+    double t[N];
+    __builtin_memcpy(t, &v, sizeof(S));
+#pragma unroll
+    for (int f = 0; f < N; ++f) gl_lds64[(slot0 + f) * 64 + threadIdx.x] = t[f];
 }
-__device__ __noinline__ inline void slow_coef_f64(const double* ym, const StepCoef<double>* s,
-                                                  const ModelConst<double>* m, const CropConst<double>* cr,
-                                                  SlowCoef<double>* q)
+template <class S> __device__ __forceinline__ void f64_get(S& v, int slot0)
 {
-    slow_coef<double>(ym, *s, *m, *cr, *q);
+    constexpr int N = (int)(sizeof(S) / 8);
+    double t[N];
+#pragma unroll
+    for (int f = 0; f < N; ++f) t[f] = gl_lds64[(slot0 + f) * 64 + threadIdx.x];
+    __builtin_memcpy(&v, t, sizeof(S));
+}
+__device__ __forceinline__ void f64_get_model(ModelConst<double>& m)
+{
+    double t[GL_F64_NM];
+#pragma unroll
+    for (int f = 0; f < GL_F64_NM; ++f) t[f] = gl_lds64[GL_F64_M + f];       // same address in every lane: broadcast read
+    __builtin_memcpy(&m, t, sizeof m);
+}
+
+__device__ __forceinline__ void f64_get_crop(CropConst<double>& cr, const ModelConst<double>& m)
+{
+    if (gl_lds64[GL_F64_M + GL_F64_NM] != 0.0) f64_get(cr, GL_F64_CR);        // wave-uniform flag
+    else cr = m.crop;
+}
+
+template <bool PIPE, bool RATES>
+__device__ __noinline__ inline void rhs_stage_f64()
+{
+    double x[NX], dx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x];
+    StepCoef<double> s; SlowCoef<double> q; CropConst<double> cr; ModelConst<double> m;
+    f64_get(s, GL_F64_S); f64_get(q, GL_F64_Q); f64_get_model(m); f64_get_crop(cr, m);
+    double lam = RATES ? gl_lds64[GL_F64_LAM * 64 + threadIdx.x] : 0.0;
+    rhs_fast<double, false, PIPE, RATES>(x, q, s, m, cr, dx, RATES ? &lam : nullptr);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x] = dx[i];
+    if (RATES) gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = lam;
+}
+__device__ __noinline__ inline void slow_coef_f64()
+{
+    double ym[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ym[i] = gl_slow_slot(i) >= 0 ? gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] : 0.0;
+    StepCoef<double> s; CropConst<double> cr; ModelConst<double> m; SlowCoef<double> q;
+    f64_get(s, GL_F64_S); f64_get_model(m); f64_get_crop(cr, m);
+    slow_coef<double>(ym, s, m, cr, q);
+    f64_put(q, GL_F64_Q);
 }
 #endif
 template <class T, bool PIPE> struct RhsStage {
+    static constexpr bool UNIFORM_CALLS = false;
+    static GL_HD void begin(const StepCoef<T>&, const ModelConst<T>&, const CropConst<T>&) {}
     template <bool RATES>
     static GL_HD void run(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
                           const CropConst<T>& cr, T* dx, T* lam)
@@ -1115,16 +1195,39 @@ template <class T, bool PIPE> struct RhsStage {
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <bool PIPE> struct RhsStage<double, PIPE> {
-    template <bool RATES>
-    static GL_HD void run(const double* x, const SlowCoef<double>& q, const StepCoef<double>& s,
-                          const ModelConst<double>& m, const CropConst<double>& cr, double* dx, double* lam)
+    static constexpr bool UNIFORM_CALLS = true;
+    // once per integration: the per-env-step coefficients, the crop constants and (uniform) the model constants
+    static __device__ void begin(const StepCoef<double>& s, const ModelConst<double>& m, const CropConst<double>& cr)
     {
-        rhs_stage_f64<PIPE, RATES>(x, &q, &s, &m, &cr, dx, lam);
+        f64_put(s, GL_F64_S);
+        const bool per_env_crop = &cr != &m.crop;                     // folds after inlining
+        if (per_env_crop) f64_put(cr, GL_F64_CR);
+        gl_lds64[GL_F64_M + GL_F64_NM] = per_env_crop ? 1.0 : 0.0;
+        double t[GL_F64_NM];
+        __builtin_memcpy(t, &m, sizeof m);
+#pragma unroll
+        for (int f = 0; f < GL_F64_NM; ++f) gl_lds64[GL_F64_M + f] = t[f];     // every lane writes the same values
     }
-    static GL_HD void slow(const double* ym, const StepCoef<double>& s, const ModelConst<double>& m,
-                           const CropConst<double>& cr, SlowCoef<double>& q)
+    template <bool RATES>
+    static __device__ void run(const double* x, const SlowCoef<double>&, const StepCoef<double>&,
+                               const ModelConst<double>&, const CropConst<double>&, double* dx, double* lam)
     {
-        slow_coef_f64(ym, &s, &m, &cr, &q);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] = x[i];
+        if (RATES) gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = *lam;
+        rhs_stage_f64<PIPE, RATES>();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x];
+        if (RATES) *lam = gl_lds64[GL_F64_LAM * 64 + threadIdx.x];
+    }
+    // q stays in the mailbox (run() reads it there); only the slow-slot entries of ym are defined, the rest is not read
+    static __device__ void slow(const double* ym, const StepCoef<double>&, const ModelConst<double>&,
+                                const CropConst<double>&, SlowCoef<double>&)
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (gl_slow_slot(i) >= 0) gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] = ym[i];
+        slow_coef_f64();
     }
 };
 #endif
@@ -1181,16 +1284,6 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
 // adjacent half steps are merged into one call (group property of the flow).
 // Returns del (x(dt) - x0); the caller adds it once.
 // ---------------------------------------------------------------------------------------------------
-// slot of state i in the integrator's "previous increment" array, -1 if tier 2b does not read the state
-GL_HD constexpr int gl_slow_slot(int i)
-{
-    return i == 0 ? 0 : i == 2 ? 1 : i == 4 ? 2 : i == 8 ? 3 : (i >= 10 && i <= 14) ? i - 6 : i == 19 ? 9
-           : (i >= 21 && i <= 26) ? i - 11 : -1;
-}
-// states whose derivative tier 2b holds constant over a sub-step (soil layers, grow pipes, crop pools): RK4 degenerates
-// to  h * dx
-GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || i == 19 || (i >= 22 && i <= 25); }
-constexpr int GL_N_SLOW = 16;
 
 // ---------------------------------------------------------------------------------------------------
 // The sub-stepper, round 2: STABILITY-CONTROLLED.
@@ -1254,6 +1347,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
     for (int j = 0; j < GL_N_SLOW; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
+    RhsStage<T, PIPE>::begin(s, m, cr);
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
     int n_steps = 0, flags = 0;
@@ -1303,7 +1397,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         hs = capped ? hmin : hs;
         t_cap += capped ? hw : T(0);
         T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
-        const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h;
+        T h = hw * M::rcp(n_rem), h2 = T(0.5) * h;
         h_last = h;
         // one sub-step from (y, k = f(y)): leaves the increment in del and the scheme's last stage in k
         auto sub_step = [&]() {
@@ -1335,15 +1429,38 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // the first sub-step uses the stage evaluated above; every further one starts with its own first stage (written
         // as two loops so that the compiler cannot hoist that evaluation above the exit test of the previous sub-step)
         sub_step();
-        for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
-            rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
-            sub_step();
-        }
         // the last stage (RK4: k4; midpoint: 2 k2 - k1) of the window's last sub-step, for the estimate at the next start
 #pragma unroll
         for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+        if (RhsStage<T, PIPE>::UNIFORM_CALLS) {
+            // fp64 on the device: the stage is an out-of-line call, and calls are kept wave-uniform -- every lane runs the
+            // wave's longest window, lanes that are done take sub-steps of length 0 (same time at wave level: they would
+            // idle), and keep the estimate stage of their own last real sub-step
+            for (n_rem -= T(1); GL_WAVE_ANY(n_rem >= T(0.5)); n_rem -= T(1)) {
+                const bool act = n_rem >= T(0.5);
+                h = act ? h_last : T(0); h2 = T(0.5) * h;
+                T keep[SC_NFAST];
+#pragma unroll
+                for (int j = 0; j < SC_NFAST; ++j) keep[j] = est[j];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+                rhs_stage<T, PIPE>(y, q, s, m, cr, k);
+                sub_step();
+                n_steps -= act ? 0 : 1;
+#pragma unroll
+                for (int j = 0; j < SC_NFAST; ++j)
+                    est[j] = !act ? keep[j] : (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+            }
+        } else {
+            for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+                rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
+                sub_step();
+#pragma unroll
+                for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+            }
+        }
         // ---- window end: increment of the window's RK part (harvest excluded), harvest flow
 #pragma unroll
         for (int i = 0; i < NX; ++i)

@@ -134,6 +134,14 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #ifndef GL_RK4_WIN_F32
 #define GL_RK4_WIN_F32 2
 #endif
+ // kernels that integrate in fp64 take the LDS mailbox of gl_model.hpp (rhs_stage_f64) as dynamic LDS
+#define GL_LAUNCH_T(kern, crop, grid, block, st, ...)                                                                       \
+    do {                                                                                                               \
+        auto kf_ = kern;                                                                                               \
+        const size_t lds_ = sizeof(T) == 8 ? glm::gl_f64_lds_bytes(crop) : 0;                                           \
+        if (lds_) (void)hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+        hipLaunchKernelGGL(kf_, grid, block, lds_, st, __VA_ARGS__);                                                   \
+    } while (0)
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : 1; };
 
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
@@ -1041,20 +1049,20 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
             g_err = "glgym_evalF: GLGYM_ODE_PIPE supports neither per-row parameter blocks nor GLGYM_SCHEME_RK2";
             return GLGYM_EINVAL;
         }
-        hipLaunchKernelGGL((evalf_kernel<T, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+        GL_LAUNCH_T((evalf_kernel<T, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                            T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     } else if (h->scheme == GLGYM_SCHEME_RK2) {
         if (dcrop)
-            hipLaunchKernelGGL((evalf_kernel<T, true, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt),
+            GL_LAUNCH_T((evalf_kernel<T, true, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt),
                                h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
         else
-            hipLaunchKernelGGL((evalf_kernel<T, false, false, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt),
+            GL_LAUNCH_T((evalf_kernel<T, false, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt),
                                h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     } else if (dcrop)
-        hipLaunchKernelGGL((evalf_kernel<T, true>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+        GL_LAUNCH_T((evalf_kernel<T, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                            T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     else
-        hipLaunchKernelGGL((evalf_kernel<T, false>), grid, block, 0, 0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+        GL_LAUNCH_T((evalf_kernel<T, false>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                            T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
@@ -1157,7 +1165,7 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
             g_err = "glgym_step: GLGYM_ODE_PIPE supports neither per-env crop parameters nor GLGYM_SCHEME_RK2";
             return GLGYM_EINVAL;
         }
-        hipLaunchKernelGGL((step_kernel<T, false, false, true>), grid, block, 0, st, k, m, rw);
+        GL_LAUNCH_T((step_kernel<T, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
     }
@@ -1169,29 +1177,29 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     const bool occ2 = def && !a->crop_p && (occ_env == 2 || (occ_env == 0 && a->B >= 4 * h->n_simd * WAVE));
     if constexpr (sizeof(T) == 4) {      // fp64 never takes the specialised kernels (def is false), so no fp64 OCC = 2 build
         if (occ2) {
-            if (h->scheme == GLGYM_SCHEME_RK2) hipLaunchKernelGGL((step_kernel<T, false, true, false, true, 2>), grid, block, 0, st, k, m, rw);
-            else hipLaunchKernelGGL((step_kernel<T, false, true, false, false, 2>), grid, block, 0, st, k, m, rw);
+            if (h->scheme == GLGYM_SCHEME_RK2) GL_LAUNCH_T((step_kernel<T, false, true, false, true, 2>), a->crop_p != nullptr, grid, block, st, k, m, rw);
+            else GL_LAUNCH_T((step_kernel<T, false, true, false, false, 2>), a->crop_p != nullptr, grid, block, st, k, m, rw);
             HIPCHK(hipGetLastError());
             return GLGYM_OK;
         }
     }
     if (h->scheme == GLGYM_SCHEME_RK2) {
         if (a->crop_p) {
-            if (def) hipLaunchKernelGGL((step_kernel<T, true, true, false, true>), grid, block, 0, st, k, m, rw);
-            else hipLaunchKernelGGL((step_kernel<T, true, false, false, true>), grid, block, 0, st, k, m, rw);
+            if (def) GL_LAUNCH_T((step_kernel<T, true, true, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
+            else GL_LAUNCH_T((step_kernel<T, true, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
         } else {
-            if (def) hipLaunchKernelGGL((step_kernel<T, false, true, false, true>), grid, block, 0, st, k, m, rw);
-            else hipLaunchKernelGGL((step_kernel<T, false, false, false, true>), grid, block, 0, st, k, m, rw);
+            if (def) GL_LAUNCH_T((step_kernel<T, false, true, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
+            else GL_LAUNCH_T((step_kernel<T, false, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
         }
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
     }
     if (a->crop_p) {
-        if (def) hipLaunchKernelGGL((step_kernel<T, true, true>), grid, block, 0, st, k, m, rw);
-        else hipLaunchKernelGGL((step_kernel<T, true, false>), grid, block, 0, st, k, m, rw);
+        if (def) GL_LAUNCH_T((step_kernel<T, true, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
+        else GL_LAUNCH_T((step_kernel<T, true, false>), a->crop_p != nullptr, grid, block, st, k, m, rw);
     } else {
-        if (def) hipLaunchKernelGGL((step_kernel<T, false, true>), grid, block, 0, st, k, m, rw);
-        else hipLaunchKernelGGL((step_kernel<T, false, false>), grid, block, 0, st, k, m, rw);
+        if (def) GL_LAUNCH_T((step_kernel<T, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
+        else GL_LAUNCH_T((step_kernel<T, false, false>), a->crop_p != nullptr, grid, block, st, k, m, rw);
     }
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
