@@ -808,6 +808,123 @@ template <> struct FirBlock<float> {
 #endif
 
 // ---------------------------------------------------------------------------------------------------
+// The two screens (thermal, blackout) go through identical algebra with their own coefficients: screen air flux, the two
+// |dT|^(1/3) exchange laws, saturation pressure, condensation gate, vapour flux, heat balance (aux_states.hpp:746-779,
+// 846-905, 999-1012; ode.hpp:41-47, 101-107).  Generic version: scalar.  fp32 on the device: both screens as one register
+// pair, 33 packed instructions (v_pk_add / v_pk_mul / v_pk_fma_f32) for 66 plain ones; the saturation pressures of the
+// cover and the canopy ride along as a second pair.  Same operations in the same order per component.
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct ScrOut {
+    T fTh, fBl, dATh, dABl, hecAirTh, hecAirBl, hAirThScr, hAirBlScr, hecThTop, hecBlTop, hThScrTop, hBlScrTop;
+    T svTh, svBl, rTh, rBl, gTh, gBl, mvAirThScr, mvAirBlScr, svCov, rCov, svCan;
+};
+
+template <class T> struct ScreenBlock {
+    static GL_HD void run(T tAir, T tTop, T tThScr, T tBlScr, T tCovIn, T tCan, T vpAir, T pw66, T iRhoMean, T rhoMean,
+                          T dRho, const StepCoef<T>& s, const ModelConst<T>& m, ScrOut<T>& o)
+    {
+        using M = Math<T>;
+        const T one = T(1), eps = T(1e-10), third = T(1.0 / 3.0);
+        o.fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
+        o.fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
+        o.dATh = tAir - tThScr; o.dABl = tAir - tBlScr;
+        const T dThTop = tThScr - tTop, dBlTop = tBlScr - tTop;
+        o.hecAirTh = s.hTh * M::powa(M::abs(o.dATh + eps), third);
+        o.hecAirBl = s.hBl * M::powa(M::abs(o.dABl + eps), third);
+        o.hAirThScr = M::abs(o.hecAirTh) * o.dATh;
+        o.hAirBlScr = M::abs(o.hecAirBl) * o.dABl;
+        o.hecThTop = s.hTh * M::powa(M::abs(dThTop + eps), third);
+        o.hecBlTop = s.hBl * M::powa(M::abs(dBlTop + eps), third);
+        o.hThScrTop = o.hecThTop * dThTop;
+        o.hBlScrTop = o.hecBlTop * dBlTop;
+        auto satVpR = [&](T t, T& r) { r = M::rcp(t + T(238.3)); return T(610.78) * M::expk(T(17.2694), t * r); };
+        // gate(dv) = dv / (1 + exp(-0.1 dv));  condensation = 6.4e-9 hec gate
+        auto gate = [&](T dv) { return dv * M::rcp(one + M::expk(T(-0.1), dv)); };
+        o.svTh = satVpR(tThScr, o.rTh); o.svBl = satVpR(tBlScr, o.rBl); o.svCov = satVpR(tCovIn, o.rCov);
+        T rCan;
+        o.svCan = satVpR(tCan, rCan);
+        o.gTh = gate(vpAir - o.svTh); o.gBl = gate(vpAir - o.svBl);
+        o.mvAirThScr = o.hecAirTh * T(6.4e-9) * o.gTh;
+        o.mvAirBlScr = o.hecAirBl * T(6.4e-9) * o.gBl;
+    }
+    // dx7, dx20 (ode.hpp:41-47, 101-107)
+    static GL_HD void balance(const ScrOut<T>& o, T L, T firTh, T firBl, T iToTh, T iToBl, const ModelConst<T>& m,
+                              T& dxTh, T& dxBl)
+    {
+        dxTh = m.iCapThScr * (o.hAirThScr + L * o.mvAirThScr + firTh - o.hThScrTop + iToTh);
+        dxBl = m.iCapBlScr * (o.hAirBlScr + L * o.mvAirBlScr + firBl - o.hBlScrTop + iToBl);
+    }
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_PACKED_SCREENS)
+template <> struct ScreenBlock<float> {
+    static __device__ __forceinline__ gl_f2 mk(float a, float b) { gl_f2 r; r.x = a; r.y = b; return r; }
+    static __device__ __forceinline__ gl_f2 sp(float a) { gl_f2 r; r.x = a; r.y = a; return r; }
+    static __device__ __forceinline__ gl_f2 lg2(gl_f2 v) { return mk(__builtin_amdgcn_logf(__builtin_fabsf(v.x)), __builtin_amdgcn_logf(__builtin_fabsf(v.y))); }
+    static __device__ __forceinline__ gl_f2 ex2(gl_f2 v) { return mk(__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)); }
+    static __device__ __forceinline__ gl_f2 rc(gl_f2 v) { return mk(__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)); }
+    static __device__ __forceinline__ void run(float tAir, float tTop, float tThScr, float tBlScr, float tCovIn, float tCan,
+                                               float vpAir, float pw66, float iRhoMean, float rhoMean, float dRho,
+                                               const StepCoef<float>& s, const ModelConst<float>& m, ScrOut<float>& o)
+    {
+        const float eps = 1e-10f, third = 1.0f / 3.0f, l2e = 1.44269504088896341f;
+        const gl_f2 tS = mk(tThScr, tBlScr), omu = mk(s.oneMinusUTh, s.oneMinusUBl), hS = mk(s.hTh, s.hBl);
+        // screen air flux
+        const gl_f2 arg = sp(m.gHalf * rhoMean) * omu * sp(dRho) + sp(eps);
+        const gl_f2 sq = mk(__builtin_amdgcn_sqrtf(arg.x), __builtin_amdgcn_sqrtf(arg.y));
+        const gl_f2 f = mk(s.kTh, s.kBl) * sp(pw66) + omu * sp(iRhoMean) * sq;
+        o.fTh = f.x; o.fBl = f.y;
+        // exchange laws  h |dT|^(1/3):  pow = exp2(third * log2 |.|)
+        const gl_f2 dA = sp(tAir) - tS, dT = tS - sp(tTop);
+        const gl_f2 hecA = hS * ex2(sp(third) * lg2(dA + sp(eps)));
+        const gl_f2 hecT = hS * ex2(sp(third) * lg2(dT + sp(eps)));
+        const gl_f2 hTop = hecT * dT;
+        o.dATh = dA.x; o.dABl = dA.y;
+        o.hecAirTh = hecA.x; o.hecAirBl = hecA.y; o.hecThTop = hecT.x; o.hecBlTop = hecT.y;
+        o.hAirThScr = __builtin_fabsf(hecA.x) * dA.x; o.hAirBlScr = __builtin_fabsf(hecA.y) * dA.y;
+        o.hThScrTop = hTop.x; o.hBlScrTop = hTop.y;
+        // saturation pressures: (thScr, blScr) and (covIn, can)
+        const gl_f2 tC = mk(tCovIn, tCan);
+        const gl_f2 rS = rc(tS + sp(238.3f)), rC = rc(tC + sp(238.3f));
+        const gl_f2 svS = sp(610.78f) * ex2(sp(17.2694f * l2e) * (tS * rS));
+        const gl_f2 svC = sp(610.78f) * ex2(sp(17.2694f * l2e) * (tC * rC));
+        o.svTh = svS.x; o.svBl = svS.y; o.rTh = rS.x; o.rBl = rS.y; o.svCov = svC.x; o.rCov = rC.x; o.svCan = svC.y;
+        // condensation gate and vapour flux
+        const gl_f2 dv = sp(vpAir) - svS;
+        const gl_f2 g = dv * rc(sp(1.0f) + ex2(sp(-0.1f * l2e) * dv));
+        const gl_f2 mv = hecA * sp(6.4e-9f) * g;
+        o.gTh = g.x; o.gBl = g.y; o.mvAirThScr = mv.x; o.mvAirBlScr = mv.y;
+    }
+    static __device__ __forceinline__ void balance(const ScrOut<float>& o, float L, float firTh, float firBl, float iToTh,
+                                                   float iToBl, const ModelConst<float>& m, float& dxTh, float& dxBl)
+    {
+        const gl_f2 b = mk(m.iCapThScr, m.iCapBlScr) * (mk(o.hAirThScr, o.hAirBlScr) + sp(L) * mk(o.mvAirThScr, o.mvAirBlScr) +
+                                                       mk(firTh, firBl) - mk(o.hThScrTop, o.hBlScrTop) + mk(iToTh, iToBl));
+        dxTh = b.x; dxBl = b.y;
+    }
+};
+#endif
+
+// The air streams: CO2, vapour and sensible heat carried through the screens (air -> top) and the roof vents (top -> out)
+// are the same three differences times the same two volume fluxes (aux_states.hpp:869-870, 1017-1024, 1201-1209).
+template <class T> struct AirOut { T hAirTop, hTopOut, mvAirTop, mvTopOut, mcAirTop, mcTopOut, vAirOverT; };
+template <class T> struct AirBlock {
+    static GL_HD void run(T fScrAbs, T fRoofAbs, T tAir, T tTop, T co2Air, T co2Top, T vAirOverT, T vTopOverT,
+                          const StepCoef<T>& s, const ModelConst<T>& m, AirOut<T>& o)
+    {
+        const T kMv = T(0.002165);
+        o.hAirTop = m.rhoCp * fScrAbs * (tAir - tTop);
+        o.hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
+        o.mvAirTop = kMv * fScrAbs * (vAirOverT - vTopOverT);
+        o.mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
+        o.mcAirTop = fScrAbs * (co2Air - co2Top);
+        o.mcTopOut = fRoofAbs * (co2Top - s.co2Out);
+    }
+};
+// (A packed fp32 version of this block was built and measured: the pairs (x, y) - (y, z) have to be assembled with
+// register moves, +28 v_mov for +64 packed instructions per kernel: 40 instructions MORE than the scalar form.  Not kept.)
+
+// ---------------------------------------------------------------------------------------------------
 // Tier 3: everything that follows the fast states.  HARVEST_IN_RHS = true gives the reference's complete right-hand
 // side (test hook); the integrator uses false: the two harvest terms are advanced by their exact flow instead
 // (harvest_flow below).
@@ -899,9 +1016,9 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T dAT = tAir - tTop;
     const T pw66 = M::powa(M::abs(dAT + eps), T(0.66));
     const T iRhoMean = M::rcp(rhoMean);
-    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
-    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
-    const T fScr = M::min(fTh, fBl);                                    // a144
+    ScrOut<T> sc;          // both screens at once (ScreenBlock above)
+    ScreenBlock<T>::run(tAir, tTop, tThScr, tBlScr, tCovIn, tCan, vpAir, pw66, iRhoMean, rhoMean, dRho, s, m, sc);
+    const T fScr = M::min(sc.fTh, sc.fBl);                              // a144
     const T fScrAbs = M::abs(fScr), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
 
     // ---- convection / conduction (aux_states.hpp:824-935)
@@ -911,21 +1028,15 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T hecFlr = (warmFlr ? T(1.7) : T(1.3)) *
                      M::powa(M::abs((warmFlr ? dFA : -dFA) + eps), warmFlr ? third : T(0.25));
     const T hAirFlr = hecFlr * (-dFA);
-    const T dATh = tAir - tThScr, dABl = tAir - tBlScr, dThTop = tThScr - tTop, dBlTop = tBlScr - tTop;
+    const T dATh = sc.dATh, dABl = sc.dABl;
     const T dTopCov = tTop - tCovIn;
-    const T hecAirTh = s.hTh * M::powa(M::abs(dATh + eps), third);
-    const T hecAirBl = s.hBl * M::powa(M::abs(dABl + eps), third);
+    const T hecAirTh = sc.hecAirTh, hecAirBl = sc.hecAirBl;
     const T hecTopCov = m.cTopCov * M::powa(M::abs(dTopCov + eps), third);
-    const T hAirThScr = M::abs(hecAirTh) * dATh;
-    const T hAirBlScr = M::abs(hecAirBl) * dABl;
+    const T hAirThScr = sc.hAirThScr, hAirBlScr = sc.hAirBlScr;
     const T hAirOut = s.hAirOutK * dTOut;
-    const T hAirTop = m.rhoCp * fScrAbs * dAT;
-    const T hecThTop = s.hTh * M::powa(M::abs(dThTop + eps), third);
-    const T hecBlTop = s.hBl * M::powa(M::abs(dBlTop + eps), third);
-    const T hThScrTop = hecThTop * dThTop;
-    const T hBlScrTop = hecBlTop * dBlTop;
+    const T hecThTop = sc.hecThTop, hecBlTop = sc.hecBlTop;
+    const T hThScrTop = sc.hThScrTop, hBlScrTop = sc.hBlScrTop;
     const T hTopCovIn = M::abs(hecTopCov) * dTopCov;
-    const T hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
     const T hCovEOut = s.covOutK * (tCovE - s.tOut);
     const T dPA = tPipe - tAir;
     const T hPipeAir = m.cPipeAir * M::powa(M::abs(dPA + eps), T(0.32)) * dPA;
@@ -933,9 +1044,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T hLampAir = m.cLampAir * (tLamp - tAir);
 
     // ---- transpiration (aux_states.hpp:958-981)
-    auto satVpR = [&](T t, T& r) { r = M::rcp(t + T(238.3)); return T(610.78) * M::expk(T(17.2694), t * r); };
-    auto satVp = [&](T t) { T r; return satVpR(t, r); };
-    const T vpd = satVp(tCan) - vpAir;
+    const T vpd = sc.svCan - vpAir;
     const T co2Dev = m.etaMgPpm * co2Air - T(200);
     const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
     const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
@@ -945,11 +1054,9 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     // ---- condensation and vapour carried by air (aux_states.hpp:999-1024)
     // gate(dv) = dv / (1 + exp(-0.1 dv));  condensation = 6.4e-9 hec gate
     auto gate = [&](T dv) { return dv * M::rcp(one + M::expk(T(-0.1), dv)); };
-    T rTh, rBl, rCov;
-    const T svTh = satVpR(tThScr, rTh), svBl = satVpR(tBlScr, rBl), svCov = satVpR(tCovIn, rCov);
-    const T gTh = gate(vpAir - svTh), gBl = gate(vpAir - svBl), gCov = gate(vpTop - svCov);
-    const T mvAirThScr = hecAirTh * T(6.4e-9) * gTh;
-    const T mvAirBlScr = hecAirBl * T(6.4e-9) * gBl;
+    const T rTh = sc.rTh, rBl = sc.rBl, rCov = sc.rCov, svTh = sc.svTh, svBl = sc.svBl, svCov = sc.svCov;
+    const T gTh = sc.gTh, gBl = sc.gBl, gCov = gate(vpTop - svCov);
+    const T mvAirThScr = sc.mvAirThScr, mvAirBlScr = sc.mvAirBlScr;
     const T mvTopCovIn = hecTopCov * T(6.4e-9) * gCov;
     T vAirOverT, vTopOverT;
     if (sizeof(T) == 8) {   // the float-typed Kelvin offset of the reference's airMv() is only visible in fp64
@@ -960,8 +1067,9 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         vTopOverT = vpTop * iTopK;
     }
     const T kMv = T(0.002165);
-    const T mvAirTop = kMv * fScrAbs * (vAirOverT - vTopOverT);
-    const T mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
+    AirOut<T> air;         // screen and roof streams at once (AirBlock above)
+    AirBlock<T>::run(fScrAbs, fRoofAbs, tAir, tTop, co2Air, co2Top, vAirOverT, vTopOverT, s, m, air);
+    const T hAirTop = air.hAirTop, hTopOut = air.hTopOut, mvAirTop = air.mvAirTop, mvTopOut = air.mvTopOut;
     const T mvAirOut = kMv * fSideAbs * (vAirOverT - s.vpOutOverT);
 
     // ---- crop: photosynthesis and carbohydrate flows come from tier 2b (q.mcAirCan, q.dBuf ... q.dFruit); only the
@@ -974,8 +1082,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     }
 
     // ---- CO2 carried by air (aux_states.hpp:1201-1209)
-    const T mcAirTop = fScrAbs * (co2Air - co2Top);
-    const T mcTopOut = fRoofAbs * (co2Top - s.co2Out);
+    const T mcAirTop = air.mcAirTop, mcTopOut = air.mcTopOut;
     const T mcAirOut = fSideAbs * (co2Air - s.co2Out);
 
     // ---- balances (ode.hpp:14-121)
@@ -988,7 +1095,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     dx[4] = q.iCapCan * (q.swCan + fir.can - hCanAir - L * mvCanAir + q.rGroPipeCan + iToCan);
     dx[5] = m.iCapCov * (hTopCovIn + L * mvTopCovIn + fir.covIn - hCovInCovE + iToCovIn);
     dx[6] = m.iCapCov * (s.sunCovE + hCovInCovE - hCovEOut + fir.covE);
-    dx[7] = m.iCapThScr * (hAirThScr + L * mvAirThScr + fir.thScr - hThScrTop + iToThScr);
+    ScreenBlock<T>::balance(sc, L, fir.thScr, fir.blScr, iToThScr, iToBlScr, m, dx[7], dx[20]);
     dx[8] = m.iCapFlr * (hAirFlr + q.swFlr + fir.flr - q.hFlrSo1 + iToFlr);
     dx[9] = m.iCapPipe * (s.hBoilPipe + fir.pipe - hPipeAir + iToPipe);
     dx[10] = q.dSo1;
@@ -1005,7 +1112,6 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         dx[9] = (s.pipeTrack != T(0)) ? (s.tPipeSet - x[9]) : dx[9];      // ode.hpp:184-189
         dx[19] = T(0);                                                    // ode.hpp:240
     }
-    dx[20] = m.iCapBlScr * (hAirBlScr + L * mvAirBlScr + fir.blScr - hBlScrTop + iToBlScr);
     const T perDay = T(1.0 / 86400.0);
     dx[21] = perDay * (tCan - tCan24);
     dx[22] = q.dBuf;
