@@ -1392,6 +1392,45 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
 // ---------------------------------------------------------------------------------------------------
 
 // ---------------------------------------------------------------------------------------------------
+// The integrator's vector updates (y = x0 + del, stage inputs, accumulators, increments) run over PAIRS of states, so that
+// fp32 on the device does two states per v_pk_add / v_pk_fma_f32.  The pairing keeps states of one kind together (the ten
+// whose rate tier 2b holds constant over a sub-step: gl_const_rate) and matches the register pairs the FIR and screen blocks
+// use -- (tCan, tPipe) (tFlr, tLamp) (tThScr, tBlScr) (tCovIn, tCovE) -- so those pairs exist as such from the stage input on.
+// Generic version: the same loop bodies, one state at a time.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GL_NPAIR = 14, GL_NPAIR_FAST = 9;          // pairs 0..8: full RK update; 9..13: constant-rate states
+GL_HD constexpr int gl_pair_a(int p)
+{
+    return p == 0 ? 4 : p == 1 ? 8 : p == 2 ? 7 : p == 3 ? 5 : p == 4 ? 0 : p == 5 ? 2 : p == 6 ? 15 : p == 7 ? 18 : p == 8 ? 26
+           : p == 9 ? 10 : p == 10 ? 12 : p == 11 ? 14 : p == 12 ? 22 : 24;
+}
+GL_HD constexpr int gl_pair_b(int p)
+{
+    return p == 0 ? 9 : p == 1 ? 17 : p == 2 ? 20 : p == 3 ? 6 : p == 4 ? 1 : p == 5 ? 3 : p == 6 ? 16 : p == 7 ? 21 : p == 8 ? 27
+           : p == 9 ? 11 : p == 10 ? 13 : p == 11 ? 19 : p == 12 ? 23 : 25;
+}
+template <class T> struct RkOne {                        // accessor of one state
+    int i;
+    GL_HD T ld(const T* a) const { return a[i]; }
+    GL_HD void st(T* a, T v) const { a[i] = v; }
+    GL_HD T sp(T v) const { return v; }
+};
+template <class T> struct RkVec {
+    template <class F> static GL_HD void pair(int i, int j, F f) { f(RkOne<T>{i}); f(RkOne<T>{j}); }
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_PACKED_RK)
+struct RkTwo {                                           // accessor of a register pair
+    int i, j;
+    __device__ __forceinline__ gl_f2 ld(const float* a) const { gl_f2 r; r.x = a[i]; r.y = a[j]; return r; }
+    __device__ __forceinline__ void st(float* a, gl_f2 v) const { a[i] = v.x; a[j] = v.y; }
+    __device__ __forceinline__ gl_f2 sp(float v) const { gl_f2 r; r.x = v; r.y = v; return r; }
+};
+template <> struct RkVec<float> {
+    template <class F> static __device__ __forceinline__ void pair(int i, int j, F f) { f(RkTwo{i, j}); }
+};
+#endif
+
+// ---------------------------------------------------------------------------------------------------
 // The sub-stepper, round 2: STABILITY-CONTROLLED.
 //
 // ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 2 = explicit midpoint
@@ -1465,6 +1504,11 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hw2);
     const int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     T h_last = hnom;
+    auto state_now = [&]() {                                      // y = x0 + del
+#pragma unroll
+        for (int p = 0; p < GL_NPAIR; ++p)
+            RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(y, r.ld(x0) + r.ld(del)); });
+    };
     for (int it = 0; it < n_win; ++it) {
         // A rate beyond SC_MAX_REFINE x the nominal one is followed at the finest sub-step (the seconds before a cold, wet
         // surface crosses the air temperature); only one that PERSISTS is unresolvable: reported as a failed integration
@@ -1472,8 +1516,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         if (flags & SC_FLAG_CAP) break;
         // ---- window start: tier 2b at the predicted window midpoint  y + (previous window's increment) / 2, then the
         // first stage of the window's first sub-step together with the rate bound (the only place it is evaluated)
-#pragma unroll
-        for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+        state_now();
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) { xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)]; dwin[gl_slow_slot(i)] = del[i]; }
@@ -1510,25 +1553,35 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             if (ORDER == 4) {
                 const T h6 = h * T(1.0 / 6.0);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        r.st(acc, r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        r.st(acc, r.ld(acc) + r.sp(T(2)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        r.st(acc, r.ld(acc) + r.sp(T(2)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h) * r.ld(k)); });
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    del[i] += gl_const_rate(i) ? h * k[i] : h6 * (acc[i] + k[i]);       // k1 = k2 = k3 = k4 for those
+                for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 = k4 for the constant-rate states
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        if (p < GL_NPAIR_FAST) r.st(del, r.ld(del) + r.sp(h6) * (r.ld(acc) + r.ld(k)));
+                        else r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
             } else {
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] = -k[sc_fast(j)];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) if (!gl_const_rate(i)) xs[i] = y[i] + h2 * k[i];
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
                 rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) del[i] += h * k[i];
+                for (int p = 0; p < GL_NPAIR; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
             }
             ++n_steps;
         };
@@ -1548,8 +1601,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 T keep[SC_NFAST];
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) keep[j] = est[j];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+                state_now();
                 rhs_stage<T, PIPE>(y, q, s, m, cr, k);
                 sub_step();
                 n_steps -= act ? 0 : 1;
@@ -1559,8 +1611,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             }
         } else {
             for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) y[i] = x0[i] + del[i];
+                state_now();
                 rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
                 sub_step();
 #pragma unroll
