@@ -905,6 +905,29 @@ template <> struct ScreenBlock<float> {
 };
 #endif
 
+// dx[i] = ci * ri, dx[j] = cj * rj for two balances whose states form a register pair in the integrator (RkVec below).
+// (Summing the leading terms of the two rows as pairs as well was built and measured: the pairs of unrelated fresh values
+// have to be assembled with register moves -- +61 v_mov, +60 instructions per kernel.  Not kept.)
+template <class T> struct Mul2 {
+    static GL_HD void run(T* dx, int i, int j, T ci, T cj, T ri, T rj) { dx[i] = ci * ri; dx[j] = cj * rj; }
+    static GL_HD void run3(T* dx, int i, int j, T ci, T cj, T ti, T tj, T ri, T rj) { dx[i] = ci * ti * ri; dx[j] = cj * tj * rj; }
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_NO_PACKED_ROWS)
+template <> struct Mul2<float> {
+    static __device__ __forceinline__ gl_f2 mk(float a, float b) { gl_f2 r; r.x = a; r.y = b; return r; }
+    static __device__ __forceinline__ void run(float* dx, int i, int j, float ci, float cj, float ri, float rj)
+    {
+        const gl_f2 v = mk(ci, cj) * mk(ri, rj);
+        dx[i] = v.x; dx[j] = v.y;
+    }
+    static __device__ __forceinline__ void run3(float* dx, int i, int j, float ci, float cj, float ti, float tj, float ri, float rj)
+    {
+        const gl_f2 v = mk(ci, cj) * mk(ti, tj) * mk(ri, rj);
+        dx[i] = v.x; dx[j] = v.y;
+    }
+};
+#endif
+
 // The air streams: CO2, vapour and sensible heat carried through the screens (air -> top) and the roof vents (top -> out)
 // are the same three differences times the same two volume fluxes (aux_states.hpp:869-870, 1017-1024, 1201-1209).
 template <class T> struct AirOut { T hAirTop, hTopOut, mvAirTop, mvTopOut, mcAirTop, mcTopOut, vAirOverT; };
@@ -1087,25 +1110,26 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
 
     // ---- balances (ode.hpp:14-121)
     const T L = m.latent;
-    dx[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
-    dx[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
-    dx[2] = m.iCapAir * (hCanAir + hPipeAir + q.swAir - hAirFlr - hAirThScr - hAirOut - hAirTop - hAirBlScr +
-                         hLampAir + q.hGroPipeAir + hIntLampAir);
-    dx[3] = m.iCapTop * (hThScrTop + hAirTop - hTopCovIn - hTopOut + hBlScrTop);
-    dx[4] = q.iCapCan * (q.swCan + fir.can - hCanAir - L * mvCanAir + q.rGroPipeCan + iToCan);
-    dx[5] = m.iCapCov * (hTopCovIn + L * mvTopCovIn + fir.covIn - hCovInCovE + iToCovIn);
-    dx[6] = m.iCapCov * (s.sunCovE + hCovInCovE - hCovEOut + fir.covE);
+    // (the products  capacity^-1 x net flux  are formed two at a time for states that are a register pair in the integrator)
+    Mul2<T>::run(dx, 0, 1, m.iCapCo2Air, m.iCapCo2Top, s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut, mcAirTop - mcTopOut);
+    Mul2<T>::run(dx, 2, 3, m.iCapAir, m.iCapTop,
+                 hCanAir + hPipeAir + q.swAir - hAirFlr - hAirThScr - hAirOut - hAirTop - hAirBlScr + hLampAir + q.hGroPipeAir +
+                     hIntLampAir,
+                 hThScrTop + hAirTop - hTopCovIn - hTopOut + hBlScrTop);
+    Mul2<T>::run(dx, 4, 9, q.iCapCan, m.iCapPipe, q.swCan + fir.can - hCanAir - L * mvCanAir + q.rGroPipeCan + iToCan,
+                 s.hBoilPipe + fir.pipe - hPipeAir + iToPipe);
+    Mul2<T>::run(dx, 5, 6, m.iCapCov, m.iCapCov, hTopCovIn + L * mvTopCovIn + fir.covIn - hCovInCovE + iToCovIn,
+                 s.sunCovE + hCovInCovE - hCovEOut + fir.covE);
     ScreenBlock<T>::balance(sc, L, fir.thScr, fir.blScr, iToThScr, iToBlScr, m, dx[7], dx[20]);
-    dx[8] = m.iCapFlr * (hAirFlr + q.swFlr + fir.flr - q.hFlrSo1 + iToFlr);
-    dx[9] = m.iCapPipe * (s.hBoilPipe + fir.pipe - hPipeAir + iToPipe);
+    Mul2<T>::run(dx, 8, 17, m.iCapFlr, m.iCapLamp, hAirFlr + q.swFlr + fir.flr - q.hFlrSo1 + iToFlr,
+                 s.lampNet - hLampAir + fir.lamp + iToLamp);
     dx[10] = q.dSo1;
     dx[11] = q.dSo2;
     dx[12] = q.dSo3;
     dx[13] = q.dSo4;
     dx[14] = q.dSo5;
-    dx[15] = m.kCapVpAir * tAirK * (mvCanAir - mvAirThScr - mvAirTop - mvAirOut - mvAirBlScr);
-    dx[16] = m.kCapVpTop * tTopK * (mvAirTop - mvTopCovIn - mvTopOut);
-    dx[17] = m.iCapLamp * (s.lampNet - hLampAir + fir.lamp + iToLamp);
+    Mul2<T>::run3(dx, 15, 16, m.kCapVpAir, m.kCapVpTop, tAirK, tTopK, mvCanAir - mvAirThScr - mvAirTop - mvAirOut - mvAirBlScr,
+                  mvAirTop - mvTopCovIn - mvTopOut);
     dx[18] = m.iCapIntLamp * (-hIntLampAir - iToSky - iToCovIn - iToThScr - iToPipe - iToBlScr - iToFlr - iToCan - iToLamp);
     dx[19] = q.dGro;
     if (PIPE) {
