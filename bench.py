@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- TomatoEnv env-steps/sec on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scheme rk4|rk2] [--n-sub S] [--dtype f32|f64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scheme rk4|rk3|rk2] [--n-sub S] [--dtype f32|f64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -14,7 +14,8 @@ Deviation from the config text: "RK4 with 4 sub-steps" diverges (stiff ODE, lamb
 the stability-controlled sub-stepper: environments whose local rate bound needs more take more, smaller sub-steps, and 320 is
 the count at which that stays rare under sustained random actions.  The defaults time 2 000
 steps so that `value` is the sustained rate, not the first milliseconds after a reset.  A second, informational leg
-times the library's explicit-midpoint sub-stepper on the same workload (`other_scheme`).
+times the library's third-order (Bogacki-Shampine) sub-stepper on the same workload (`other_scheme`); `--scheme rk2` times the
+explicit-midpoint one.
 
 Prints ONE JSON line on rank 0.  `value` = all env-steps of all ranks / max-over-ranks wall time.
 """
@@ -61,8 +62,8 @@ def load_pmc():
 
 
 DEFAULT_SCHEME = "rk4"
-STAGES = {"rk4": 4, "rk2": 2}
-N_SUB = {"rk4": 320, "rk2": 376}
+STAGES = {"rk4": 4, "rk2": 2, "rk3": 3}
+N_SUB = {"rk4": 320, "rk2": 376, "rk3": 354}
 
 
 def cpu_baseline(n_sub: int, budget_s: float = 10.0):
@@ -122,9 +123,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
-    ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2"],
-                    help="sub-stepper: classical RK4 (n_sub 320) or explicit midpoint (n_sub 376); include/glgym.h")
-    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 320 rk4 / 376 rk2)")
+    ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2", "rk3"],
+                    help="sub-stepper: classical RK4 (n_sub 320), Bogacki-Shampine (354) or explicit midpoint (376); include/glgym.h")
+    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 320 rk4 / 354 rk3 / 376 rk2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,7 +230,7 @@ def main():
     # (include/glgym.h glgym_scheme), timed the same way right after the main leg.
     alt = None
     if not args.no_alt_scheme:
-        other = "rk2" if args.scheme == "rk4" else "rk4"
+        other = "rk3" if args.scheme == "rk4" else "rk4"
         env.set_scheme(other)
         for i in range(min(W, 2)):
             one_step(i)
@@ -329,8 +330,8 @@ def main():
             "other_scheme": None if alt is None else {
                 "integrator": alt[0], "n_sub": alt[1], "value": B * world * K / alt[2], "unit": "env-steps/s",
                 "ms_per_step": 1e3 * alt[2] / K,
-                "note": "informational: same workload and timing protocol with the library's other sub-stepper (rank-0 "
-                        "clock); accuracy of both vs the tight fixtures in DESIGN.md section 2"},
+                "note": "informational: same workload and timing protocol with the library's third-order sub-stepper "
+                        "(Bogacki-Shampine 3(2), rank-0 clock); accuracy of all schemes vs the tight fixtures in DESIGN.md section 2"},
             "sum_reward": agg["sum_reward"], "ode_failures": agg["ode_failures"],
             "episodes_finished": agg["episodes_finished"],
         }

@@ -1457,12 +1457,13 @@ template <> struct RkVec<float> {
 // ---------------------------------------------------------------------------------------------------
 // The sub-stepper, round 2: STABILITY-CONTROLLED.
 //
-// ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 2 = explicit midpoint
-// (2.0, i.e. 1.0 per stage: the same stability margin with 30 % fewer right-hand sides; second order).  WIN: nominal
+// ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 3 = Bogacki-Shampine
+// (2.513: 0.84 per stage, third order, a true embedded second-order solution), 2 = explicit midpoint (2.0, i.e. 1.0 per
+// stage: the same stability margin with 30 % fewer right-hand sides than RK4; second order).  WIN: nominal
 // number of sub-steps per WINDOW; a window shares one tier-2b evaluation and one pair of harvest half steps.
 //
 // The env-step is n_win = ceil(n_sub / WIN) windows of length hw.  Inside a window every lane takes
-//        n = ceil(t_rem / hs)  equal sub-steps,     hs = min(hw / WIN, S / lam),     S = SC_SAFETY * (2.785 | 2.0),
+//        n = ceil(t_rem / hs)  equal sub-steps,     hs = min(hw / WIN, S / lam),     S = SC_SAFETY * (2.785 | 2.513 | 2.0),
 // lam being the rate bound rhs_fast<RATES> returns with the first stage of the window's first sub-step (that stage is
 // evaluated at the END of the previous sub-step: it is also the comparison stage of the error estimate below) and, once
 // a lane is refined, with the first stage of every sub-step.  A nominal lane (lam * hw / WIN <= S) takes exactly WIN
@@ -1473,7 +1474,8 @@ template <> struct RkVec<float> {
 // a failed CVODES call in the reference (tomato_env.py:119-123) it terminates the episode with the state unchanged.
 // Safety net: an embedded error estimate on the nine fast states.  With k1' = f(y_{n+1}) (= the next sub-step's first
 // stage, free), y* = y_n + h/6 (k1 + 2 k2 + 2 k3 + k1') is a third-order solution, so  e = h/6 |k4 - k1'|  estimates the
-// local error of RK4 (for a mode at the stability limit e ~ 2x the mode's amplitude); midpoint: e = h/6 |k1 - 2 k2 + k1'|.
+// local error of RK4 (for a mode at the stability limit e ~ 2x the mode's amplitude); midpoint: e = h/6 |k1 - 2 k2 + k1'|;
+// Bogacki-Shampine: its own embedded pair, e = h/8 |(-5/9 k1 + 2/3 k2 + 8/9 k3) - k1'|.
 // It is checked at every window boundary (every sub-step once refined); SC_FLAG_ERR makes the guard redo the env-step
 // with 2x, then 4x windows.  oracle/gl_oracle.c (rk_sc_impl) restates all of it.
 // ---------------------------------------------------------------------------------------------------
@@ -1504,11 +1506,12 @@ template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                     int n_sub, T* del, ScStat<T>& st)
 {
-    static_assert(ORDER == 4 || ORDER == 2, "ORDER: 4 (classical RK4) or 2 (explicit midpoint)");
+    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (classical RK4), 3 (Bogacki-Shampine) or 2 (explicit midpoint)");
     using M = Math<T>;
     const int n_win = (n_sub + WIN - 1) / WIN;
     const T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WIN);
-    const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : 2.0));
+    const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
+    const T est_fac = T(ORDER == 3 ? 1.0 / 8.0 : 1.0 / 6.0);
     const T hmin = hnom * T(1.0 / SC_MAX_REFINE);
     T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
     // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 19, 21..26)
@@ -1552,7 +1555,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
             for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * T(sc_itol(j)));
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
-            flags |= (worst * h_last * T(1.0 / 6.0) <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
+            flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
         }
         // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
         T hs = M::min(S * M::rcp(lam), hnom);
@@ -1596,6 +1599,29 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
                         if (p < GL_NPAIR_FAST) r.st(del, r.ld(del) + r.sp(h6) * (r.ld(acc) + r.ld(k)));
                         else r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
+            } else if (ORDER == 3) {
+                // Bogacki-Shampine: k2 = f(y + h/2 k1), k3 = f(y + 3h/4 k2), y+ = y + h (2/9 k1 + 1/3 k2 + 4/9 k3);
+                // est accumulates  -5/9 k1 + 2/3 k2 + 8/9 k3  (the embedded second-order solution, see rk_delta's header)
+                const T h34 = T(0.75) * h;
+#pragma unroll
+                for (int j = 0; j < SC_NFAST; ++j) est[j] = T(-5.0 / 9.0) * k[sc_fast(j)];
+#pragma unroll
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        r.st(acc, r.sp(T(2.0 / 9.0)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int j = 0; j < SC_NFAST; ++j) est[j] += T(2.0 / 3.0) * k[sc_fast(j)];
+#pragma unroll
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        r.st(acc, r.ld(acc) + r.sp(T(1.0 / 3.0)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h34) * r.ld(k)); });
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 for the constant-rate states
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                        if (p < GL_NPAIR_FAST) r.st(del, r.ld(del) + r.sp(h) * (r.ld(acc) + r.sp(T(4.0 / 9.0)) * r.ld(k)));
+                        else r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
             } else {
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] = -k[sc_fast(j)];
@@ -1614,7 +1640,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         sub_step();
         // the last stage (RK4: k4; midpoint: 2 k2 - k1) of the window's last sub-step, for the estimate at the next start
 #pragma unroll
-        for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+        for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
         if (RhsStage<T, PIPE>::UNIFORM_CALLS) {
             // fp64 on the device: the stage is an out-of-line call, and calls are kept wave-uniform -- every lane runs the
             // wave's longest window, lanes that are done take sub-steps of length 0 (same time at wave level: they would
@@ -1631,7 +1657,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 n_steps -= act ? 0 : 1;
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j)
-                    est[j] = !act ? keep[j] : (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+                    est[j] = !act ? keep[j] : (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
             }
         } else {
             for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
@@ -1639,7 +1665,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
                 sub_step();
 #pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(2) * k[sc_fast(j)];
+                for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
             }
         }
         // ---- window end: increment of the window's RK part (harvest excluded), harvest flow

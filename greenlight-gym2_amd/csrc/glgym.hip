@@ -143,9 +143,13 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
         hipLaunchKernelGGL(kf_, grid, block, lds_, st, __VA_ARGS__);                                                   \
     } while (0)
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : 1; };
+// SCH (template argument of the integrating kernels) = GLGYM_SCHEME_*: 0 classical RK4, 1 explicit midpoint (four sub-steps
+// per tier-2b window), 2 Bogacki-Shampine (three)
+constexpr int gl_order(int sch) { return sch == 0 ? 4 : sch == 1 ? 2 : 3; }
+template <class T, int SCH> struct SchemeWin { static constexpr int value = SCH == 0 ? RK4_WINDOW<T>::value : SCH == 1 ? 4 : 3; };
 
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
-// RK2 = true: explicit-midpoint sub-steps with tier 2b and the harvest flow shared by four of them (GLGYM_SCHEME_RK2)
+// SCH = GLGYM_SCHEME_RK2 / _RK3: explicit-midpoint / Bogacki-Shampine sub-steps, tier 2b and the harvest flow shared by four / three of them
 // instead of classical RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.
 // OCC = waves per SIMD the kernel is compiled for.  1 (default): up to 512 registers per lane, no scratch -- the right choice
 // when the batch gives every SIMD one wave (B <= 65 536).  2: 256 registers per lane (spills go to scratch) so that two
@@ -154,7 +158,7 @@ template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) ==
 // (profiles/r02_occupancy2_variant.txt): the spills eat most of it -- B = 131 072: 5.64e7 vs 5.60e7 env-steps/s,
 // B = 262 144: 6.04e7 vs 5.75e7 -- so it is used from four waves per SIMD on; at B = 65 536 the dispatcher packs the 1 024
 // waves two per SIMD onto half the chip (3.1e7).
-template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, bool RK2 = false, int OCC = GL_STEP_WAVES_PER_SIMD>
+template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, int SCH = 0, int OCC = GL_STEP_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
     T del[NX];
     bool bad;
     int extra_steps;
-    const int retries = rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps);
+    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps);
     const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
 // ---------------------------------------------------------------------------------------------------
 // reference-compatible step map / RHS with row-major double I/O (B small; B = 1 for the drop-in evalF)
 // ---------------------------------------------------------------------------------------------------
-template <class T, bool PER_ENV_CROP, bool PIPE = false, bool RK2 = false>
+template <class T, bool PER_ENV_CROP, bool PIPE = false, int SCH = 0>
 __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
                                                      const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
                                                      ModelConst<T> m, double* x_next, int rhs_only, int nd,
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE, RK2 ? 2 : 4, RK2 ? 4 : RK4_WINDOW<T>::value>(x0, s, m, cr, dt, n_sub, del, &failed);
+    rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, dt, n_sub, del, &failed);
     // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
     for (int i = 0; i < NX; ++i)
         x_next[(size_t)b * NX + i] = failed ? __builtin_nan("") : (double)x0[i] + (double)del[i];
@@ -869,7 +873,7 @@ struct glgym_handle_s {
     int* fail_dev = nullptr;            // glgym_evalF: number of rows whose integration failed
     int nd = ND;                        // weather / disturbance row stride: 10, or up to 16 (ODE_pipe reads columns 10, 12)
     int variant = GLGYM_ODE;            // GLGYM_ODE | GLGYM_ODE_PIPE
-    int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2
+    int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
     float du = 0.1f, u_min[NU] = {0, 0, 0, 0, 0, 0}, u_max[NU] = {1, 1, 1, 1, 1, 1};   // glgym_set_control_limits
@@ -985,8 +989,8 @@ int glgym_set_model_variant(glgym_handle h, int variant)
 
 int glgym_set_scheme(glgym_handle h, int scheme)
 {
-    if (!h || (scheme != GLGYM_SCHEME_RK4 && scheme != GLGYM_SCHEME_RK2)) {
-        g_err = "glgym_set_scheme: GLGYM_SCHEME_RK4 or GLGYM_SCHEME_RK2";
+    if (!h || (scheme != GLGYM_SCHEME_RK4 && scheme != GLGYM_SCHEME_RK2 && scheme != GLGYM_SCHEME_RK3)) {
+        g_err = "glgym_set_scheme: GLGYM_SCHEME_RK4, GLGYM_SCHEME_RK2 or GLGYM_SCHEME_RK3";
         return GLGYM_EINVAL;
     }
     h->scheme = scheme;
@@ -1039,6 +1043,18 @@ static int ensure_scratch(glgym_handle h, size_t elems)
     return GLGYM_OK;
 }
 
+template <class T, int SCH>
+static void launch_evalf_sch(glgym_handle h, const ModelConst<T>& m, const double* p_used, const double* dx, const double* du,
+                             const double* dd, const double* dcrop, int B, double* dout, int rhs_only, dim3 grid, dim3 block)
+{
+    if (dcrop)
+        GL_LAUNCH_T((evalf_kernel<T, true, false, SCH>), true, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
+    else
+        GL_LAUNCH_T((evalf_kernel<T, false, false, SCH>), false, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
+}
+
 template <class T>
 static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_used, const double* dx, const double* du,
                      const double* dd, const double* dcrop, int B, double* dout, int rhs_only)
@@ -1046,24 +1062,18 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
     const dim3 grid((B + WAVE - 1) / WAVE), block(WAVE);
     if (h->variant == GLGYM_ODE_PIPE) {
         if (dcrop || h->scheme != GLGYM_SCHEME_RK4) {
-            g_err = "glgym_evalF: GLGYM_ODE_PIPE supports neither per-row parameter blocks nor GLGYM_SCHEME_RK2";
+            g_err = "glgym_evalF: GLGYM_ODE_PIPE supports neither per-row parameter blocks nor schemes other than GLGYM_SCHEME_RK4";
             return GLGYM_EINVAL;
         }
         GL_LAUNCH_T((evalf_kernel<T, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                            T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
     } else if (h->scheme == GLGYM_SCHEME_RK2) {
-        if (dcrop)
-            GL_LAUNCH_T((evalf_kernel<T, true, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt),
-                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
-        else
-            GL_LAUNCH_T((evalf_kernel<T, false, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt),
-                               h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
-    } else if (dcrop)
-        GL_LAUNCH_T((evalf_kernel<T, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
-    else
-        GL_LAUNCH_T((evalf_kernel<T, false>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
+        launch_evalf_sch<T, GLGYM_SCHEME_RK2>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
+    } else if (h->scheme == GLGYM_SCHEME_RK3) {
+        launch_evalf_sch<T, GLGYM_SCHEME_RK3>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
+    } else {
+        launch_evalf_sch<T, GLGYM_SCHEME_RK4>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
+    }
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }
@@ -1146,6 +1156,25 @@ int glgym_rhs(glgym_handle h, const double* x, const double* u, const double* d,
 }  // extern "C"
 
 // ---- device-pointer hot path ----------------------------------------------------------------------
+template <class T, int SCH>
+static void launch_step_sch(const glgym_step_args* a, const StepArgsT<T>& k, const ModelConst<T>& m, const RewardConst<T>& rw,
+                            dim3 grid, dim3 block, hipStream_t st, bool def, bool occ2)
+{
+    if constexpr (sizeof(T) == 4) {      // fp64 never takes the specialised kernels (def is false), so no fp64 OCC = 2 build
+        if (occ2) {
+            GL_LAUNCH_T((step_kernel<T, false, true, false, SCH, 2>), false, grid, block, st, k, m, rw);
+            return;
+        }
+    }
+    if (a->crop_p) {
+        if (def) GL_LAUNCH_T((step_kernel<T, true, true, false, SCH>), true, grid, block, st, k, m, rw);
+        else GL_LAUNCH_T((step_kernel<T, true, false, false, SCH>), true, grid, block, st, k, m, rw);
+    } else {
+        if (def) GL_LAUNCH_T((step_kernel<T, false, true, false, SCH>), false, grid, block, st, k, m, rw);
+        else GL_LAUNCH_T((step_kernel<T, false, false, false, SCH>), false, grid, block, st, k, m, rw);
+    }
+}
+
 template <class T>
 static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelConst<T>& m, const RewardConst<T>& rw,
                        hipStream_t st)
@@ -1162,7 +1191,7 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
     if (h->variant == GLGYM_ODE_PIPE) {
         if (a->crop_p || h->scheme != GLGYM_SCHEME_RK4) {
-            g_err = "glgym_step: GLGYM_ODE_PIPE supports neither per-env crop parameters nor GLGYM_SCHEME_RK2";
+            g_err = "glgym_step: GLGYM_ODE_PIPE supports neither per-env crop parameters nor schemes other than GLGYM_SCHEME_RK4";
             return GLGYM_EINVAL;
         }
         GL_LAUNCH_T((step_kernel<T, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
@@ -1175,32 +1204,9 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // two waves per SIMD pay once the batch holds at least two waves for every SIMD (GLGYM_OCC = 1 | 2 overrides)
     static const int occ_env = [] { const char* e = std::getenv("GLGYM_OCC"); return e ? std::atoi(e) : 0; }();
     const bool occ2 = def && !a->crop_p && (occ_env == 2 || (occ_env == 0 && a->B >= 4 * h->n_simd * WAVE));
-    if constexpr (sizeof(T) == 4) {      // fp64 never takes the specialised kernels (def is false), so no fp64 OCC = 2 build
-        if (occ2) {
-            if (h->scheme == GLGYM_SCHEME_RK2) GL_LAUNCH_T((step_kernel<T, false, true, false, true, 2>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-            else GL_LAUNCH_T((step_kernel<T, false, true, false, false, 2>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-            HIPCHK(hipGetLastError());
-            return GLGYM_OK;
-        }
-    }
-    if (h->scheme == GLGYM_SCHEME_RK2) {
-        if (a->crop_p) {
-            if (def) GL_LAUNCH_T((step_kernel<T, true, true, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-            else GL_LAUNCH_T((step_kernel<T, true, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-        } else {
-            if (def) GL_LAUNCH_T((step_kernel<T, false, true, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-            else GL_LAUNCH_T((step_kernel<T, false, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-        }
-        HIPCHK(hipGetLastError());
-        return GLGYM_OK;
-    }
-    if (a->crop_p) {
-        if (def) GL_LAUNCH_T((step_kernel<T, true, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-        else GL_LAUNCH_T((step_kernel<T, true, false>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-    } else {
-        if (def) GL_LAUNCH_T((step_kernel<T, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-        else GL_LAUNCH_T((step_kernel<T, false, false>), a->crop_p != nullptr, grid, block, st, k, m, rw);
-    }
+    if (h->scheme == GLGYM_SCHEME_RK2) launch_step_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, grid, block, st, def, occ2);
+    else if (h->scheme == GLGYM_SCHEME_RK3) launch_step_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, grid, block, st, def, occ2);
+    else launch_step_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, grid, block, st, def, occ2);
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
 }

@@ -13,21 +13,24 @@ NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 10
 F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
 SCHEME_RK4, SCHEME_RK2 = 0, 1
-SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2}
+SCHEME_RK3 = 2
+SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3}
 # NOMINAL sub-steps per 900 s env-step.  The floor is the 0.67-0.72 1/s cover mode (RK4: 224, midpoint: 302).  The kernels
 # are stability-controlled per environment (gl_model.hpp rk_delta): a lane whose local rate bound exceeds what the nominal
 # sub-step covers (0.91 1/s at 320) takes more, smaller sub-steps in that window -- and at one wave per SIMD the whole
 # launch waits for it.  320 / 376 keep that rare on the bench workload (rate bound above 0.85 1/s in 5e-6 of random-action
 # env-steps on the synthetic weather year, never above 0.91 in 1.9e5); lower counts refine in most launches and end up slower.
-DEFAULT_N_SUB = {"rk4": 320, "rk2": 376}
+DEFAULT_N_SUB = {"rk4": 320, "rk2": 376, "rk3": 354}
+N_SUB_MULTIPLE = {"rk4": 4, "rk2": 4, "rk3": 3}          # widest tier-2b window of the scheme
 
 
 def default_n_sub(scheme: str, dt: float) -> int:
     """Nominal sub-steps per env-step when the caller gives none: the scheme's count for the reference's dt = 900 s,
     scaled with dt so that the nominal sub-step h = dt / n_sub stays the same (2.81 s RK4, 2.39 s midpoint) -- e.g. 108 for
-    the dt = 300 s of experiments/run_time.py; rounded up to a multiple of 4 (the widest tier-2b window)."""
+    the dt = 300 s of experiments/run_time.py; rounded up to a multiple of the scheme's tier-2b window (4, 4, 3)."""
     n = DEFAULT_N_SUB[scheme] * float(dt) / 900.0
-    return max(4, int(-(-n // 4) * 4))
+    mult = N_SUB_MULTIPLE[scheme]
+    return max(mult, int(-(-n // mult) * mult))
 OK, EINVAL, ENODEV, EHIP, ENOMEM, EODE = 0, -1, -2, -3, -4, -5
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",

@@ -162,7 +162,7 @@ class TomatoVecEnv:
                  u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
-        scheme / n_sub: "rk4" (classical RK4, default n_sub 320) or "rk2" (explicit midpoint, default n_sub 376);
+        scheme / n_sub: "rk4" (classical RK4, default n_sub 320), "rk3" (Bogacki-Shampine, 354) or "rk2" (explicit midpoint, 376);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
@@ -196,7 +196,7 @@ class TomatoVecEnv:
         self.f64 = str(dtype) in ("float64", "f64", "double")
         self.tdtype = torch.float64 if self.f64 else torch.float32
         if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'rk4' or 'rk2'")
+            raise ValueError("scheme must be 'rk4', 'rk3' or 'rk2'")
         self.scheme = scheme
         self.n_sub = int(L.default_n_sub(scheme, self.dt) if n_sub is None else n_sub)
         self.uncertainty_scale = float(uncertainty_scale)
@@ -560,9 +560,9 @@ class TomatoVecEnv:
         return replay
 
     def set_scheme(self, scheme: str, n_sub: Optional[int] = None):
-        """Switch the sub-stepper ("rk4" | "rk2", include/glgym.h) and its sub-step count (default: the scheme's own)."""
+        """Switch the sub-stepper ("rk4" | "rk3" | "rk2", include/glgym.h) and its sub-step count (default: the scheme's own)."""
         if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'rk4' or 'rk2'")
+            raise ValueError("scheme must be 'rk4', 'rk3' or 'rk2'")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
         self.scheme = scheme
         self.set_n_sub(L.default_n_sub(scheme, self.dt) if n_sub is None else n_sub)

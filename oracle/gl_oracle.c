@@ -663,7 +663,7 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
     dx[21] = (1.0 / 86400.0) * (xs[4] - xs[21]);
 }
 
-/* order = 4 classical RK4, 3 Kutta's third-order method, 2 explicit midpoint.  window = number of consecutive sub-steps that
+/* order = 4 classical RK4, 3 Bogacki-Shampine's third-order method, 2 explicit midpoint.  window = number of consecutive sub-steps that
  * share one tier-2b evaluation and one harvest half-step pair (1 = every sub-step). */
 static void rk_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                            double *x1, int pipe, int order, int window)
@@ -691,13 +691,13 @@ static void rk_lagged_impl(const double *x0, const double *u, const double *d, c
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
             rhs_lagged(xs, ym, u, d, p, k4, pipe);
             for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-        } else if (order == 3) {
+        } else if (order == 3) {   /* Bogacki-Shampine (GLGYM_SCHEME_RK3) */
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
             rhs_lagged(xs, ym, u, d, p, k2, pipe);
-            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * (2.0 * k2[i] - k1[i]);
+            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.75 * h * k2[i];
             rhs_lagged(xs, ym, u, d, p, k3, pipe);
-            for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 4.0 * k2[i] + k3[i]);
+            for (int i = 0; i < GL_NX; ++i) x[i] += h * ((2.0 / 9.0) * k1[i] + (1.0 / 3.0) * k2[i] + (4.0 / 9.0) * k3[i]);
         } else {
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
@@ -873,7 +873,8 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
     double est[9] = {0};
     const int n_win = (n_sub + window - 1) / window;
     const double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
-    const double S = SC_SAFETY * (order == 4 ? 2.785 : 2.0);
+    const double S = SC_SAFETY * (order == 4 ? 2.785 : order == 3 ? 2.5127 : 2.0);
+    const double est_fac = order == 3 ? 1.0 / 8.0 : 1.0 / 6.0;
     double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0, h_last = hnom;
     int flags = 0;
     const int n_grace = (int)ceil(SC_GRACE_S / hw);
@@ -894,7 +895,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         if (it > 0) {
             double worst = 0.0;
             for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - k1[SC_FAST[j]]) / SC_TOL[j]);
-            worst *= h_last / 6.0;
+            worst *= h_last * est_fac;
             if (getenv("SC_TRACE")) fprintf(stderr, "it %d h %.3f ratio %.4f lam %.3f\n", it, h_last, worst, lam);
             if (it <= n_grace) worst *= 1.0 / SC_GRACE_MUL;
             if (!(worst <= 1.0)) flags |= 4;
@@ -927,6 +928,17 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                 rhs_lagged(xs, ym, u, d, p, k4, pipe);
                 for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
                 for (int j = 0; j < 9; ++j) est[j] = k4[SC_FAST[j]];
+            } else if (order == 3) {
+                /* Bogacki-Shampine 3(2): with k1' = f(y_{n+1}) (the next sub-step's first stage) the embedded second-order
+                 * solution differs from the third-order one by  h (-5/72 k1 + 1/12 k2 + 1/9 k3 - 1/8 k1')  =
+                 * h/8 ((-5/9 k1 + 2/3 k2 + 8/9 k3) - k1') */
+                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
+                rhs_lagged(xs, ym, u, d, p, k2, pipe);
+                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.75 * h * k2[i];
+                rhs_lagged(xs, ym, u, d, p, k3, pipe);
+                for (int i = 0; i < GL_NX; ++i) x[i] += h * ((2.0 / 9.0) * k1[i] + (1.0 / 3.0) * k2[i] + (4.0 / 9.0) * k3[i]);
+                for (int j = 0; j < 9; ++j)
+                    est[j] = (-5.0 / 9.0) * k1[SC_FAST[j]] + (2.0 / 3.0) * k2[SC_FAST[j]] + (8.0 / 9.0) * k3[SC_FAST[j]];
             } else {
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
                 rhs_lagged(xs, ym, u, d, p, k2, pipe);

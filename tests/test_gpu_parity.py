@@ -70,7 +70,7 @@ def test_n_sub_4_is_unstable_and_flagged(golden):
     env.close()
 
 
-@pytest.mark.parametrize("scheme", ["rk4", "rk2"])
+@pytest.mark.parametrize("scheme", ["rk4", "rk2", "rk3"])
 @pytest.mark.parametrize("fixture,dtype,tol", [("rollout_10day", "float64", 5e-6), ("rollout_10day", "float32", 1e-4),
                                                ("rollout_3day_synth", "float64", 5e-6),
                                                ("rollout_3day_synth", "float32", 1e-4)])
@@ -463,7 +463,27 @@ def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
         m.close()
 
 
-@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 1), ("rk2", 2, 4)])
+def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
+    """GLGYM_SCHEME_RK3 (Bogacki-Shampine 3(2), tier 2b and harvest flow shared by three sub-steps) through glgym_evalF against
+    the oracle's independent restatement of the same scheme, and against the tight one-step solutions."""
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight")
+    X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
+    for dtype, tol_o, tol_t in (("float64", 1e-9, 3e-5), ("float32", 3e-5, 4e-5)):          # measured 1.6e-5 in fp64
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk3")
+        assert m.n_sub == 354                  # the scheme's default nominal count
+        got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
+        ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, 354, order=3, window=3) for i in range(len(X))])
+        print(f"rk3 {dtype}: vs oracle scheme {scaled_err(got, ref):.2e}, vs tight {scaled_err(got, XT):.2e}")
+        assert scaled_err(got, ref) < tol_o
+        assert scaled_err(got, XT) < tol_t
+        m.set_n_sub(352)                       # n_sub is rounded up to a multiple of the 3-sub-step window
+        np.testing.assert_array_equal(np.array(m.evalF(X[0], U[0], D[0], P[0])), got[0])
+        m.close()
+    assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3").n_sub == 120 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2").n_sub == 376
+
+
+@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 1), ("rk2", 2, 4), ("rk3", 3, 3)])
 def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win):
     """The fp64 step kernels spill heavily and hipcc 7.2 has miscompiled them before (rk_delta's
     SUM_INCS note): every env-step of a short rollout must agree with the oracle's restatement of the same scheme to
@@ -507,7 +527,7 @@ def test_default_n_sub_scales_with_dt(golden, oracle):
             m.close()
 
 
-@pytest.mark.parametrize("scheme", ["rk4", "rk2"])
+@pytest.mark.parametrize("scheme", ["rk4", "rk2", "rk3"])
 def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
     """From B = 4 x SIMDs x 64 = 262 144 on, float32 default-parameter launches take the `__launch_bounds__(64, 2)` build of
     step_kernel (256 registers, the rest spilled to scratch).  Same source, other register allocation: its results must

@@ -12,7 +12,7 @@ from conftest import scaled_err
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("rk4", 320), ("rk2", 376)]            # the schemes' default nominal sub-step counts
+SCHEMES = [("rk4", 320), ("rk2", 376), ("rk3", 354)]            # the schemes' default nominal sub-step counts
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -57,9 +57,8 @@ def test_storm_step_maps_through_step_kernel(golden, oracle, scheme, n_sub, dtyp
     assert m["n_ode_fail"] == 0 and not done.any()
     assert m["n_refined_substeps"] > 0                           # lanes in the storm took more than n_sub sub-steps
     if dtype == "float64":                                       # the oracle's restatement takes the same sub-steps
-        win = 4 if scheme == "rk2" else 1
-        ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, 4 if scheme == "rk4" else 2,
-                                    win) for i in range(B)]
+        order, win = {"rk4": (4, 1), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
+        ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, order, win) for i in range(B)]
         assert m["n_refined_substeps"] == sum(r_[2] for r_ in ref)
         assert scaled_err(got, np.array([r_[0] for r_ in ref])) < 1e-6        # refined lanes: a ceil() may flip on a last bit
     env.close()
