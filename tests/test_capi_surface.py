@@ -92,10 +92,11 @@ def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
                            f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(csrc / "glgym.hip")])
     s = out.read_text()
     assert "v_mfma" not in s
-    # <T, PER_ENV_CROP, DEFAULT_P, PIPE, RK2, OCC>: the one-wave-per-SIMD builds (OCC = 1) of the classical-RK4 kernels; the
+    # <T, PER_ENV_CROP, DEFAULT_P, PIPE, SCH, OCC>: the one-wave-per-SIMD builds (OCC = 1) of the classical-RK4 kernels (SCH 0) and
+    # the default-parameter Bogacki-Shampine kernel (SCH 2); the
     # OCC = 2 build is limited to 256 registers on purpose and spills to scratch
-    for variant, allow_readlane in (("step_kernelIfLb0ELb1ELb0ELb0ELi1E", False), ("step_kernelIfLb0ELb0ELb0ELb0ELi1E", True),
-                                    ("step_kernelIfLb1ELb1ELb0ELb0ELi1E", False)):
+    for variant, allow_readlane in (("step_kernelIfLb0ELb1ELb0ELi0ELi1E", False), ("step_kernelIfLb0ELb0ELb0ELi0ELi1E", True),
+                                    ("step_kernelIfLb1ELb1ELb0ELi0ELi1E", False), ("step_kernelIfLb0ELb1ELb0ELi2ELi1E", False)):
         m = re.search(r"^(_ZN\S*" + variant + r"\S*):", s, flags=re.M)
         body = s[m.start():]
         body = body[:body.index(".Lfunc_end")]

@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--constants":
     dur = []
     for f in files:
         for r in csv.DictReader(open(f)):
-            if "step_kernel<float, false, true, false, false" not in r.get("Kernel_Name", ""):
+            if "step_kernel<float, false, true, false, 0" not in r.get("Kernel_Name", ""):
                 continue
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     c = {k: sum(v) / len(v) for k, v in vals.items()}

@@ -21,7 +21,7 @@ d = json.load(open("$OUT/pmc_constants.json"))
 durs = []
 for f in glob.glob("$OUT/pmc7/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        if "step_kernel<float, false, true, false, false" in r["Kernel_Name"]:
+        if "step_kernel<float, false, true, false, 0" in r["Kernel_Name"]:
             durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 if durs and "GRBM_GUI_ACTIVE" in d:
     d["kernel_ns_under_pmc"] = sum(durs) / len(durs)
