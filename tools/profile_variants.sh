@@ -24,5 +24,6 @@ run config5_uncertainty --uncertainty 0.2 --steps 200 --warmup 20 --no-alt-schem
 run b524288 --batch 524288 --steps 20 --warmup 3 --no-alt-scheme
 run vecnorm --vecnorm --steps 200 --warmup 20 --no-alt-scheme
 run rk2 --scheme rk2 --steps 200 --warmup 20 --no-alt-scheme
+run rk3 --scheme rk3 --steps 200 --warmup 20 --no-alt-scheme
 run b4096_f32 --batch 4096 --steps 50 --warmup 5 --no-alt-scheme
 run b8_f32 --batch 8 --steps 50 --warmup 5 --no-alt-scheme --no-obs
