@@ -605,20 +605,32 @@ __global__ void crop_noise_kernel(T* crop_p, int B, int ld, const float* p0, flo
 // VecNormalize on the device (HBM-bound: one read pass for the moments, one read + write pass to normalise)
 // ---------------------------------------------------------------------------------------------------
 // pass 1: per-feature sum and sum of squares over the batch.  Thread t owns columns t, t+256, ... (consecutive lanes ->
-// consecutive addresses of a row), walks a strip of rows in registers (fp64), then one atomic pair per column.
+// consecutive addresses of a row), walks a strip of rows in registers (fp64), then one atomic pair per column.  Eight row
+// loads are issued before the first is consumed: with two in flight the pass ran at 1.7 TB/s (41.6 us for 69 MB), the
+// latency-bandwidth product of the chip wants ~60 KB in flight per CU.  The atomics go to one of VN_REP replicas of the
+// accumulator block (merged by vecnorm_merge_kernel): 1 024 blocks x 526 fp64 atomics onto the 33 cache lines of a single
+// block serialise in the L2 -- that, not the read, was most of the pass.
+constexpr int VN_REP = 16;
 __global__ __launch_bounds__(1024) void vecnorm_moments_kernel(const float* __restrict__ obs, int B, int dim,
-                                                               double* __restrict__ acc)
+                                                               double* __restrict__ acc_all)
 {
+    double* acc = acc_all + (size_t)(blockIdx.x % VN_REP) * 2 * dim;
     const int rows_per_block = (B + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {       // blockDim >= dim in practice: one column per thread
         double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
         int r = r0;
-        for (; r + 1 < r1; r += 2) {                            // two independent chains keep loads in flight
-            const double v0 = (double)obs[(size_t)r * dim + c], v1 = (double)obs[(size_t)(r + 1) * dim + c];
-            s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+        for (; r + 7 < r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = obs[(size_t)(r + j) * dim + c];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const double a = (double)v[j], b = (double)v[j + 1];
+                s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+            }
         }
-        if (r < r1) { const double v = (double)obs[(size_t)r * dim + c]; s0 += v; q0 += v * v; }
+        for (; r < r1; ++r) { const double v = (double)obs[(size_t)r * dim + c]; s0 += v; q0 += v * v; }
         if (r1 > r0) { atomicAdd(acc + c, s0 + s1); atomicAdd(acc + dim + c, q0 + q1); }
     }
 }
@@ -644,36 +656,37 @@ __global__ __launch_bounds__(256) void vecnorm_returns_kernel(const T* __restric
     }
 }
 
-// RunningMeanStd.update_from_moments for every feature (and for the scalar return statistics)
-__global__ void vecnorm_merge_kernel(double* mean, double* var, double* count, const double* acc, int dim, int B,
-                                     double* ret_stats, const double* acc2, int do_obs, int do_ret)
+// RunningMeanStd.update_from_moments for every feature (and for the scalar return statistics), then the batch count, then
+// per-column 1/sqrt(var + eps) (fp64, so that pass 2 is two fp64 ops per element) -- ONE block: the count every column
+// reads is updated after a barrier, and scale[c] may overwrite acc[c], which only column c's own thread has read.
+__global__ __launch_bounds__(1024) void vecnorm_merge_kernel(double* mean, double* var, double* count, const double* acc, int dim,
+                                                            int B, double* ret_stats, const double* acc2, int do_obs,
+                                                            int do_ret, double eps, double* scale)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const double n = (double)B;
-    if (do_obs && c < dim) {
-        const double bm = acc[c] / n, bv = fmax(acc[dim + c] / n - bm * bm, 0.0);
-        const double cnt = *count, tot = cnt + n, delta = bm - mean[c];
-        const double m2 = var[c] * cnt + bv * n + delta * delta * cnt * n / tot;
-        mean[c] += delta * n / tot;
-        var[c] = m2 / tot;
+    const double cnt = *count;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        if (do_obs) {
+            double sum = 0.0, sq = 0.0;
+            for (int r = 0; r < VN_REP; ++r) { sum += acc[(size_t)r * 2 * dim + c]; sq += acc[(size_t)r * 2 * dim + dim + c]; }
+            const double bm = sum / n, bv = fmax(sq / n - bm * bm, 0.0);
+            const double tot = cnt + n, delta = bm - mean[c];
+            const double m2 = var[c] * cnt + bv * n + delta * delta * cnt * n / tot;
+            mean[c] += delta * n / tot;
+            var[c] = m2 / tot;
+        }
+        if (scale) scale[c] = 1.0 / sqrt(var[c] + eps);
     }
-    if (do_ret && c == 0) {
+    if (do_ret && threadIdx.x == 0) {
         const double bm = acc2[0] / n, bv = fmax(acc2[1] / n - bm * bm, 0.0);
-        const double cnt = ret_stats[2], tot = cnt + n, delta = bm - ret_stats[0];
-        const double m2 = ret_stats[1] * cnt + bv * n + delta * delta * cnt * n / tot;
+        const double rc = ret_stats[2], tot = rc + n, delta = bm - ret_stats[0];
+        const double m2 = ret_stats[1] * rc + bv * n + delta * delta * rc * n / tot;
         ret_stats[0] += delta * n / tot;
         ret_stats[1] = m2 / tot;
         ret_stats[2] = tot;
     }
-}
-
-__global__ void vecnorm_count_kernel(double* count, int B) { *count += (double)B; }
-
-// per-column 1/sqrt(var + eps), once per call (fp64), so that pass 2 is two fp64 ops per element
-__global__ void vecnorm_scale_kernel(const double* __restrict__ var, double eps, int dim, double* __restrict__ scale)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < dim) scale[c] = 1.0 / sqrt(var[c] + eps);
+    __syncthreads();
+    if (do_obs && threadIdx.x == 0) *count = cnt + n;
 }
 
 // pass 2: clip((x - mean) * scale).  The subtraction stays in fp64 like SB3 (float32 obs - float64 mean): for
@@ -1288,8 +1301,8 @@ extern "C" int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* 
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, dim = a->dim;
     double* acc = a->workspace;
-    double* acc2 = a->workspace + 2 * dim;
-    HIPCHK(hipMemsetAsync(a->workspace, 0, (size_t)(2 * dim + 2) * sizeof(double), st));
+    double* acc2 = a->workspace + (size_t)VN_REP * 2 * dim;
+    HIPCHK(hipMemsetAsync(a->workspace, 0, ((size_t)VN_REP * 2 * dim + 2) * sizeof(double), st));
     const int do_obs = a->training && a->norm_obs, do_ret = a->training && a->reward != nullptr;
     int col_threads = (dim + WAVE - 1) / WAVE * WAVE;       // one thread per observation column
     if (col_threads > 1024) col_threads = 1024;
@@ -1306,16 +1319,12 @@ extern "C" int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* 
             hipLaunchKernelGGL((vecnorm_returns_kernel<double>), dim3((B + 255) / 256), dim3(256), 0, st,
                                (const double*)a->reward, a->returns, B, a->gamma, acc2);
     }
-    if (do_obs || do_ret) {
-        hipLaunchKernelGGL(vecnorm_merge_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, a->obs_mean, a->obs_var,
-                           a->obs_count, acc, dim, B, a->ret_stats, acc2, do_obs, do_ret);
-        if (do_obs) hipLaunchKernelGGL(vecnorm_count_kernel, dim3(1), dim3(1), 0, st, a->obs_count, B);
-    }
+    double* scale = acc;                           // the moment accumulators are dead once their column is merged
+    if (do_obs || do_ret || a->norm_obs)
+        hipLaunchKernelGGL(vecnorm_merge_kernel, dim3(1), dim3(1024), 0, st, a->obs_mean, a->obs_var, a->obs_count, acc, dim, B,
+                           a->ret_stats, acc2, do_obs, do_ret, a->epsilon, a->norm_obs ? scale : nullptr);
     const size_t total = (size_t)B * dim;
     if (a->norm_obs) {
-        double* scale = acc;                       // the moment accumulators are dead after the merge
-        hipLaunchKernelGGL(vecnorm_scale_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, a->obs_var, a->epsilon, dim,
-                           scale);
         int blocks = (B + 15) / 16;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(vecnorm_apply_kernel, dim3(blocks), dim3(col_threads), 0, st, a->obs, a->obs_out, B, dim,

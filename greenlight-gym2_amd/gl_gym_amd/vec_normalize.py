@@ -32,7 +32,7 @@ class VecNormalizeGPU:
         self.obs_count = t.full((1,), 1e-4, **f64)
         self.ret_stats = t.tensor([0.0, 1.0, 1e-4], **f64)
         self.returns = t.zeros(self.num_envs, **f64)
-        self._ws = t.zeros(2 * self.obs_dim + 2, **f64)
+        self._ws = t.zeros(32 * self.obs_dim + 2, **f64)          # glgym_vecnorm_args.workspace
         self.obs_norm_t = t.zeros(self.num_envs, self.obs_dim, dtype=t.float32, device=dev)
         self.reward_norm_t = t.zeros(self.num_envs, dtype=t.float32, device=dev)
         self.old_obs = self.old_reward = None

@@ -250,7 +250,7 @@ typedef struct {
     double* obs_count;         /* [1]   running count  (init 1e-4) */
     double* ret_stats;         /* [3]   mean, var, count of the discounted returns (init 0, 1, 1e-4) */
     double* returns;           /* [B]   discounted return accumulators (init 0) */
-    double* workspace;         /* [2*dim + 2] scratch, zeroed by the call */
+    double* workspace;         /* [32*dim + 2] scratch, zeroed by the call */
     double gamma, epsilon;     /* 0.99, 1e-8 in SB3 */
     float clip_obs, clip_reward;
     int32_t training, norm_obs, norm_reward;
