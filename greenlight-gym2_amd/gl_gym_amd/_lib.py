@@ -10,6 +10,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
 
 NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 10
+METRIC_REPLICAS, METRIC_STRIDE = 64, 32          # glgym.h: the metric accumulators are replicated per cache line
 F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
 SCHEME_RK4, SCHEME_RK2 = 0, 1

@@ -268,7 +268,7 @@ class TomatoVecEnv:
         self.action_t = z(self.B, L.NU, dtype=torch.float32)
         self.obs_t = z(self.B, self.obs_dim, dtype=torch.float32)
         self.term_obs_t = z(self.B, self.obs_dim, dtype=torch.float32)
-        self.metrics_t = z(L.NMETRIC, dtype=torch.float32) if collect_metrics else None
+        self.metrics_t = z(L.METRIC_REPLICAS, L.METRIC_STRIDE, dtype=torch.float32) if collect_metrics else None
         self.crop_T = z(L.NCROP, self.ld) if self.uncertainty_scale > 0 else None
         self._start_rows_t = torch.as_tensor(self.start_rows, dtype=torch.int32, device=dev)
         self._start_days_t = torch.as_tensor(self.start_days, dtype=torch.float32, device=dev)
@@ -505,7 +505,7 @@ class TomatoVecEnv:
     def metrics(self) -> Dict[str, float]:
         if self.metrics_t is None:
             return {}
-        v = self.metrics_t.cpu().numpy()
+        v = self.metrics_t.double().sum(dim=0)[:L.NMETRIC].cpu().numpy()      # sum of the replicas
         return {k: float(v[i]) for i, k in enumerate(L.METRIC_KEYS)}
 
     def capture_step_graph(self, want_obs: bool = True):

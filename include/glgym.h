@@ -50,6 +50,8 @@ extern "C" {
                                n guard retries (env-steps redone with 2x / 4x windows after a non-finite result or an
                                error estimate above tolerance), n refined sub-steps (sub-steps beyond n_sub that the
                                stability control inserted: storms, wet screens pinned to the air temperature) */
+#define GLGYM_METRIC_REPLICAS 64   /* accumulator blocks, one 128-byte line each (atomics onto a single line serialise) */
+#define GLGYM_METRIC_STRIDE 32     /* floats per replica */
 
 typedef struct glgym_handle_s* glgym_handle;
 
@@ -117,7 +119,9 @@ typedef struct {
     void* reward;              /* [ld] T out */
     void* info;                /* SoA [11][ld] T out, order of GLGYM_NINFO */
     uint8_t* done;             /* [B] out: terminated (season end, or ODE failure -> state left unchanged) */
-    float* metrics;            /* [GLGYM_NMETRIC] f32 accumulators (atomicAdd, GLGYM_NMETRIC order) or NULL */
+    float* metrics;            /* [GLGYM_METRIC_REPLICAS][GLGYM_METRIC_STRIDE] f32 accumulators or NULL: wavefront w adds
+                                  its sums (GLGYM_NMETRIC order) to replica w % GLGYM_METRIC_REPLICAS; the reader sums the
+                                  replicas */
 } glgym_step_args;
 
 /* Device-pointer arguments of observation assembly (row-major output, what SB3 / Gymnasium consume). */
