@@ -22,6 +22,8 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
     __shared__ float lds[256];
     float a0 = in[threadIdx.x], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float c = in[64], d = in[65];
+    float vc = c + 0.f * threadIdx.x, vd = d + 0.f * threadIdx.x;     // the same two constants in VGPRs (KIND 14..17)
+    asm volatile("" : "+v"(vc), "+v"(vd));
     lds[threadIdx.x] = a0; lds[threadIdx.x + 64] = a1; lds[threadIdx.x + 128] = a2; lds[threadIdx.x + 192] = a3;
     __syncthreads();
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -67,6 +69,23 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
             a4 = __builtin_amdgcn_rcpf(a4); a5 = __builtin_amdgcn_rcpf(a5); a6 = __builtin_amdgcn_rcpf(a6); a7 = __builtin_amdgcn_rcpf(a7);
         } else if (KIND == 9) {   // 8 x v_mul_f32 with an SGPR operand (uniform constant resident in SGPR)
             a0 *= c; a1 *= c; a2 *= c; a3 *= c; a4 *= c; a5 *= c; a6 *= c; a7 *= c;
+        } else if (KIND == 14) {  // encodings: 8 x v_fmac_f32_e32 (VOP2, 4 bytes; VGPR operands only)
+            asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                         "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vc), "v"(vd));
+        } else if (KIND == 15) {  // 8 x v_add_f32_e32 (VOP2, 4 bytes)
+            asm volatile("v_add_f32_e32 %0, %8, %0\n v_add_f32_e32 %1, %8, %1\n v_add_f32_e32 %2, %8, %2\n v_add_f32_e32 %3, %8, %3\n"
+                         "v_add_f32_e32 %4, %8, %4\n v_add_f32_e32 %5, %8, %5\n v_add_f32_e32 %6, %8, %6\n v_add_f32_e32 %7, %8, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vd));
+        } else if (KIND == 16) {  // 8 x v_add_f32_e64 (VOP3, 8 bytes; same operation)
+            asm volatile("v_add_f32_e64 %0, %8, %0\n v_add_f32_e64 %1, %8, %1\n v_add_f32_e64 %2, %8, %2\n v_add_f32_e64 %3, %8, %3\n"
+                         "v_add_f32_e64 %4, %8, %4\n v_add_f32_e64 %5, %8, %5\n v_add_f32_e64 %6, %8, %6\n v_add_f32_e64 %7, %8, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(vd));
+        } else if (KIND == 17) {  // 8 x v_add_f32_e32 with a 32-bit literal (VOP2 + literal, 8 bytes)
+            asm volatile("v_add_f32_e32 %0, 0x3a83126f, %0\n v_add_f32_e32 %1, 0x3a83126f, %1\n v_add_f32_e32 %2, 0x3a83126f, %2\n"
+                         "v_add_f32_e32 %3, 0x3a83126f, %3\n v_add_f32_e32 %4, 0x3a83126f, %4\n v_add_f32_e32 %5, 0x3a83126f, %5\n"
+                         "v_add_f32_e32 %6, 0x3a83126f, %6\n v_add_f32_e32 %7, 0x3a83126f, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         } else if (KIND == 12) {  // 8 x (cross-lane move from the neighbouring lane + v_fma): what splitting one env over two lanes pays
             a0 = fmaf(a0, c, __shfl_xor(a7, 1)); a1 = fmaf(a1, c, __shfl_xor(a0, 1)); a2 = fmaf(a2, c, __shfl_xor(a1, 1));
             a3 = fmaf(a3, c, __shfl_xor(a2, 1)); a4 = fmaf(a4, c, __shfl_xor(a3, 1)); a5 = fmaf(a5, c, __shfl_xor(a4, 1));
@@ -208,6 +227,10 @@ int main()
     run<12>("(ds_bpermute lane^1 + v_fma) x8", out, in, 16);
     run<13>("(DPP quad_perm lane^1 + v_fma) x8", out, in, 16);
     run_exchange(out, in);
+    run<14>("v_fmac_f32_e32 x8 (4-byte encoding)", out, in, 8);
+    run<15>("v_add_f32_e32 x8 (4-byte encoding)", out, in, 8);
+    run<16>("v_add_f32_e64 x8 (8-byte encoding)", out, in, 8);
+    run<17>("v_add_f32_e32 + literal x8 (8 bytes)", out, in, 8);
     if (getenv("MICROBENCH_ALL")) {
         run<10>("v_fma_f32 x8, 32 of 64 lanes active", out, in, 8);
         run<11>("v_fma_f32 x8, 16 of 64 lanes active", out, in, 8);
