@@ -55,7 +55,7 @@ def one(seed):
     if not np.all(np.isfinite(b)) or sce(a, b).max() > 2e-7:
         return ("notruth", seed, kind)
     res = []
-    for (n, o, wn) in ((320, 4, 2), (320, 4, 1), (376, 2, 4), (354, 3, 3), (321, 4, 3)):
+    for (n, o, wn) in ((320, 4, 2), (320, 4, 1), (376, 2, 4), (354, 3, 3), (321, 4, 3), (356, 3, 2)):
         y, r, ex, f = O.rk_sc_guarded(xs, u, d, p, 900., n, o, wn)
         e = sce(y, b) if np.all(np.isfinite(y)) else np.full(28, np.inf)
         res.append((float(e.max()), int(e.argmax()), r, ex, f))
@@ -70,7 +70,7 @@ if __name__ == "__main__":
     nt = [r for r in R if r[0] == "notruth"]; R = [r for r in R if r[0] != "notruth"]
     print(f"{len(R)} tuples with truth, {len(nt)} without (kinks), {time.time() - t0:.0f} s")
     for k, name in enumerate(("rk4-320 win2 (fp32 kernels' scheme)", "rk4-320 win1 (fp64 kernels')", "midpoint-376 win4",
-                            "bogacki-shampine-354 win3", "rk4-321 win3")):
+                            "bogacki-shampine-354 win3", "rk4-321 win3", "bogacki-shampine-356 win2")):
         E = np.array([r[3][k][0] for r in R]); fails = sum(r[3][k][4] for r in R); ref = sum(r[3][k][3] > 0 for r in R)
         ret = sum(r[3][k][2] for r in R)
         print(f"{name}: err median {np.median(E):.1e} 99% {np.quantile(E, .99):.1e} max {E.max():.1e}; > 1e-4 (not flagged): "
