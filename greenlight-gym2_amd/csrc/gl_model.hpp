@@ -65,6 +65,68 @@ constexpr int CROP0 = 128;
 template <class T> struct Math;
 template <class T> GL_HD T ceil_pos(T v) { return T(::ceil(v)); }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_F64_LIBM)
+// fp64 on the device: lean versions of the four primitives that dominate an fp64 stage (15 exp, 8 log, 14 divisions were
+// 1 100 of its 1 800 instructions through ocml, most of it special-case handling this path never meets: arguments are
+// finite, |exp argument| < 700, log / rcp arguments positive and normal; the one zero that does occur -- wind = 0 in the
+// cover's outside exchange law -- is handled in powa).  1-2 ulp; the fp64 kernels stay within 1e-11 of
+// the oracle (libm) over whole rollouts (tests/test_gpu_parity.py).  -DGL_F64_LIBM restores the library calls.
+__device__ __forceinline__ double gl_rcp_f64(double v)
+{
+    const double x0 = __builtin_amdgcn_rcp(v);              // v_rcp_f64: ~2^-26
+    double e = __builtin_fma(-v, x0, 1.0), x = __builtin_fma(x0, e, x0);
+    e = __builtin_fma(-v, x, 1.0); x = __builtin_fma(x, e, x);
+    return __builtin_isfinite(x) ? x : x0;                  // 1/inf = 0, 1/0 = inf: the refinement would make them NaN
+}
+__device__ __forceinline__ double gl_exp_f64(double v)
+{
+    const double n = __builtin_rint(v * 1.4426950408889634);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, v);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);          // |r| <= 0.3466
+    double p = 1.0 / 6227020800.0;                                  // Taylor to r^13: remainder < 5e-18
+    p = __builtin_fma(p, r, 1.0 / 479001600.0); p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);   p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);     p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);       p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);        p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);               p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+__device__ __forceinline__ double gl_log_f64(double v)
+{
+    int e = __builtin_amdgcn_frexp_exp(v);
+    double m = __builtin_amdgcn_frexp_mant(v);                      // [0.5, 1)
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? m + m : m; e = lo ? e - 1 : e;                         // [sqrt(1/2), sqrt(2))
+    const double s = (m - 1.0) * gl_rcp_f64(m + 1.0), z = s * s;   // |s| <= 0.1716
+    double p = 1.0 / 21.0;                                          // atanh series to s^21: remainder < 1e-17
+    p = __builtin_fma(p, z, 1.0 / 19.0); p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);  p = __builtin_fma(p, z, 1.0 / 5.0);  p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double t = s * z * p;                                     // ln m = 2 (s + t)
+    const double fe = (double)e;
+    return __builtin_fma(fe, 6.93147180369123816490e-01, __builtin_fma(fe, 1.90821492927058770002e-10, 2.0 * t) + 2.0 * s);
+}
+template <> struct Math<double> {
+    static GL_HD double exp(double v) { return gl_exp_f64(v); }
+    static GL_HD double expk(double c, double v) { return gl_exp_f64(c * v); }      // exp(c*v)
+    static GL_HD double log(double v) { return gl_log_f64(v); }
+    static GL_HD double rcp(double v) { return gl_rcp_f64(v); }
+    static GL_HD double sqrt(double v) { return ::sqrt(v); }
+    // av^e as exp(e ln av), av >= 1e-10: |e ln av| < 8, so the result is within a few ulp of pow() at a fraction of its
+    // instructions (ocml's pow carries a double-double logarithm for arbitrary exponents)
+    static GL_HD double powa(double av, double e)          // 0^e = 0 (calm: wind = 0); NaN stays NaN.  Branch-free on purpose:
+    {                                                      // with the evaluation inside the conditional hipcc emits 8 branches per stage
+        const double r = gl_exp_f64(e * gl_log_f64(av > 0.0 ? av : 1.0));
+        return av > 0.0 ? r : (av == 0.0 ? 0.0 : av);
+    }
+    static GL_HD double abs(double v) { return ::fabs(v); }
+    static GL_HD double min(double a, double b) { return ::fmin(a, b); }
+    static GL_HD double max(double a, double b) { return ::fmax(a, b); }
+    static GL_HD double expm1(double v) { return ::expm1(v); }
+};
+#else
 template <> struct Math<double> {
     static GL_HD double exp(double v) { return ::exp(v); }
     static GL_HD double expk(double c, double v) { return ::exp(c * v); }      // exp(c*v)
@@ -72,8 +134,6 @@ template <> struct Math<double> {
     static GL_HD double rcp(double v) { return 1.0 / v; }
     static GL_HD double sqrt(double v) { return ::sqrt(v); }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_F64_LIBM_POW)
-    // av^e as exp(e ln av), av >= 1e-8: |e ln av| < 7, so the result is within ~3 ulp of pow() at less than half its
-    // instructions (ocml's pow carries a double-double logarithm for arbitrary exponents: 8 calls were 40 % of an fp64 stage)
     static GL_HD double powa(double av, double e) { return ::exp(e * ::log(av)); }
 #else
     static GL_HD double powa(double av, double e) { return ::pow(av, e); }   // av >= 0
@@ -83,6 +143,7 @@ template <> struct Math<double> {
     static GL_HD double max(double a, double b) { return ::fmax(a, b); }
     static GL_HD double expm1(double v) { return ::expm1(v); }
 };
+#endif
 
 template <> struct Math<float> {
 #if defined(__HIP_DEVICE_COMPILE__)
