@@ -139,7 +139,8 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
     do {                                                                                                               \
         auto kf_ = kern;                                                                                               \
         const size_t lds_ = sizeof(T) == 8 ? glm::gl_f64_lds_bytes(crop) : 0;                                           \
-        if (lds_) (void)hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+        static size_t set_ = 0;                /* per kernel instantiation (one device per process) */                    \
+        if (lds_ > set_) { (void)hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); set_ = lds_; } \
         hipLaunchKernelGGL(kf_, grid, block, lds_, st, __VA_ARGS__);                                                   \
     } while (0)
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : 1; };

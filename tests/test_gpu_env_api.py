@@ -202,14 +202,15 @@ def test_step_rule_based_closed_loop_matches_host_mirror(golden):
 
 
 @pytest.mark.gpu
-def test_step_graph_replay_equals_eager_steps(golden):
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_step_graph_replay_equals_eager_steps(golden, dtype):
     """capture_step_graph(): the five launches of a step replayed from one HIP graph give bit-identical tensors to
     step_tensor, across an episode boundary (auto-reset inside the graph)."""
     import torch
     from gl_gym_amd.tomato_env import TomatoVecEnv
     w = golden("rollout_10day")["weather"]
-    kw = dict(weather=w, dtype="float32", season_length=0.05, start_rows=[0, 40, 300], start_days=[0.0, 0.4167, 3.125], seed=3)
-    a, b = TomatoVecEnv(200, **kw), TomatoVecEnv(200, **kw)
+    kw = dict(weather=w, dtype=dtype, season_length=0.05, start_rows=[0, 40, 300], start_days=[0.0, 0.4167, 3.125], seed=3)
+    a, b = TomatoVecEnv(200, **kw), TomatoVecEnv(200, **kw)      # float64: the kernels carry 73 KB of dynamic LDS
     a.reset_tensor(); b.reset_tensor()
     replay = b.capture_step_graph()
     assert torch.equal(a.x_T, b.x_T) and torch.equal(a.timestep_t, b.timestep_t)     # capture left the state alone
