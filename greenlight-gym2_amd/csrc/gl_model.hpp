@@ -991,7 +991,7 @@ template <> struct Mul2<float> {
 
 // The air streams: CO2, vapour and sensible heat carried through the screens (air -> top) and the roof vents (top -> out)
 // are the same three differences times the same two volume fluxes (aux_states.hpp:869-870, 1017-1024, 1201-1209).
-template <class T> struct AirOut { T hAirTop, hTopOut, mvAirTop, mvTopOut, mcAirTop, mcTopOut, vAirOverT; };
+template <class T> struct AirOut { T hAirTop, hTopOut, mvAirTop, mvTopOut, mcAirTop, mcTopOut; };
 template <class T> struct AirBlock {
     static GL_HD void run(T fScrAbs, T fRoofAbs, T tAir, T tTop, T co2Air, T co2Top, T vAirOverT, T vTopOverT,
                           const StepCoef<T>& s, const ModelConst<T>& m, AirOut<T>& o)

@@ -69,7 +69,7 @@ def _torch():
     return torch
 
 
-def _observation_modules(Np, names):
+def _observation_modules(Np, names):       # TomatoVecEnv.__init__ has a keyword argument of the same name as the function
     return observation_modules(Np, names)
 
 
