@@ -272,7 +272,13 @@ def main():
             valu, trans = pmc["SQ_INSTS_VALU"] * scale, pmc["SQ_INSTS_VALU_TRANS_F32"] * scale
             fma, mul, add = (pmc[k] * scale for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32",
                                                       "SQ_INSTS_VALU_ADD_F32"))
-            clock_hz = pmc["clock_ghz"] * 1e9
+            # Shader clock of THIS run.  The recorded passes give the clock under the profiler (GRBM_GUI_ACTIVE / kernel time)
+            # and, independent of any clock, the cycles one wave spends in the kernel (SQ_WAVE_CYCLES counts 4-cycle
+            # quanta, summed over the 1 024 waves).  Unprofiled the kernel finishes sooner than those cycles would take
+            # at the profiler's clock, so the live clock is at least cycles-per-wave / live kernel time: take the larger of
+            # the two (the smaller fraction).
+            wave_cycles = 4.0 * pmc["SQ_WAVE_CYCLES"] / 1024.0 * (args.n_sub / 320.0) * max(1.0, B / 65536.0)   # rounds of waves
+            clock_hz = max(pmc["clock_ghz"] * 1e9, wave_cycles / (kern_ms_max * 1e-3))
             avail = N_SIMD * kern_ms_max * 1e-3 * clock_hz                 # SIMD-cycles in one launch
             roof.update({
                 # executed fp32 flops (64 lanes; FMA = 2; packed ops are counted once by the PMC, so this is a lower bound)
@@ -287,7 +293,9 @@ def main():
                                   "(transcendental 8.4), so this -- not `frac` -- is how close the kernel is to the ceiling "
                                   "its launch geometry allows",
                 "traffic": pmc["traffic_bytes"] * (B / 65536.0),
-                "valu_insts_per_launch": valu, "trans_insts_per_launch": trans, "clock_ghz": pmc["clock_ghz"],
+                "valu_insts_per_launch": valu, "trans_insts_per_launch": trans, "clock_ghz": clock_hz * 1e-9,
+                "clock_note": "max(clock under the profiler = %.3f GHz, recorded cycles per wave / live kernel time)"
+                              % pmc["clock_ghz"],
                 "pmc_source": pmc.get("source"),
             })
         roof.update({
