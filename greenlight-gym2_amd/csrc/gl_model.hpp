@@ -1049,9 +1049,12 @@ T sc_pinned_rate(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth,
 
 // RATES = true additionally returns in *lam an upper bound on the fastest relaxation rate [1/s] at this state, from
 // quantities the evaluation has in hand anyway (the stability control of rk_delta; derivation at rk_delta).
+// With RATES, *side additionally reports where the three wet surfaces (inner cover face / thermal screen / blackout screen:
+// j = 0, 1, 2) stand relative to their air node -- the branch invariant of rk_delta: bit 3 + j = the surface is below the air
+// (dT > 0), bit j = it is above the air INSIDE THE BISTABLE REGIME with positive drive (see sc_side below).
 template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false, bool RATES = false>
 GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                    const CropConst<T>& cr, T* dx, T* lam = nullptr)
+                    const CropConst<T>& cr, T* dx, T* lam = nullptr, int* side = nullptr)
 {
     using M = Math<T>;
     const T one = T(1), eps = T(1e-10), third = T(1.0 / 3.0);
@@ -1236,16 +1239,29 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         // ... and could the equilibrium it may be pinned at (second pass below) relax faster than 0.1 1/s at all?  With
         // G >> dT_eq that rate is (kap G)^3 / (3 rfree^2); a condensing cover, for one, is "harmful" by the first test
         // most of the time but sits on 804 J K-1 m-2: 1e-3 1/s.
-        auto harmful = [&](T iCap, T hcoef, T hec, T g, T tSurf, T dT, T ddT) {
+        // Branch invariant (round 3).  d(dT)/dt = rfree - kap |dT|^(1/3) (dT + G) is BISTABLE for 0 < rfree < kap (G/4)^(1/3) (3G/4):
+        // next to the pinned equilibrium at dT_eq > 0 there is a second stable one near dT = -G (surface above the air, kept
+        // warm by condensation), separated by an unstable root at about -dT_eq.  At dT = 0 the vector field equals rfree, so
+        // the true solution cannot pass from dT > 0 to dT < 0 while rfree > 0; an explicit step that overshoots the landing
+        // (or goes unstable at the refinement cap) does, and then STAYS on the wrong branch: finite, smooth, kelvins off.
+        // sbits: bit 3 + j = surface j below its air node, bit j = above it inside the bistable regime with positive drive.
+        // rk_delta flags a window that took a surface from the first to the second.  (Cubes instead of the cube root.)
+        int sbits = 0;
+        auto harmful = [&](T iCap, T hcoef, T hec, T g, T tSurf, T dT, T ddT, int j) {
             const T tc = M::min(M::max(M::abs(tSurf), T(2)), T(40));
-            const T kG = iCap * M::abs(hcoef) * LK * M::max(g, T(0));
+            const T kap = iCap * M::abs(hcoef), G = LK * M::max(g, T(0));
+            const T kG = kap * G;
             const T rfree = ddT + iCap * hec * (dT + LK * g);
+            const T kG3 = kG * kG * kG;
+            sbits |= (dT > T(0)) ? (8 << j) : 0;
+            sbits |= ((dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
             return (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
-                   (kG * kG * kG > T(0.3) * rfree * rfree);
+                   (kG3 > T(0.3) * rfree * rfree);
         };
-        const bool harm5 = harmful(m.iCapCov, m.cTopCov, hTopCovAbs, gCov, tCovIn, dTopCov, dx[3] - dx[5]);
-        const bool harm7 = harmful(m.iCapThScr, s.hTh, hecAirTh, gTh, tThScr, dATh, dx[2] - dx[7]);
-        const bool harm20 = harmful(m.iCapBlScr, s.hBl, hecAirBl, gBl, tBlScr, dABl, dx[2] - dx[20]);
+        const bool harm5 = harmful(m.iCapCov, m.cTopCov, hTopCovAbs, gCov, tCovIn, dTopCov, dx[3] - dx[5], 0);
+        const bool harm7 = harmful(m.iCapThScr, s.hTh, hecAirTh, gTh, tThScr, dATh, dx[2] - dx[7], 1);
+        const bool harm20 = harmful(m.iCapBlScr, s.hBl, hecAirBl, gBl, tBlScr, dABl, dx[2] - dx[20], 2);
+        if (side) *side = sbits;
         T row5 = m.iCapCov * (base5 + f43 * hTopCovAbs);
         T r7 = m.iCapThScr * (base7 + f43 * hecAirTh);
         T r20 = m.iCapBlScr * (base20 + f43 * hecAirBl);
@@ -1303,7 +1319,7 @@ extern __shared__ double gl_lds64[];
 #endif
 // per-lane slots: stage state in / derivative out (shared), rate bound, StepCoef, SlowCoef; then three uniform slots (ModelConst
 // + the per-env-crop flag); then, only for kernels with per-env crop parameters, the per-lane CropConst
-constexpr int GL_F64_X = 0, GL_F64_K = 0, GL_F64_LAM = NX, GL_F64_S = NX + 1;
+constexpr int GL_F64_X = 0, GL_F64_K = 0, GL_F64_LAM = NX, GL_F64_SIDE = NX + 1, GL_F64_S = NX + 2;
 constexpr int GL_F64_NS = (int)(sizeof(StepCoef<double>) / 8), GL_F64_NQ = (int)(sizeof(SlowCoef<double>) / 8),
               GL_F64_NCR = (int)(sizeof(CropConst<double>) / 8), GL_F64_NM = (int)(sizeof(ModelConst<double>) / 8);
 constexpr int GL_F64_Q = GL_F64_S + GL_F64_NS, GL_F64_MSLOT = GL_F64_Q + GL_F64_NQ;
@@ -1353,10 +1369,11 @@ __device__ __noinline__ inline void rhs_stage_f64()
     StepCoef<double> s; SlowCoef<double> q; CropConst<double> cr; ModelConst<double> m;
     f64_get(s, GL_F64_S); f64_get(q, GL_F64_Q); f64_get_model(m); f64_get_crop(cr, m);
     double lam = RATES ? gl_lds64[GL_F64_LAM * 64 + threadIdx.x] : 0.0;
-    rhs_fast<double, false, PIPE, RATES>(x, q, s, m, cr, dx, RATES ? &lam : nullptr);
+    int side = 0;
+    rhs_fast<double, false, PIPE, RATES>(x, q, s, m, cr, dx, RATES ? &lam : nullptr, RATES ? &side : nullptr);
 #pragma unroll
     for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x] = dx[i];
-    if (RATES) gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = lam;
+    if (RATES) { gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = lam; gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] = (double)side; }
 }
 __device__ __noinline__ inline void slow_coef_f64()
 {
@@ -1374,9 +1391,9 @@ template <class T, bool PIPE> struct RhsStage {
     static GL_HD void begin(const StepCoef<T>&, const ModelConst<T>&, const CropConst<T>&) {}
     template <bool RATES>
     static GL_HD void run(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                          const CropConst<T>& cr, T* dx, T* lam)
+                          const CropConst<T>& cr, T* dx, T* lam, int* side)
     {
-        rhs_fast<T, false, PIPE, RATES>(x, q, s, m, cr, dx, lam);
+        rhs_fast<T, false, PIPE, RATES>(x, q, s, m, cr, dx, lam, side);
     }
     static GL_HD void slow(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
                            SlowCoef<T>& q)
@@ -1401,7 +1418,7 @@ template <bool PIPE> struct RhsStage<double, PIPE> {
     }
     template <bool RATES>
     static __device__ void run(const double* x, const SlowCoef<double>&, const StepCoef<double>&,
-                               const ModelConst<double>&, const CropConst<double>&, double* dx, double* lam)
+                               const ModelConst<double>&, const CropConst<double>&, double* dx, double* lam, int* side)
     {
 #pragma unroll
         for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] = x[i];
@@ -1409,7 +1426,7 @@ template <bool PIPE> struct RhsStage<double, PIPE> {
         rhs_stage_f64<PIPE, RATES>();
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[i] = gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x];
-        if (RATES) *lam = gl_lds64[GL_F64_LAM * 64 + threadIdx.x];
+        if (RATES) { *lam = gl_lds64[GL_F64_LAM * 64 + threadIdx.x]; *side = (int)gl_lds64[GL_F64_SIDE * 64 + threadIdx.x]; }
     }
     // q stays in the mailbox (run() reads it there); only the slow-slot entries of ym are defined, the rest is not read
     static __device__ void slow(const double* ym, const StepCoef<double>&, const ModelConst<double>&,
@@ -1424,9 +1441,9 @@ template <bool PIPE> struct RhsStage<double, PIPE> {
 #endif
 template <class T, bool PIPE = false, bool RATES = false>
 GL_HD void rhs_stage(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                     const CropConst<T>& cr, T* dx, T* lam = nullptr)
+                     const CropConst<T>& cr, T* dx, T* lam = nullptr, int* side = nullptr)
 {
-    RhsStage<T, PIPE>::template run<RATES>(x, q, s, m, cr, dx, lam);
+    RhsStage<T, PIPE>::template run<RATES>(x, q, s, m, cr, dx, lam, side);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1550,7 +1567,7 @@ template <> struct RkVec<float> {
 #define SC_GRACE_MUL 64.0
 #define SC_CAP_S 120.0
 #define SC_MOVE 32.0
-constexpr int SC_FLAG_CAP = 1, SC_FLAG_NONFINITE = 2, SC_FLAG_ERR = 4;
+constexpr int SC_FLAG_CAP = 1, SC_FLAG_NONFINITE = 2, SC_FLAG_ERR = 4, SC_FLAG_BRANCH = 8;
 constexpr int SC_NFAST = 9;
 GL_HD constexpr int sc_fast(int j) { return j == 0 ? 1 : j == 1 ? 3 : j == 2 ? 5 : j == 3 ? 6 : j == 4 ? 7 : j == 5 ? 15 : j == 6 ? 16 : j == 7 ? 17 : 20; }
 // 1 / tolerance of the per-sub-step error estimate: co2Top 12.5 mg m-3, temperatures 0.125 K (lamp 0.5 K), vapour
@@ -1597,11 +1614,16 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         for (int p = 0; p < GL_NPAIR; ++p)
             RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(y, r.ld(x0) + r.ld(del)); });
     };
-    for (int it = 0; it < n_win; ++it) {
+    int side_prev = 0;
+    // n_win windows + one closing evaluation at the final state (it == n_win): the error estimate of the last sub-step and the
+    // branch invariant of the last window (round 2 left that tail unchecked)
+    for (int it = 0; it <= n_win; ++it) {
         // A rate beyond SC_MAX_REFINE x the nominal one is followed at the finest sub-step (the seconds before a cold, wet
-        // surface crosses the air temperature); only one that PERSISTS is unresolvable: reported as a failed integration
+        // surface crosses the air temperature); one that PERSISTS is unresolvable at this n_sub: the guard retries finer
         flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
-        if (flags & SC_FLAG_CAP) break;
+        // (fp64 on the device keeps its out-of-line calls wave-uniform: a capped lane runs on, its result is discarded anyway
+        // and its sub-steps are no longer counted)
+        if ((flags & SC_FLAG_CAP) && !RhsStage<T, PIPE>::UNIFORM_CALLS) break;
         // ---- window start: tier 2b at the predicted window midpoint  y + (previous window's increment) / 2, then the
         // first stage of the window's first sub-step together with the rate bound (the only place it is evaluated)
         state_now();
@@ -1610,7 +1632,12 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             if (gl_slow_slot(i) >= 0) { xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)]; dwin[gl_slow_slot(i)] = del[i]; }
         RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
         T lam = hnom;                                             // in: nominal sub-step; out: the rate bound
-        rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam);
+        int side = 0;
+        rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam, &side);
+        // branch invariant (rhs_fast<RATES>): a wet surface that was below its air node at the last look and now sits above
+        // it inside the bistable regime with positive drive has jumped branches
+        flags |= (((side_prev >> 3) & side & 7) != 0) ? SC_FLAG_BRANCH : 0;
+        side_prev = side;
         if (it > 0) {                                             // embedded error estimate of the previous sub-step
             T worst = T(0);
 #pragma unroll
@@ -1618,6 +1645,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
             flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
         }
+        if (it == n_win) break;
         // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
         T hs = M::min(S * M::rcp(lam), hnom);
         {   // accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by
@@ -1694,7 +1722,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int p = 0; p < GL_NPAIR; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
             }
-            ++n_steps;
+            n_steps += (flags & SC_FLAG_CAP) ? 0 : 1;
         };
         // the first sub-step uses the stage evaluated above; every further one starts with its own first stage (written
         // as two loops so that the compiler cannot hoist that evaluation above the exit test of the previous sub-step)
@@ -1715,7 +1743,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 state_now();
                 rhs_stage<T, PIPE>(y, q, s, m, cr, k);
                 sub_step();
-                n_steps -= act ? 0 : 1;
+                n_steps -= (act || (flags & SC_FLAG_CAP)) ? 0 : 1;
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j)
                     est[j] = !act ? keep[j] : (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
@@ -1743,13 +1771,25 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Guard.  The stability control above keeps every lane inside its scheme's stability region; what is left is the
-// unforeseen: a non-finite result or an error estimate above tolerance.  Such an env-step is redone from x0 with 2x,
-// then 4x windows; a lane that still fails, or whose rate bound asked for more than SC_MAX_REFINE x the nominal
-// sub-step count (not retried: halving h does not rescue a surface pinned at > 15 1/s), is reported as a failed
-// integration -- the reference's behaviour for a failed CVODES call (tomato_env.py:119-123).
+// Guard, round 3.  An attempt is UNVERIFIED when rk_delta flagged it (rate beyond the refinement cap for too long, non-finite,
+// error estimate above tolerance, a wet surface changed sides inside the bistable regime) or when it took SC_HEAVY x the nominal
+// number of sub-steps (the scheme knew it was in trouble).  An unverified env-step is redone from x0 with 2x, 4x, 8x windows
+// and accepted as soon as an attempt is clean, or as soon as two consecutive COMPLETE attempts agree on the nine fast states to
+// SC_AGREE x the estimate tolerances (1.25e-4 K, 1.25e-2 Pa / mg m-3): step doubling.  Otherwise it is a failed integration --
+// the reference's behaviour for a failed CVODES call (tomato_env.py:119-123).
+// verify = true: NO attempt is accepted on its own; the result is the finer of two agreeing attempts (at least n_sub and
+// 2 n_sub: 3x the work).  The C ABI integrates that way wherever the control is not bounded by delta_u_max -- glgym_evalF,
+// glgym_step(control = ...), i.e. step_raw_control and the rule-based controller (tomato_env.py:148-173, baseline.py:68-227):
+// after an all-actuator jump RK4 near its stability limit damps the fast transients too slowly (amplification 0.65 per
+// sub-step where the exact flow has 0.08), and where a wet surface lands on its pinned equilibrium seconds later that path
+// error alone can put it on the other branch with every check of rk_delta green (oracle/studies/stress_jump.py, seed 5265:
+// 4 refined sub-steps, cover 1.6 K off).  Round 2 accepted any unflagged attempt and never retried a cap hit.
 // Returns the number of extra attempts used (0 in the common case); *extra_steps = sub-steps beyond n_sub, all attempts.
+// oracle/gl_oracle.c (gl_oracle_rk_sc_guarded2) restates it.
 // ---------------------------------------------------------------------------------------------------
+#define SC_HEAVY 3
+#define SC_AGREE 1e-3
+#define SC_ATTEMPTS 4
 template <class T> GL_HD bool all_finite(const T* v)
 {
     T chk = T(0);
@@ -1760,22 +1800,47 @@ template <class T> GL_HD bool all_finite(const T* v)
 
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                            int n_sub, T* del, bool* failed, int* extra_steps = nullptr)
+                            int n_sub, T* del, bool* failed, int* extra_steps = nullptr, bool verify = false)
 {
+    using M = Math<T>;
+    constexpr bool UNIFORM = RhsStage<T, PIPE>::UNIFORM_CALLS;
     int n = n_sub, extra = 0, total = 0;
-    bool ok = false;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    bool done = false, ok = false, have_prev = false;
+    T prev[SC_NFAST];
+#pragma unroll
+    for (int j = 0; j < SC_NFAST; ++j) prev[j] = T(0);
+    for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
+        // fp64 on the device: every lane of the wave runs the attempt while any lane needs it (wave-uniform out-of-line calls);
+        // lanes that are done keep their accepted result
+        if (UNIFORM ? !GL_WAVE_ANY(!done) : done) break;
         ScStat<T> st;
-        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del, st);
-        total += st.n_steps;
-        ok = all_finite(del) && st.flags == 0;
-        if (ok || (st.flags & SC_FLAG_CAP)) break;
+        T tmp[NX];
+        T* dst = UNIFORM ? tmp : del;
+        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, dst, st);
+        if (!done) {
+            if (UNIFORM) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) del[i] = tmp[i];
+            }
+            total += st.n_steps;
+            const int n_nom = ((n + WIN - 1) / WIN) * WIN;
+            const bool complete = all_finite(del) && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE));
+            const bool clean = complete && st.flags == 0 && st.n_steps < SC_HEAVY * n_nom;
+            T worst = T(0);
+#pragma unroll
+            for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(del[sc_fast(j)] - prev[j]) * T(sc_itol(j)));
+            ok = (clean && !verify) || (complete && have_prev && worst <= T(SC_AGREE));
+            done = ok || attempt == SC_ATTEMPTS - 1;
+            have_prev = complete;
+#pragma unroll
+            for (int j = 0; j < SC_NFAST; ++j) prev[j] = del[sc_fast(j)];
+            extra += done ? 0 : 1;
+        }
         n *= 2;
-        ++extra;
     }
     *failed = !ok;
     if (extra_steps) { const int ex = total - ((n_sub + WIN - 1) / WIN) * WIN; *extra_steps = ex > 0 ? ex : 0; }
-    return ok ? extra : (extra > 2 ? 2 : extra);
+    return extra;
 }
 
 template <class T, bool PIPE = false>

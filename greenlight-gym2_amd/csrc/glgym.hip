@@ -107,6 +107,7 @@ template <class T> struct StepArgsT {
     T gasR, tCanMin;
     int nd;                     // weather row stride (10, or 14 with the measured-pipe columns of ODE_pipe)
     float du, u_min[NU], u_max[NU];      // action_to_control: clip(u + action * delta_u_max, u_min, u_max)
+    int verify;                 // 1: step-doubling verified integration (rk4_delta_guarded), see glgym_set_verify
 };
 
 template <class T> __device__ __forceinline__ T wave_sum(T v)
@@ -139,8 +140,11 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
     do {                                                                                                               \
         auto kf_ = kern;                                                                                               \
         const size_t lds_ = sizeof(T) == 8 ? glm::gl_f64_lds_bytes(crop) : 0;                                           \
-        static size_t set_ = 0;                /* per kernel instantiation (one device per process) */                    \
-        if (lds_ > set_) { (void)hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); set_ = lds_; } \
+        /* the attribute is per device: set it on every launch that needs it (cheap), and report a refusal */            \
+        if (lds_ > 0) {                                                                                                \
+            const hipError_t ea_ = hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+            if (ea_ != hipSuccess) g_err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea_); \
+        }                                                                                                              \
         hipLaunchKernelGGL(kf_, grid, block, lds_, st, __VA_ARGS__);                                                   \
     } while (0)
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : 1; };
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
     T del[NX];
     bool bad;
     int extra_steps;
-    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps);
+    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0);
     const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
@@ -294,7 +298,7 @@ template <class T, bool PER_ENV_CROP, bool PIPE = false, int SCH = 0>
 __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
                                                      const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
                                                      ModelConst<T> m, double* x_next, int rhs_only, int nd,
-                                                     int* n_failed)
+                                                     int* n_failed, int verify)
 {
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= B) return;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, dt, n_sub, del, &failed);
+    rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, dt, n_sub, del, &failed, nullptr, verify != 0);
     // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
     for (int i = 0; i < NX; ++i)
         x_next[(size_t)b * NX + i] = failed ? __builtin_nan("") : (double)x0[i] + (double)del[i];
@@ -891,6 +895,7 @@ struct glgym_handle_s {
     int nd = ND;                        // weather / disturbance row stride: 10, or up to 16 (ODE_pipe reads columns 10, 12)
     int variant = GLGYM_ODE;            // GLGYM_ODE | GLGYM_ODE_PIPE
     int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3
+    int verify_mode = GLGYM_VERIFY_AUTO;   // glgym_set_verify
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
     float du = 0.1f, u_min[NU] = {0, 0, 0, 0, 0, 0}, u_max[NU] = {1, 1, 1, 1, 1, 1};   // glgym_set_control_limits
@@ -926,7 +931,7 @@ static int refresh(glgym_handle h)
 
 extern "C" {
 
-const char* glgym_version(void) { return "glgym 0.3 (gfx950; thread-per-env; stability-controlled RK4 / explicit-midpoint sub-steppers in delta form)"; }
+const char* glgym_version(void) { return "glgym 0.4 (gfx950; stability-controlled, step-doubling-verified RK4 / RK3 / midpoint sub-steppers in delta form)"; }
 const char* glgym_last_error(void) { return g_err.c_str(); }
 
 int glgym_destroy(glgym_handle h);
@@ -1024,6 +1029,16 @@ int glgym_set_control_limits(glgym_handle h, const double* u_min, const double* 
     return GLGYM_OK;
 }
 
+int glgym_set_verify(glgym_handle h, int mode)
+{
+    if (!h || (mode != GLGYM_VERIFY_AUTO && mode != GLGYM_VERIFY_ALWAYS && mode != GLGYM_VERIFY_NEVER)) {
+        g_err = "glgym_set_verify: GLGYM_VERIFY_AUTO, GLGYM_VERIFY_ALWAYS or GLGYM_VERIFY_NEVER";
+        return GLGYM_EINVAL;
+    }
+    h->verify_mode = mode;
+    return GLGYM_OK;
+}
+
 int glgym_set_n_sub(glgym_handle h, int n_sub)
 {
     if (!h || n_sub < 1) return GLGYM_EINVAL;
@@ -1066,10 +1081,10 @@ static void launch_evalf_sch(glgym_handle h, const ModelConst<T>& m, const doubl
 {
     if (dcrop)
         GL_LAUNCH_T((evalf_kernel<T, true, false, SCH>), true, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
+                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev, h->verify_mode != GLGYM_VERIFY_NEVER);
     else
         GL_LAUNCH_T((evalf_kernel<T, false, false, SCH>), false, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
+                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev, h->verify_mode != GLGYM_VERIFY_NEVER);
 }
 
 template <class T>
@@ -1083,7 +1098,7 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
             return GLGYM_EINVAL;
         }
         GL_LAUNCH_T((evalf_kernel<T, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev);
+                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev, h->verify_mode != GLGYM_VERIFY_NEVER);
     } else if (h->scheme == GLGYM_SCHEME_RK2) {
         launch_evalf_sch<T, GLGYM_SCHEME_RK2>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
     } else if (h->scheme == GLGYM_SCHEME_RK3) {
@@ -1150,8 +1165,7 @@ static int evalf_impl(glgym_handle h, const double* x, const double* u, const do
     HIPCHK(hipMemcpy(&n_failed, h->fail_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (n_failed > 0) {
         g_err = "glgym_evalF: the integration failed for " + std::to_string(n_failed) + " of " + std::to_string(B) +
-                " rows (rate bound beyond 16x the nominal sub-step count, or error estimate / non-finite result after "
-                "the 2x and 4x retries); their rows of x_next are NaN";
+                " rows (no two consecutive attempts of the n_sub, 2x, 4x, 8x ladder agreed); their rows of x_next are NaN";
         return GLGYM_EODE;
     }
     return GLGYM_OK;
@@ -1205,6 +1219,9 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]); k.nd = h->nd;
     k.du = h->du;
     for (int j = 0; j < NU; ++j) { k.u_min[j] = h->u_min[j]; k.u_max[j] = h->u_max[j]; }
+    // AUTO: verified wherever the control can jump -- raw controls (step_raw_control, the rule-based controller), or an action
+    // path whose delta_u_max is wider than the reference's 0.1 (TomatoEnv.yml; base_env.py:74)
+    k.verify = h->verify_mode == GLGYM_VERIFY_ALWAYS || (h->verify_mode == GLGYM_VERIFY_AUTO && (!a->action || h->du > 0.1001f));
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
     if (h->variant == GLGYM_ODE_PIPE) {
         if (a->crop_p || h->scheme != GLGYM_SCHEME_RK4) {

@@ -22,6 +22,7 @@ SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3}
 # launch waits for it.  320 / 376 keep that rare on the bench workload (rate bound above 0.85 1/s in 5e-6 of random-action
 # env-steps on the synthetic weather year, never above 0.91 in 1.9e5); lower counts refine in most launches and end up slower.
 DEFAULT_N_SUB = {"rk4": 320, "rk2": 376, "rk3": 354}
+VERIFY_MODES = {"auto": 0, "always": 1, "never": 2}     # glgym_verify (include/glgym.h)
 N_SUB_MULTIPLE = {"rk4": 4, "rk2": 4, "rk3": 3}          # widest tier-2b window of the scheme
 
 
@@ -120,6 +121,7 @@ PROTOTYPES = {
     "glgym_set_n_sub": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_model_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_scheme": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_verify": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_reward": (C.c_int, [C.c_void_p, C.POINTER(RewardCfg)]),
     "glgym_get_reward_scale": (C.c_int, [C.c_void_p, _DP, _DP, _DP]),
     "glgym_evalF": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.c_int, _DP]),

@@ -49,6 +49,11 @@ class GreenLight:
         L.check(self._lib.glgym_set_n_sub(self._h, int(n_sub)), "glgym_set_n_sub")
         self.n_sub = int(n_sub)
 
+    def set_verify(self, mode: str):
+        """Step-doubling verified integration: "auto" (default; evalF is always verified: it takes any u), "always", "never"
+        (include/glgym.h, glgym_verify)."""
+        L.check(self._lib.glgym_set_verify(self._h, L.VERIFY_MODES[mode]), "glgym_set_verify")
+
     def _as(self, a, n, B):
         a = np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1)
         if a.shape[1] != n:

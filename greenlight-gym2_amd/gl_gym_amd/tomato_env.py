@@ -577,6 +577,11 @@ class TomatoVecEnv:
         self.n_sub = int(n_sub)
         L.check(self._lib.glgym_set_n_sub(self._h, self.n_sub), "glgym_set_n_sub")
 
+    def set_verify(self, mode: str):
+        """Step-doubling verified integration (include/glgym.h, glgym_verify): "auto" (default) verifies wherever the control
+        can jump -- step_raw_control / controller= steps, or delta_u_max > 0.1 -- "always" / "never" every / no env-step."""
+        L.check(self._lib.glgym_set_verify(self._h, L.VERIFY_MODES[mode]), "glgym_set_verify")
+
     def timer_start(self):
         L.check(self._lib.glgym_timer_start(self._h, self._stream()))
 

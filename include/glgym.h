@@ -47,8 +47,8 @@ extern "C" {
 #define GLGYM_NINFO 11      /* EPI, revenue, variable_costs, fixed_costs, co2_cost, heat_cost, elec_cost,
                                temp_violation, co2_violation, rh_violation, lamp_violation (tomato_env.py:208-222) */
 #define GLGYM_NMETRIC 10    /* sum reward, sum EPI, n done, n failed integrations, sum co2/temp/rh violation, n env-steps,
-                               n guard retries (env-steps redone with 2x / 4x windows after a non-finite result or an
-                               error estimate above tolerance), n refined sub-steps (sub-steps beyond n_sub that the
+                               n guard retries (extra attempts of the n_sub, 2x, 4x, 8x ladder: unverified or -- verified
+                               mode -- every env-step's second attempt), n refined sub-steps (sub-steps beyond n_sub that the
                                stability control inserted: storms, wet screens pinned to the air temperature) */
 #define GLGYM_METRIC_REPLICAS 64   /* accumulator blocks, one 128-byte line each (atomics onto a single line serialise) */
 #define GLGYM_METRIC_STRIDE 32     /* floats per replica */
@@ -70,9 +70,11 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  * relaxation rate (cover pair 0.67-0.72 1/s; top-compartment exchange up to 1.1 1/s in storms; a wet screen pinned to
  * the air temperature 3 ... 15 1/s) is evaluated once per window of 1-4 nominal sub-steps and the environment takes as
  * many smaller sub-steps in that window as its scheme's stability interval asks for; an embedded error estimate is the
- * safety net (env-step redone with 2x / 4x n_sub, counted in GLGYM_NMETRIC).  An environment whose rate bound asks for
- * more than 16x the nominal count, or that still fails after the retries, is reported like a failed CVODES call in the
- * reference (tomato_env.py:119-123): done = 1, state unchanged (glgym_step) / GLGYM_EODE (glgym_evalF).
+ * safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 16x the nominal count for more than 120 s,
+ * a wet surface that changed sides inside its bistable regime) or that took 3x the nominal number of sub-steps is UNVERIFIED:
+ * the env-step is redone with 2x, 4x, 8x n_sub until an attempt is clean or two consecutive attempts agree on the fast states
+ * (step doubling; counted in GLGYM_NMETRIC).  An environment for which no two attempts agree is reported like a failed CVODES
+ * call in the reference (tomato_env.py:119-123): done = 1, state unchanged (glgym_step) / GLGYM_EODE (glgym_evalF).
  *   GLGYM_SCHEME_RK4: classical RK4 (stability interval 2.785): n_sub >= 224 at dt = 900; use n_sub 320 (nominal lanes
  *     then cover rates up to 0.91 1/s without refinement).  The slow sub-expressions and the harvest flow are evaluated
  *     once per nominal sub-step in fp64, once per two in fp32 (n_sub is then rounded up to even).
@@ -83,6 +85,16 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     second-order solution as the error estimate; 17 % fewer right-hand sides than RK4 at RK4-like accuracy; the slow
  *     sub-expressions and the harvest flow are shared by three nominal sub-steps (n_sub is rounded up to a multiple of 3). */
 typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1, GLGYM_SCHEME_RK3 = 2 } glgym_scheme;
+
+/* Step-doubling VERIFIED integration: no attempt is accepted on its own, the result is the finer of two agreeing attempts (at
+ * least n_sub and 2 n_sub: 3x the work, 4e-7 median error instead of 2e-6).  The reference's solver is error-controlled
+ * (greenlight_model.cpp:46-63) and its raw-control entry points apply any u with no delta-u clip (tomato_env.py:148-173; the
+ * rule-based controller bang-bangs, baseline.py:68-227): after an all-actuator jump an explicit scheme near its stability limit
+ * can put a wet cover on the wrong branch with every in-step check green.
+ *   GLGYM_VERIFY_AUTO (default): verified wherever the control can jump -- glgym_evalF, glgym_step(control = ...), and
+ *     glgym_step(action = ...) when delta_u_max > 0.1; the reference's action path (delta_u_max = 0.1) runs unverified + guard.
+ *   GLGYM_VERIFY_ALWAYS / GLGYM_VERIFY_NEVER: every / no entry point. */
+typedef enum { GLGYM_VERIFY_AUTO = 0, GLGYM_VERIFY_ALWAYS = 1, GLGYM_VERIFY_NEVER = 2 } glgym_verify;
 
 typedef enum {
     GLGYM_OK = 0,
@@ -172,6 +184,7 @@ int glgym_destroy(glgym_handle h);
 int glgym_set_params(glgym_handle h, const double* p);
 int glgym_set_n_sub(glgym_handle h, int n_sub);
 int glgym_set_scheme(glgym_handle h, int scheme);            /* GLGYM_SCHEME_RK4 (default) | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3 */
+int glgym_set_verify(glgym_handle h, int mode);              /* GLGYM_VERIFY_AUTO (default) | _ALWAYS | _NEVER */
 /* action_to_control (tomato_env.py:109-113): u = clip(u_prev + action * delta_u_max, u_min, u_max), held in float32 like
  * base_env.py:72-74.  Default: the yml's [0, 1] bounds and 0.1 (configs/envs/TomatoEnv.yml:12-14).  The `control` input
  * of glgym_step (step_raw_control) is applied unclipped, as the reference does (tomato_env.py:148-149). */

@@ -778,11 +778,27 @@ static double dsat_vp(double t) { return sat_vp(t) * 17.2694 * 238.3 / ((t + 238
  * x (the kernels use the stage they have in hand).  Two passes, as in gl_model.hpp rhs_fast<RATES>: tangent slopes first;
  * if a wet surface's singular slope exceeds lam_nominal, that slope is replaced by the relaxation rate of the equilibrium the
  * surface is pinned at (or dropped when the surface merely crosses the air temperature). */
+double gl_sc_probe[8] = {0};
 static double sc_pinned(double iCap, double hcoef, double hec, double g, double dT, double ddT, double base, double LK,
-                        double tSurf, double h_nominal)
+                        double tSurf, double h_nominal, int *side, double *Gout)
 {
     const double G = LK * fmax(g, 0.0), kap = iCap * fabs(hcoef);
     const double rfree = ddT + iCap * hec * (dT + LK * g);
+    /* Round 3, branch invariant.  d(dT)/dt = rfree - kap |dT|^(1/3) (dT + G) is BISTABLE for 0 < rfree < fmax =
+     * kap (G/4)^(1/3) (3G/4): next to the pinned equilibrium at dT = dT_eq > 0 there is a second stable one near dT = -G
+     * (surface above the air, kept warm by condensation), the two separated by an unstable root at about -dT_eq.  At
+     * dT = 0 the vector field equals rfree > 0, so the true solution cannot pass from dT > 0 to dT < 0 while rfree > 0; an
+     * explicit step that overshoots the landing on dT_eq does, and then stays on the wrong branch: finite, smooth, kelvins
+     * off (tuples A / B).  side: 1 = the surface is on the negative side inside the bistable regime with
+     * positive drive; 2 / 3 = dT > 0 with rfree <= 0 / > 0.  rk_sc_impl flags a window that went from 3 to 1: positive drive
+     * on both sides of the crossing.  (A legitimate crossing happens while rfree < 0; with the drive tested on the far side
+     * only, 117 of 5 891 jump tuples were flagged although every ladder level agreed with the truth -- the drive had turned
+     * positive after the crossing.)  Cubes instead of the cube root. */
+    if (Gout) *Gout = G;
+    if (side) {
+        const double f3 = kap * kap * kap * (27.0 / 256.0) * G * G * G * G;
+        *side = (dT > 0.0) ? (rfree > 0.0 ? 3 : 2) : ((dT < 0.0 && rfree > 0.0 && rfree * rfree * rfree < f3) ? 1 : 0);
+    }
     /* harm gate: (kap G h)^(3/2) > 1e-4 max(|T|, 2)  <=>  kap G h > 2.154e-3 T^(2/3), T^(2/3) bounded below by its chord
      * over 2 ... 40 C (the kernels avoid the fractional power) */
     const double tc = fmin(fmax(fabs(tSurf), 2.0), 40.0);
@@ -802,8 +818,8 @@ static double sc_pinned(double iCap, double hcoef, double hec, double g, double 
     return iCap * base + kap * ((4.0 / 3.0) * s + G / (3.0 * s * s));
 }
 
-double gl_rate_bound_dx(const double *x, const double *u, const double *d, const double *p, const double *dx,
-                        double h_nominal)
+static double rate_bound_impl(const double *x, const double *u, const double *d, const double *p, const double *dx,
+                              double h_nominal, int *sides, double *Gs)
 {
     double a[GL_NAUX];
     gl_oracle_aux(x, u, d, p, a);
@@ -848,12 +864,22 @@ double gl_rate_bound_dx(const double *x, const double *u, const double *d, const
     const double base5 = 2.0 * cCov + LK * hecTopCov * 1.1 * dsat_vp(tCovIn) + firCovIn;
     const double base7 = f43 * hecThTop + LK * hecATh * 1.1 * dsat_vp(tTh) + firTh;
     const double base20 = f43 * hecBlTop + LK * hecABl * 1.1 * dsat_vp(tBl) + firBl;
-    const double row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, h_nominal);
-    const double r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, h_nominal);
-    const double r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, h_nominal);
+    int s5 = 0, s7 = 0, s20 = 0;
+    double G5 = 0, G7 = 0, G20 = 0;
+    const double row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, h_nominal, &s5, &G5);
+    const double r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, h_nominal, &s7, &G7);
+    const double r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, h_nominal, &s20, &G20);
     double r = fmax(fmax(r1, r3), fmax(r16, row6));
     r = fmax(fmax(r, row5), fmax(r7, r20));
+    if (sides) { sides[0] = s5; sides[1] = s7; sides[2] = s20; }
+    if (Gs) { Gs[0] = G5; Gs[1] = G7; Gs[2] = G20; }
     return r;
+}
+
+double gl_rate_bound_dx(const double *x, const double *u, const double *d, const double *p, const double *dx,
+                        double h_nominal)
+{
+    return rate_bound_impl(x, u, d, p, dx, h_nominal, NULL, NULL);
 }
 
 /* convenience: the bound with the second pass always on (lam_nominal = 0) and dx evaluated here */
@@ -865,7 +891,8 @@ double gl_rate_bound(const double *x, const double *u, const double *d, const do
 }
 
 /* stats: [0] sub-steps taken, [1] max error-estimate ratio (after the grace scaling), [2] max rate bound, [3] flags
- * (1 rate beyond the refinement cap for more than SC_CAP_S, 2 non-finite, 4 error estimate above tolerance) */
+ * (1 rate beyond the refinement cap for more than SC_CAP_S, 2 non-finite, 4 error estimate above tolerance, 8 a wet surface
+ * jumped to the other branch) */
 static void rk_sc_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                        double *x1, int pipe, int order, int window, double *stats)
 {
@@ -882,16 +909,31 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
     memset(dprev, 0, sizeof dprev);
     x[23] = harvest_flow_ref(x[23], p[144], 0.5 * hw);
     x[25] = harvest_flow_ref(x[25], p[145], 0.5 * hw);
-    for (int it = 0; it < n_win; ++it) {
+    int side_prev[3] = {0, 0, 0};
+    /* n_win windows + one closing evaluation at the final state (it == n_win): the error estimate of the last sub-step and
+     * the branch invariant of the last window (round 2 left that tail unchecked) */
+    for (int it = 0; it <= n_win; ++it) {
         if (t_cap > SC_CAP_S) flags |= 1;
         if (flags & 1) break;
         /* window start: tier 2b at the predicted midpoint, first stage + rate bound, estimate of the previous sub-step */
         for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
         memcpy(xw, x, sizeof xw);
         rhs_lagged(x, ym, u, d, p, k1, pipe);
-        double lam = gl_rate_bound_dx(x, u, d, p, k1, hnom);
+        int side[3];
+        double Gs[3];
+        double lam = rate_bound_impl(x, u, d, p, k1, hnom, side, Gs);
         if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
         if (lam > lmax) lmax = lam;
+        /* branch invariant (sc_pinned): a wet surface that was below its air node at the last look and now sits above it in
+         * the bistable regime with positive drive has jumped branches */
+        for (int j = 0; j < 3; ++j) {
+            if (side_prev[j] >= 2 && side[j] == 1) flags |= 8;
+            if (side_prev[j] >= 2 && side[j] < 2) {      /* probe: crossings of a condensing surface, by G */
+                gl_sc_probe[0] += 1; if (Gs[j] > 0.02) gl_sc_probe[1] += 1; if (Gs[j] > 0.1) gl_sc_probe[2] += 1; if (Gs[j] > 0.5) gl_sc_probe[3] += 1;
+                if (side[j] == 1) gl_sc_probe[4] += 1;
+            }
+            side_prev[j] = side[j];
+        }
         if (it > 0) {
             double worst = 0.0;
             for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - k1[SC_FAST[j]]) / SC_TOL[j]);
@@ -901,6 +943,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
             if (!(worst <= 1.0)) flags |= 4;
             if (worst > emax) emax = worst;
         }
+        if (it == n_win) break;
         double hs = fmin(S / lam, hnom);
         {   /* accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by more
              * than SC_MOVE x its tolerance scale -- 4 K, 400 Pa, 400 mg m-3 -- in one sub-step.  Idle on trajectories (10-day
@@ -963,21 +1006,39 @@ void gl_oracle_rk_sc(const double *x0, const double *u, const double *d, const d
     rk_sc_impl(x0, u, d, p, dt, n_sub, x1, 0, order, window, stats);
 }
 
-/* The kernels' guard around it (gl_model.hpp rk4_delta_guarded): a non-finite result or an error estimate above tolerance
- * -> redo from x0 with 2x, then 4x windows; a refinement-cap hit is not retried.  Returns the retries used; out[0] = 1
- * if the integration failed (x1 then holds the last attempt), out[1] = sub-steps beyond n_sub over all attempts.
- * pipe != 0: ODE_pipe (d has 14 entries). */
-int gl_oracle_rk_sc_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
-                            int order, int window, int pipe, double *x1, double *out)
+/* The kernels' guard around it (gl_model.hpp rk4_delta_guarded), round 3.  An attempt is UNVERIFIED when rk_sc_impl flagged it
+ * (rate beyond the refinement cap for too long, non-finite, error estimate above tolerance, a wet surface changed sides in the
+ * bistable regime) or when it took SC_HEAVY x the nominal number of sub-steps (the scheme knew it was in trouble).  An
+ * unverified env-step is redone from x0 with 2x, then 4x windows and accepted as soon as an attempt is clean, or as soon as two
+ * consecutive COMPLETE attempts agree on the nine fast states to SC_AGREE x the estimate tolerances (1.25e-4 K, 1.25e-2 Pa /
+ * mg m-3) -- step doubling.  Otherwise it is a failed integration.  (Round 2 accepted any unflagged attempt and never retried a
+ * cap hit: tuples A / B of the round-2 review -- wet cover pinned to the top air, sub-step capped, branch jump, failed = 0.)
+ * Returns the retries used; out[0] = 1 if the integration failed (x1 then holds the last attempt), out[1] = sub-steps beyond
+ * n_sub over all attempts.  pipe != 0: ODE_pipe (d has 14 entries). */
+#define SC_HEAVY 3.0
+#define SC_AGREE 1e-3
+#define SC_ATTEMPTS 4            /* n, 2n, 4n, 8n */
+int gl_oracle_rk_sc_guarded2(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                             int order, int window, int pipe, int verify, double *x1, double *out)
 {
-    int n = n_sub, extra = 0, ok = 0;
-    double total = 0.0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    int n = n_sub, extra = 0, ok = 0, have_prev = 0;
+    double total = 0.0, prev[9];
+    for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         double st[4];
         rk_sc_impl(x0, u, d, p, dt, n, x1, pipe, order, window, st);
         total += st[0];
-        ok = ((int)st[3] == 0);
-        if (ok || ((int)st[3] & 1)) break;
+        const int flags = (int)st[3];
+        const int n_nom = ((n + window - 1) / window) * window;
+        const int complete = !(flags & 3);                           /* ran to the end, finite */
+        if (!verify && flags == 0 && st[0] < SC_HEAVY * (double)n_nom) { ok = 1; break; }
+        if (complete && have_prev) {
+            double worst = 0.0;
+            for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(x1[SC_FAST[j]] - prev[j]) / SC_TOL[j]);
+            if (worst <= SC_AGREE) { ok = 1; break; }
+        }
+        have_prev = complete;
+        if (complete) for (int j = 0; j < 9; ++j) prev[j] = x1[SC_FAST[j]];
+        if (attempt == SC_ATTEMPTS - 1) break;
         n *= 2;
         ++extra;
     }
@@ -985,7 +1046,13 @@ int gl_oracle_rk_sc_guarded(const double *x0, const double *u, const double *d, 
         out[0] = ok ? 0.0 : 1.0;
         out[1] = total - (double)(((n_sub + window - 1) / window) * window);
     }
-    return ok ? extra : (extra > 2 ? 2 : extra);
+    return extra;
+}
+
+int gl_oracle_rk_sc_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
+                            int order, int window, int pipe, double *x1, double *out)
+{
+    return gl_oracle_rk_sc_guarded2(x0, u, d, p, dt, n_sub, order, window, pipe, 0, x1, out);
 }
 
 /* ROUND-1 guard (kept for regression comparisons; the kernels now run rk_sc_impl + gl_oracle_rk_sc_guarded above): redo the

@@ -50,6 +50,8 @@ def lib():
         L.gl_rate_bound.argtypes = [_dp] * 4
         L.gl_oracle_rk_sc_guarded.argtypes = [_dp] * 4 + [ctypes.c_double] + [ctypes.c_int] * 4 + [_dp, _dp]
         L.gl_oracle_rk_sc_guarded.restype = ctypes.c_int
+        L.gl_oracle_rk_sc_guarded2.argtypes = [_dp] * 4 + [ctypes.c_double] + [ctypes.c_int] * 5 + [_dp, _dp]
+        L.gl_oracle_rk_sc_guarded2.restype = ctypes.c_int
         L.gl_rate_bound.restype = ctypes.c_double
         L.gl_oracle_rk4_guarded.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_guarded.restype = ctypes.c_int
@@ -138,14 +140,14 @@ def rk_sc(x, u, d, p, dt=900.0, n_sub=320, order=4, window=2):
     return out, st
 
 
-def rk_sc_guarded(x, u, d, p, dt=900.0, n_sub=320, order=4, window=2, pipe=False):
+def rk_sc_guarded(x, u, d, p, dt=900.0, n_sub=320, order=4, window=2, pipe=False, verify=False):
     """rk_sc with the kernels' guard (retry with 2x / 4x windows on a non-finite result or an error estimate above
     tolerance).  Returns (x_next, retries, refined sub-steps beyond n_sub, failed)."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, 14 if pipe else ND), _c(p, NP)
     out = np.empty(NX)
     st = np.zeros(2)
-    r = lib().gl_oracle_rk_sc_guarded(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window),
-                                      int(bool(pipe)), _p(out), _p(st))
+    r = lib().gl_oracle_rk_sc_guarded2(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window),
+                                       int(bool(pipe)), int(bool(verify)), _p(out), _p(st))
     return out, int(r), int(st[1]), bool(st[0])
 
 

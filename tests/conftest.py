@@ -122,13 +122,13 @@ def hostmath():
         assert rc == 0, "unsupported (order, window)"
         return (out, st) if stats else out            # st = [sub-steps taken, SC_FLAG_* bits]
 
-    def _step_guarded(x, u, d_, p, f32=False, dt=900.0, n_sub=320, order=4, window=2):
+    def _step_guarded(x, u, d_, p, f32=False, dt=900.0, n_sub=320, order=4, window=2, verify=False):
         """The guarded step map as the kernels call it: (x_next, retries, extra sub-steps, failed)."""
         out = np.empty(28)
         st = np.zeros(2)
         x, u, d_, p = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, u, d_, p)]
-        r = lib.hostmath_step_guarded(P(x), P(u), P(d_), P(p), int(f32), ctypes.c_double(dt), int(n_sub), int(order),
-                                      int(window), P(out), P(st))
+        r = lib.hostmath_step_guarded2(P(x), P(u), P(d_), P(p), int(f32), ctypes.c_double(dt), int(n_sub), int(order),
+                                       int(window), int(bool(verify)), P(out), P(st))
         assert r >= 0, "unsupported (order, window)"
         return out, int(r), int(st[0]), bool(st[1])
 

@@ -419,6 +419,81 @@ def g_storm():
                         truth_kind=np.array(KIND), truth_agreement=np.array(AGREE), lam_max_start=LAM)
 
 
+def _jump_one(args):
+    """(x, u, d) -> (truth, kind, agreement, bdf) or None; module level for the process pool."""
+    xs, u, d = args
+    p = init_default_params(208).astype(np.float64)
+
+    def sc_err(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * np.maximum(np.abs(b), 1.0))))
+    b = O.rk4(xs, u, d, p, 900.0, 32768)
+    if not np.all(np.isfinite(b)):
+        return None
+    a = None
+    try:
+        s = solve_ivp(lambda t, y: O.rhs(np.clip(y, -1e3, 1e9), u, d, p), (0.0, 900.0), xs, method="Radau", rtol=1e-11, atol=1e-11)
+        if s.success and np.all(np.isfinite(s.y[:, -1])):
+            a = s.y[:, -1]
+    except (ValueError, FloatingPointError):
+        pass
+    if a is not None and sc_err(a, b) < 2e-7:
+        xt, kind, agree = a, 0, sc_err(a, b)
+    else:
+        c = O.rk4(xs, u, d, p, 900.0, 16384)
+        if sc_err(c, b) >= 2e-7 / 15:
+            return None
+        xt, kind, agree = b, 1, sc_err(c, b)
+    # the CVODES stand-in: scipy's BDF at the reference's tolerances (greenlight_model.cpp:51-52)
+    s = solve_ivp(lambda t, y: O.rhs(y, u, d, p), (0.0, 900.0), xs, method="BDF", rtol=1e-6, atol=1e-6)
+    bdf = s.y[:, -1] if s.status == 0 else np.full(28, np.nan)
+    return xt, kind, agree, bdf
+
+
+def g_jump():
+    """One-step maps under RAW CONTROL JUMPS: what step_raw_control (tomato_env.py:148-173) and the
+    bang-bang rule-based controller (baseline.py:68-227) can ask of the step map -- vents slammed to 1, screens pulled to 0,
+    cold, 8-40 m/s wind, plus all-six-actuator corner flips; recipe and draws = oracle/studies/stress_jump.py (draw()).  The two
+    tuples of the review (A: wind 12.9, B: wind 25.5) verbatim, the tuples on which the round-2 scheme was silently wrong or
+    falsely failed in a 5 891-tuple study (wet cover pinned to the top-compartment air: capped sub-step -> branch jump; path
+    error after the jump -> wrong branch with 4 refined sub-steps), a sample of legitimate wet-surface crossings, and a random
+    fill.  Truth = Radau rtol = atol = 1e-11 cross-checked with plain RK4 at 32 768 sub-steps (kept if they agree to 2e-7;
+    fine RK4 16 384 ^ 32 768 otherwise); the BDF rtol = atol = 1e-6 solution (the CVODES-tolerance proxy) is stored beside it."""
+    from concurrent.futures import ProcessPoolExecutor
+    sys.path.insert(0, str(HERE.parent.parent / "greenlight-gym2_amd"))
+    sys.path.insert(0, str(HERE.parent.parent / "oracle" / "studies"))
+    import stress_jump as SJ
+    from gl_gym_amd.utils import init_state as init_state_amd
+    p = init_default_params(208).astype(np.float64)
+    A = (np.array([1738.6249713652644, 972.4595071949202, 10.123872982507889, -0.40791896627070773, 10.526722851972561, -1.6739663564610772, -1.9010666529867748, 5.7011003616063345, 15.325061417505628, 25.362727025637536, 15.473409658637504, 14.264590530199523, 11.799878941329906, 9.330184845084096, 6.920264674550914, 1151.5805849559622, 807.6483045449821, 9.832964227364847, 16.5, 15.371643988876016, 6.781175334730476, 20.219633431659386, 309.75788393902326, 95201.17767899371, 250993.2435805765, 55335.65064214456, 3098.2264093517742, 0.03468688829657113]),
+         np.array([0.39470528367270685, 0, 0, 1, 1, 0.]),
+         np.array([144.52254197918592, -5.512476825560999, 839.1356458449775, 768.7394015107947, 12.860354734974642, -11.633142664023282, 6.908756609091183, 12.75908784132683, 0, 0.]))
+    Bt = (np.array([879.8245581796797, 817.3061342679193, 4.266358708183611, 1.4684519875966708, 8.1289461676755, 0.6725054005725234, 0.38324846341340507, 4.22922066790302, 14.362800793616229, 26.576165140722736, 15.17781278450347, 15.093571829974938, 13.719129144600952, 12.260757450547118, 10.835873428828785, 1178.6855579547248, 1195.394444697216, 6.077274310197308, 16.5, 13.185764878872732, 4.955895622415963, 20.106754220371215, 978.1780476115397, 95238.56885738781, 251022.56096939236, 55349.251036734815, 3098.1113490597977, 0.03468441635011204]),
+          np.array([0.5250631905472637, 1, 0, 1, 1, 0.]),
+          np.array([144.12554836978472, -1.8541696508070658, 1260.9140993942478, 744.3427180647019, 25.542645227113603, -11.82517466572429, 10.829069648015357, 12.57469150450984, 1, 1.]))
+    hard = [1023, 1586, 3810, 5265, 3573, 4681, 2956, 2610, 3367, 4914, 6864, 5609, 2720,           # wrong / failed in round 2
+            1024, 1134, 1152, 1223, 1239, 1260, 1620, 1917, 2736, 3097, 3171, 3222, 3469, 3754, 3578, 3711, 4608, 5542, 5673, 6633]
+    seeds = hard + [s for s in range(1000, 1000 + 560) if s not in hard]
+    tuples = [A, Bt]
+    tags = [-1, -2]
+    for sd in seeds:
+        kind, d, u_prev, u, t_spin = SJ.draw(sd)
+        xs = O.rk4(init_state_amd(d), u_prev, d, p, t_spin, 16384)
+        if np.all(np.isfinite(xs)):
+            tuples.append((xs, u, d)); tags.append(sd)
+    with ProcessPoolExecutor(8) as ex:
+        R = list(ex.map(_jump_one, tuples, chunksize=4))
+    keep = [i for i, r in enumerate(R) if r is not None]
+    X = np.array([tuples[i][0] for i in keep]); U = np.array([tuples[i][1] for i in keep]); D = np.array([tuples[i][2] for i in keep])
+    XT = np.array([R[i][0] for i in keep]); KIND = np.array([R[i][1] for i in keep]); AG = np.array([R[i][2] for i in keep])
+    BDF = np.array([R[i][3] for i in keep]); SEED = np.array([tags[i] for i in keep])
+    eb = np.array([np.max(np.abs(BDF[i] - XT[i]) / np.maximum(np.abs(XT[i]), 1e-3 * np.maximum(np.abs(XT[i]), 1.0)))
+                   if np.all(np.isfinite(BDF[i])) else np.inf for i in range(len(keep))])
+    print("step_tight_jump: %d tuples kept of %d (%d by fine RK4); BDF-1e-6 proxy: failed %d, max scaled distance from truth %.1e"
+          % (len(keep), len(tuples), int(np.sum(KIND == 1)), int(np.sum(~np.isfinite(eb))), float(np.max(eb[np.isfinite(eb)]))))
+    np.savez_compressed(HERE / "step_tight_jump.npz", X=X, U=U, D=D, X_tight=XT, X_bdf=BDF, truth_kind=KIND,
+                        truth_agreement=AG, seed=SEED)
+
+
 def _reference_env(season_length=1, uncertainty_scale=0.0, training=True, observation_modules=None):
     """The reference's REAL TomatoEnv (gl_gym/environments/tomato_env.py, base_env.py, observations.py, rewards.py,
     noise.py, utils.py, parameters.py -- imported from /root/reference, nothing copied) with its two absent third-party
@@ -580,7 +655,7 @@ def g_refobs():
     np.savez_compressed(HERE / "refenv_obs_layouts.npz", n_layouts=len(layouts), **out)
 
 
-ALL = dict(refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+ALL = dict(jump=g_jump, refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

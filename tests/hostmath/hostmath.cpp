@@ -61,7 +61,7 @@ static void run_scheme(const double* x, const double* u, const double* d, const 
 // the guarded step map exactly as step_kernel / evalf_kernel call it: returns retries, *failed, extra sub-steps
 template <class T, int ORDER, int WIN>
 static int run_guarded(const double* x, const double* u, const double* d, const double* p, double dt, int n_sub, double* out,
-                       double* stats)
+                       double* stats, int verify)
 {
     ModelConst<T> m;
     make_model_const<T>(p, m);
@@ -73,7 +73,7 @@ static int run_guarded(const double* x, const double* u, const double* d, const 
     precompute(uu, dd, m, m.crop, s);
     bool failed;
     int extra = 0;
-    const int r = rk4_delta_guarded<T, false, ORDER, WIN>(x0, s, m, m.crop, T(dt), n_sub, del, &failed, &extra);
+    const int r = rk4_delta_guarded<T, false, ORDER, WIN>(x0, s, m, m.crop, T(dt), n_sub, del, &failed, &extra, verify != 0);
     for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
     if (stats) { stats[0] = extra; stats[1] = failed ? 1 : 0; }
     return r;
@@ -129,13 +129,13 @@ int hostmath_step_scheme(const double* x, const double* u, const double* d, cons
 #undef GL_CASE
     return -1;
 }
-int hostmath_step_guarded(const double* x, const double* u, const double* d, const double* p, int f32, double dt,
-                          int n_sub, int order, int win, double* x_next, double* stats)
+int hostmath_step_guarded2(const double* x, const double* u, const double* d, const double* p, int f32, double dt,
+                           int n_sub, int order, int win, int verify, double* x_next, double* stats)
 {
 #define GL_CASE(O, W)                                                                            \
     if (order == O && win == W)                                                                  \
-        return f32 ? run_guarded<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats)              \
-                   : run_guarded<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats);
+        return f32 ? run_guarded<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats, verify)      \
+                   : run_guarded<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats, verify);
     GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 4) GL_CASE(2, 4) GL_CASE(3, 3)
 #undef GL_CASE
     return -1;

@@ -45,7 +45,7 @@ def test_random_tuples_against_oracle_scheme(golden, oracle, scheme, order, win6
         m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
         worst, guarded = 0.0, 0
         for i in range(N):
-            ref, retries, refined, failed = oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, n_sub, order, win)
+            ref, retries, refined, failed = oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, n_sub, order, win, verify=True)   # evalF integrates verified
             assert not failed
             guarded += (refined > 0) or (retries > 0)  # tuples on which the stability control / the guard acted
             got = np.array(m.evalF(X[i], U[i], D[i], P[i]))

@@ -1,0 +1,79 @@
+"""Raw-control-jump fixture through the C ABI on the GPU: glgym_evalF and glgym_step(control = ...), the three
+schemes, fp32 and fp64, against the TIGHT truth of tests/golden/step_tight_jump.npz (Radau 1e-11 ^ RK4-32 768; make_golden.py
+g_jump) -- 576 one-step maps "vents slammed to 1, screens pulled to 0, cold, 8-40 m/s wind" and all-actuator corner flips,
+incl. the review's tuples A and B, on which the round-2 kernels returned the wet cover on the wrong branch with failed = 0.
+
+Bar: NO silent error above 1e-4 (per-state scaled error of oracle/studies/stress_jump.py; a temperature within 0.1 C of 0 C that
+is off by < 1e-4 K counts as the metric's floor and is bounded separately), and a failed integration only where the BDF-1e-6
+proxy of the reference's CVODES also fails (it fails on none of the fixture)."""
+import numpy as np
+import pytest
+
+from test_jump_fixture import judge, sce
+
+pytestmark = pytest.mark.gpu
+
+SCHEMES = [("rk4", 320), ("rk3", 354), ("rk2", 376)]
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme,n_sub", SCHEMES)
+def test_jump_step_maps_through_evalF(golden, scheme, n_sub, dtype):
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight_jump")
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
+    got = m.evalF_batch(X, U, D)                     # raises GlgymOdeError on a failed row: none may fail (BDF-1e-6 does not)
+    assert np.all(np.isfinite(got))
+    wrong, floor = judge(got, XT)
+    print(f"jump evalF {scheme} {dtype}: above 1e-4: {wrong} (+ {floor} at the metric floor), max {sce(got, XT).max():.1e}; "
+          f"tuple A {sce(got[0], XT[0]).max():.1e}, tuple B {sce(got[1], XT[1]).max():.1e}")
+    assert wrong == 0, (scheme, dtype)
+    assert floor <= (12 if scheme == "rk2" else 4)
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme,n_sub", SCHEMES)
+def test_jump_step_maps_through_step_kernel(golden, scheme, n_sub, dtype):
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = golden("step_tight_jump")
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+    B = len(X)
+    w = np.repeat(D, 4, axis=0)                                  # env b integrates over row 4 b
+    env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, n_sub=n_sub, season_length=0.02, pred_horizon=0,
+                       auto_reset=False)
+    env.reset()
+    env.w_off_t.copy_(torch.arange(B, dtype=torch.int32, device=env.device) * 4)
+    env.x.copy_(torch.as_tensor(X, dtype=env.tdtype, device=env.device))
+    env.metrics_t.zero_()
+    obs, r, done, infos = env.step_raw_control(U)                # step_raw_control: no delta-u clip (tomato_env.py:148-149)
+    got = env.x.double().cpu().numpy()
+    m = env.metrics()
+    wrong, floor = judge(got, XT)
+    print(f"jump step {scheme} {dtype}: above 1e-4: {wrong} (+ {floor} floor), max {sce(got, XT).max():.1e}; refined sub-steps "
+          f"{m['n_refined_substeps']:.0f}, extra attempts {m['n_guard_retries']:.0f}, failed {m['n_ode_fail']:.0f}")
+    assert m["n_ode_fail"] == 0 and not done.any()
+    assert wrong == 0, (scheme, dtype)
+    assert m["n_guard_retries"] >= B                             # verified mode: every env-step took at least two attempts
+    env.close()
+
+
+def test_unverified_mode_flags_what_round_2_missed(golden):
+    """GLGYM_VERIFY_NEVER = the action path's integration (guard only).  On the review's tuples A and B the branch invariant now
+    sends the env-step up the ladder: right, or failed -- not silently wrong."""
+    from gl_gym_amd import GreenLight
+    from gl_gym_amd._lib import GlgymOdeError
+    g = golden("step_tight_jump")
+    for dtype in ("float64", "float32"):
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=320)
+        m.set_verify("never")
+        for i in (0, 1):
+            try:
+                got = m.evalF_batch(g["X"][i:i + 1], g["U"][i:i + 1], g["D"][i:i + 1])
+            except GlgymOdeError:
+                continue
+            wrong, floor = judge(got, g["X_tight"][i:i + 1])
+            assert wrong == 0, (dtype, i, sce(got[0], g["X_tight"][i]).max())
+        m.close()

@@ -306,7 +306,7 @@ def test_stability_control_in_storm(golden, oracle):
     for k in range(12):
         x_prev = env.x.double().cpu().numpy().copy()
         env.step_raw_control(ctrl)
-        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2)
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2, verify=True)   # raw control: verified
         plain_failed |= not np.all(np.isfinite(oracle.rk4_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256)))
         assert np.all(np.isfinite(ref)) and not failed
         assert scaled_err(env.x[0].double().cpu().numpy(), ref) < 5e-5, k

@@ -1,0 +1,73 @@
+"""Raw-control-jump fixture on the CPU: tests/golden/step_tight_jump.npz (make_golden.py g_jump) holds 576
+one-step maps "vents slammed open, screens pulled, cold, 8-40 m/s wind" / all-actuator corner flips with Radau-1e-11 truth
+and the BDF-1e-6 solution (CVODES-tolerance proxy).  Checked here: the fixture itself, the oracle's restatement of the
+step-doubling-verified guard, and the PRODUCT's gl_model.hpp arithmetic (host instantiation, tests/hostmath) on the hard
+tuples.  The GPU kernels are checked through the C ABI in tests/test_gpu_jump.py."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+COLMAX = np.array([1500, 1500, 30, 30, 30, 30, 30, 30, 30, 60, 30, 30, 30, 30, 30, 3000, 3000, 60, 30, 30, 30, 30, 2e4, 1e5,
+                   2.6e5, 6e4, 3.2e3, 60.])
+
+
+def sce(a, b):
+    """per-state scaled error of oracle/studies/stress_jump.py: |a - b| / max(|b|, 1e-3 x the state's typical magnitude)"""
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * COLMAX)
+
+
+def judge(got, truth):
+    """-> (n above 1e-4 that are real, n at the metric's floor: a temperature within 0.1 C of 0 C off by < 1e-4 K)"""
+    e = sce(got, truth)
+    bad = e > 1e-4
+    floor = bad & (np.abs(got - truth) < 1e-4) & (np.arange(28)[None, :] < 22)
+    return int((bad & ~floor).any(axis=1).sum()), int(floor.any(axis=1).sum())
+
+
+def test_fixture_is_what_it_says(golden):
+    g = golden("step_tight_jump")
+    assert len(g["X"]) >= 512 and g["seed"][0] == -1 and g["seed"][1] == -2          # the review's tuples A, B first
+    assert np.all(g["truth_agreement"] < 2e-7)                                        # Radau 1e-11 ^ RK4-32 768
+    assert abs(g["D"][0][4] - 12.860354734974642) < 1e-12 and abs(g["D"][1][4] - 25.542645227113603) < 1e-12
+    assert np.all(np.isfinite(g["X_bdf"]))                                            # the CVODES proxy fails on none
+    wrong, floor = judge(g["X_bdf"], g["X_tight"])
+    assert wrong <= 3                                   # BDF at 1e-6 itself: a few 1e-4 ... 2e-3 (its tolerance), nothing gross
+    assert sce(g["X_bdf"], g["X_tight"]).max() < 1e-2
+
+
+def test_oracle_verified_guard_against_the_jump_truth(golden, oracle):
+    g = golden("step_tight_jump")
+    p = golden("params_default")["p"].astype(np.float64)
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+
+    def run(i):
+        return oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, 320, 4, 2, verify=True)
+    with ThreadPoolExecutor(8) as ex:
+        R = list(ex.map(run, range(len(X))))
+    got = np.array([r[0] for r in R])
+    assert not any(r[3] for r in R)                                                   # no failed integration
+    wrong, floor = judge(got, XT)
+    print(f"oracle RK4-320 verified on {len(X)} jump tuples: above 1e-4: {wrong} (+ {floor} at the metric floor), "
+          f"max {sce(got, XT).max():.1e}, attempts beyond the first: {sum(r[1] for r in R)}")
+    assert wrong == 0 and floor <= 3
+    # what round 2 shipped (accept any unflagged attempt): tuples A and B land on the wrong branch
+    for i in (0, 1):
+        y, st = oracle.rk_sc(X[i], U[i], D[i], p, 900.0, 320, 4, 2)
+        assert int(st[3]) & 8 and sce(y, XT[i]).max() > 1e-2                          # ... and rk_sc now flags it (branch invariant)
+
+
+def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
+    """gl_model.hpp's rk4_delta_guarded (host build) == the oracle's restatement on the tuples where round 2 was wrong; fp32
+    within the bar of the truth."""
+    g = golden("step_tight_jump")
+    p = golden("params_default")["p"].astype(np.float64)
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+    for i in list(range(0, 15)) + [40, 100, 300]:
+        for (n, o, w) in ((320, 4, 2), (354, 3, 3)):
+            a = hostmath.step_guarded(X[i], U[i], D[i], p, False, 900.0, n, o, w, verify=True)
+            b = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n, o, w, verify=True)
+            assert a[1] == b[1] and a[3] == b[3] and not a[3], (i, n, a[1:], b[1:])
+            assert sce(a[0], b[0]).max() < 1e-7, (i, n, sce(a[0], b[0]).max())      # kinks amplify rounding: 2e-8 seen
+        y32 = hostmath.step_guarded(X[i], U[i], D[i], p, True, 900.0, 320, 4, 2, verify=True)
+        wrong, floor = judge(y32[0][None], XT[i][None])
+        assert not y32[3] and wrong == 0, (i, sce(y32[0], XT[i]).max())
