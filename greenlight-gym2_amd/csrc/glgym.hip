@@ -230,8 +230,8 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
     }
     T del[NX];
     bool bad;
-    int extra_steps;
-    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0);
+    int extra_steps, first_flags = 0;
+    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags);
     const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
@@ -279,7 +279,10 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         const float w = live ? 1.f : 0.f;
         float mv[GLGYM_NMETRIC] = {w * (float)reward, w * (float)profit, (live && term) ? 1.f : 0.f,
                                    (live && bad) ? 1.f : 0.f, w * (float)viol[0], w * (float)viol[1],
-                                   w * (float)viol[2], w, w * (float)retries, w * (float)extra_steps};
+                                   w * (float)viol[2], w, w * (float)retries, w * (float)extra_steps,
+                                   (live && (first_flags & SC_FLAG_ERR)) ? 1.f : 0.f, (live && (first_flags & SC_FLAG_BRANCH)) ? 1.f : 0.f,
+                                   (live && (first_flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE))) ? 1.f : 0.f,
+                                   (live && (first_flags & 16)) ? 1.f : 0.f};
         // one atomic per wave per metric, onto the wave's replica of the accumulator block (its own 128-byte line): 1 024 waves
         // finishing together onto ONE line serialised in the L2 for 52 us per launch
         float* mrep = a.metrics + (size_t)(blockIdx.x % GLGYM_METRIC_REPLICAS) * GLGYM_METRIC_STRIDE;

@@ -9,7 +9,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("GLGYM_LIB", _HERE / "libglgym.so"))
 
-NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 10
+NX, NU, ND, NP, NCROP, NINFO, NMETRIC = 28, 6, 10, 208, 34, 11, 14
 METRIC_REPLICAS, METRIC_STRIDE = 64, 32          # glgym.h: the metric accumulators are replicated per cache line
 F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
@@ -38,7 +38,8 @@ OK, EINVAL, ENODEV, EHIP, ENOMEM, EODE = 0, -1, -2, -3, -4, -5
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
              "temp_violation", "co2_violation", "rh_violation", "lamp_violation")      # tomato_env.py:208-222
 METRIC_KEYS = ("sum_reward", "sum_EPI", "n_done", "n_ode_fail", "sum_co2_violation", "sum_temp_violation",
-               "sum_rh_violation", "n_env_steps", "n_guard_retries", "n_refined_substeps")
+               "sum_rh_violation", "n_env_steps", "n_guard_retries", "n_refined_substeps", "n_flag_err", "n_flag_branch",
+               "n_flag_cap", "n_flag_heavy")
 
 
 class GlgymError(RuntimeError):

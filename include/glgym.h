@@ -46,10 +46,12 @@ extern "C" {
 #define GLGYM_NCROP 34      /* p[128..161], the block noise.py perturbs */
 #define GLGYM_NINFO 11      /* EPI, revenue, variable_costs, fixed_costs, co2_cost, heat_cost, elec_cost,
                                temp_violation, co2_violation, rh_violation, lamp_violation (tomato_env.py:208-222) */
-#define GLGYM_NMETRIC 10    /* sum reward, sum EPI, n done, n failed integrations, sum co2/temp/rh violation, n env-steps,
+#define GLGYM_NMETRIC 14    /* sum reward, sum EPI, n done, n failed integrations, sum co2/temp/rh violation, n env-steps,
                                n guard retries (extra attempts of the n_sub, 2x, 4x, 8x ladder: unverified or -- verified
                                mode -- every env-step's second attempt), n refined sub-steps (sub-steps beyond n_sub that the
-                               stability control inserted: storms, wet screens pinned to the air temperature) */
+                               stability control inserted: storms, wet screens pinned to the air temperature), then why
+                               first attempts were unverified: n error-estimate flags, n branch-invariant flags, n cap /
+                               non-finite flags, n heavy (>= 3x the nominal sub-steps) */
 #define GLGYM_METRIC_REPLICAS 64   /* accumulator blocks, one 128-byte line each (atomics onto a single line serialise) */
 #define GLGYM_METRIC_STRIDE 32     /* floats per replica */
 
@@ -70,8 +72,8 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  * relaxation rate (cover pair 0.67-0.72 1/s; top-compartment exchange up to 1.1 1/s in storms; a wet screen pinned to
  * the air temperature 3 ... 15 1/s) is evaluated once per window of 1-4 nominal sub-steps and the environment takes as
  * many smaller sub-steps in that window as its scheme's stability interval asks for; an embedded error estimate is the
- * safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 16x the nominal count for more than 120 s,
- * a wet surface that changed sides inside its bistable regime) or that took 3x the nominal number of sub-steps is UNVERIFIED:
+ * safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 64x the nominal count for more than 120 s,
+ * a wet surface that changed sides inside its bistable regime in a capped window) or that took 3x the nominal number of sub-steps is UNVERIFIED:
  * the env-step is redone with 2x, 4x, 8x n_sub until an attempt is clean or two consecutive attempts agree on the fast states
  * (step doubling; counted in GLGYM_NMETRIC).  An environment for which no two attempts agree is reported like a failed CVODES
  * call in the reference (tomato_env.py:119-123): done = 1, state unchanged (glgym_step) / GLGYM_EODE (glgym_evalF).

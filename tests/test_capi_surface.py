@@ -115,7 +115,9 @@ def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
             assert "scratch_" not in body, variant
             assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", desc), variant
         if not allow_readlane:
-            assert body.count("v_readlane_b32") < 16, (variant, body.count("v_readlane_b32"))
+            # wave-uniform scalars of the attempt ladder (round 3: four attempts, verified mode) live in VGPR lanes around the
+            # integrator; a handful, outside its sub-step loops
+            assert body.count("v_readlane_b32") < 32, (variant, body.count("v_readlane_b32"))
 
 
 def test_scheme_table_and_default_sub_step_counts():

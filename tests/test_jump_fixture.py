@@ -50,10 +50,12 @@ def test_oracle_verified_guard_against_the_jump_truth(golden, oracle):
     print(f"oracle RK4-320 verified on {len(X)} jump tuples: above 1e-4: {wrong} (+ {floor} at the metric floor), "
           f"max {sce(got, XT).max():.1e}, attempts beyond the first: {sum(r[1] for r in R)}")
     assert wrong == 0 and floor <= 3
-    # what round 2 shipped (accept any unflagged attempt): tuples A and B land on the wrong branch
+    # the review's tuples A and B under the UNVERIFIED guard (the action path's integration): round 2 capped the refinement at
+    # 16x, went unstable on the pinned cover and returned the wrong branch with failed = 0; now the sub-step follows the rate
+    # bound down to 1/64 of the nominal one, the attempt is 'heavy' (>= 3x the nominal sub-steps) and gets verified by 2x
     for i in (0, 1):
-        y, st = oracle.rk_sc(X[i], U[i], D[i], p, 900.0, 320, 4, 2)
-        assert int(st[3]) & 8 and sce(y, XT[i]).max() > 1e-2                          # ... and rk_sc now flags it (branch invariant)
+        y, retries, refined, failed = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, 320, 4, 2)
+        assert not failed and retries >= 1 and refined > 3 * 320 and judge(y[None], XT[i][None])[0] == 0
 
 
 def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
