@@ -881,14 +881,16 @@ template <class T> struct ScrOut {
 };
 
 template <class T> struct ScreenBlock {
+    // dATh / dABl = tAir - tThScr / tAir - tBlScr, handed in by the caller (it may hold them more precisely than the difference
+    // of the two rounded temperatures: rhs_fast<WETDIFF>)
     static GL_HD void run(T tAir, T tTop, T tThScr, T tBlScr, T tCovIn, T tCan, T vpAir, T pw66, T iRhoMean, T rhoMean,
-                          T dRho, const StepCoef<T>& s, const ModelConst<T>& m, ScrOut<T>& o)
+                          T dRho, T dATh, T dABl, const StepCoef<T>& s, const ModelConst<T>& m, ScrOut<T>& o)
     {
         using M = Math<T>;
         const T one = T(1), eps = T(1e-10), third = T(1.0 / 3.0);
         o.fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
         o.fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
-        o.dATh = tAir - tThScr; o.dABl = tAir - tBlScr;
+        o.dATh = dATh; o.dABl = dABl;
         const T dThTop = tThScr - tTop, dBlTop = tBlScr - tTop;
         o.hecAirTh = s.hTh * M::powa(M::abs(o.dATh + eps), third);
         o.hecAirBl = s.hBl * M::powa(M::abs(o.dABl + eps), third);
@@ -926,6 +928,7 @@ template <> struct ScreenBlock<float> {
     static __device__ __forceinline__ gl_f2 rc(gl_f2 v) { return mk(__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)); }
     static __device__ __forceinline__ void run(float tAir, float tTop, float tThScr, float tBlScr, float tCovIn, float tCan,
                                                float vpAir, float pw66, float iRhoMean, float rhoMean, float dRho,
+                                               float dATh, float dABl,
                                                const StepCoef<float>& s, const ModelConst<float>& m, ScrOut<float>& o)
     {
         const float eps = 1e-10f, third = 1.0f / 3.0f, l2e = 1.44269504088896341f;
@@ -936,7 +939,7 @@ template <> struct ScreenBlock<float> {
         const gl_f2 f = mk(s.kTh, s.kBl) * sp(pw66) + omu * sp(iRhoMean) * sq;
         o.fTh = f.x; o.fBl = f.y;
         // exchange laws  h |dT|^(1/3):  pow = exp2(third * log2 |.|)
-        const gl_f2 dA = sp(tAir) - tS, dT = tS - sp(tTop);
+        const gl_f2 dA = mk(dATh, dABl), dT = tS - sp(tTop);
         const gl_f2 hecA = hS * ex2(sp(third) * lg2(dA + sp(eps)));
         const gl_f2 hecT = hS * ex2(sp(third) * lg2(dT + sp(eps)));
         const gl_f2 hTop = hecT * dT;
@@ -1052,7 +1055,15 @@ T sc_pinned_rate(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth,
 // With RATES, *side additionally reports where the three wet surfaces (inner cover face / thermal screen / blackout screen:
 // j = 0, 1, 2) stand relative to their air node -- the branch invariant of rk_delta: bit 3 + j = the surface is below the air
 // (dT > 0), bit j = it is above the air INSIDE THE BISTABLE REGIME with positive drive (see sc_side below).
-template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false, bool RATES = false>
+// WETDIFF = true (how the integrator calls it): slots 5, 7, 20 of x hold the DIFFERENCES  tTop - tCovIn,  tAir - tThScr,
+// tAir - tBlScr  instead of the three wet surfaces' temperatures, and the same slots of dx return the differences' derivatives.
+// A wet surface pinned to its air node sits dT_eq = 1e-7 ... 1e-5 K below it (rk_delta); carried as the difference of two
+// rounded fp32 temperatures that is a handful of ulps (2.4e-7 K at 3.6 C) and rounding alone pushes the surface across the
+// unstable root onto the other branch, at every n_sub (oracle/studies/stress_jump.py seeds 1586, 3810, 2956 with the fp32
+// midpoint scheme: attempts n_sub and 2 n_sub AGREEING on a cover 0.5 - 1.5 K off).  As a state of its own the difference
+// keeps its full relative precision.  A linear change of variables commutes with every Runge-Kutta scheme: in exact
+// arithmetic (and in the fp64 oracle, to rounding) nothing changes.
+template <class T, bool HARVEST_IN_RHS = true, bool PIPE = false, bool RATES = false, bool WETDIFF = false>
 GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
                     const CropConst<T>& cr, T* dx, T* lam = nullptr, int* side = nullptr)
 {
@@ -1060,9 +1071,10 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T one = T(1), eps = T(1e-10), third = T(1.0 / 3.0);
     const T c2k = Kelvin<T>::c2k();
 
-    const T co2Air = x[0], co2Top = x[1], tAir = x[2], tTop = x[3], tCan = x[4], tCovIn = x[5], tCovE = x[6];
-    const T tThScr = x[7], tFlr = x[8], tPipe = x[9], vpAir = x[15], vpTop = x[16], tLamp = x[17];
-    const T tBlScr = x[20], tCan24 = x[21], cLeaf = x[23], cFruit = x[25];
+    const T co2Air = x[0], co2Top = x[1], tAir = x[2], tTop = x[3], tCan = x[4], tCovE = x[6];
+    const T tCovIn = WETDIFF ? tTop - x[5] : x[5], tThScr = WETDIFF ? tAir - x[7] : x[7], tBlScr = WETDIFF ? tAir - x[20] : x[20];
+    const T tFlr = x[8], tPipe = x[9], vpAir = x[15], vpTop = x[16], tLamp = x[17];
+    const T tCan24 = x[21], cLeaf = x[23], cFruit = x[25];
 
     // ---- long wave: net FIR gain of every surface (FirBlock above; aux_states.hpp:493-632)
     auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };   // sigma lives in the coefficients
@@ -1104,7 +1116,8 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T pw66 = M::powa(M::abs(dAT + eps), T(0.66));
     const T iRhoMean = M::rcp(rhoMean);
     ScrOut<T> sc;          // both screens at once (ScreenBlock above)
-    ScreenBlock<T>::run(tAir, tTop, tThScr, tBlScr, tCovIn, tCan, vpAir, pw66, iRhoMean, rhoMean, dRho, s, m, sc);
+    ScreenBlock<T>::run(tAir, tTop, tThScr, tBlScr, tCovIn, tCan, vpAir, pw66, iRhoMean, rhoMean, dRho,
+                        WETDIFF ? x[7] : tAir - tThScr, WETDIFF ? x[20] : tAir - tBlScr, s, m, sc);
     const T fScr = M::min(sc.fTh, sc.fBl);                              // a144
     const T fScrAbs = M::abs(fScr), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
 
@@ -1116,7 +1129,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
                      M::powa(M::abs((warmFlr ? dFA : -dFA) + eps), warmFlr ? third : T(0.25));
     const T hAirFlr = hecFlr * (-dFA);
     const T dATh = sc.dATh, dABl = sc.dABl;
-    const T dTopCov = tTop - tCovIn;
+    const T dTopCov = WETDIFF ? x[5] : tTop - tCovIn;
     const T hecAirTh = sc.hecAirTh, hecAirBl = sc.hecAirBl;
     const T hecTopCov = m.cTopCov * M::powa(M::abs(dTopCov + eps), third);
     const T hAirThScr = sc.hAirThScr, hAirBlScr = sc.hAirBlScr;
@@ -1281,6 +1294,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         if (PIPE) r = (s.pipeTrack != T(0)) ? M::max(r, one) : r;         // dxdt(9) = tPipeSet - x9: rate 1 1/s
         *lam = r;
     }
+    if (WETDIFF) { dx[5] = dx[3] - dx[5]; dx[7] = dx[2] - dx[7]; dx[20] = dx[2] - dx[20]; }
 }
 
 // The reference's right-hand side at one state: slow sub-expressions evaluated at that same state.
@@ -1370,7 +1384,7 @@ __device__ __noinline__ inline void rhs_stage_f64()
     f64_get(s, GL_F64_S); f64_get(q, GL_F64_Q); f64_get_model(m); f64_get_crop(cr, m);
     double lam = RATES ? gl_lds64[GL_F64_LAM * 64 + threadIdx.x] : 0.0;
     int side = 0;
-    rhs_fast<double, false, PIPE, RATES>(x, q, s, m, cr, dx, RATES ? &lam : nullptr, RATES ? &side : nullptr);
+    rhs_fast<double, false, PIPE, RATES, true>(x, q, s, m, cr, dx, RATES ? &lam : nullptr, RATES ? &side : nullptr);
 #pragma unroll
     for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x] = dx[i];
     if (RATES) { gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = lam; gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] = (double)side; }
@@ -1393,7 +1407,7 @@ template <class T, bool PIPE> struct RhsStage {
     static GL_HD void run(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
                           const CropConst<T>& cr, T* dx, T* lam, int* side)
     {
-        rhs_fast<T, false, PIPE, RATES>(x, q, s, m, cr, dx, lam, side);
+        rhs_fast<T, false, PIPE, RATES, true>(x, q, s, m, cr, dx, lam, side);
     }
     static GL_HD void slow(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
                            SlowCoef<T>& q)
@@ -1592,6 +1606,11 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     const T est_fac = T(ORDER == 3 ? 1.0 / 8.0 : 1.0 / 6.0);
     const T hmin = hnom * T(1.0 / SC_MAX_REFINE);
     T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
+    // the integrator works in the coordinates of rhs_fast<WETDIFF>: slots 5, 7, 20 = tTop - tCovIn, tAir - tThScr, tAir - tBlScr
+    T z0[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z0[i] = x0[i];
+    z0[5] = x0[3] - x0[5]; z0[7] = x0[2] - x0[7]; z0[20] = x0[2] - x0[20];
     // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 19, 21..26)
     T dprev[GL_N_SLOW], dwin[GL_N_SLOW];
 #pragma unroll
@@ -1612,7 +1631,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     auto state_now = [&]() {                                      // y = x0 + del
 #pragma unroll
         for (int p = 0; p < GL_NPAIR; ++p)
-            RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(y, r.ld(x0) + r.ld(del)); });
+            RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(y, r.ld(z0) + r.ld(del)); });
     };
     int side_prev = 0;
     bool capped_prev = false;
@@ -1772,6 +1791,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
     }
+    del[5] = del[3] - del[5]; del[7] = del[2] - del[7]; del[20] = del[2] - del[20];     // back to the three temperatures
     del[NX - 1] = dt * T(1.0 / 86400.0);     // x27 = time [days]: dx = 1/86400 exactly, nothing depends on it
     st.n_steps = n_steps;
     st.flags = flags;

@@ -964,6 +964,8 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     std::memcpy(h->p, p, sizeof h->p);
     default_reward(h->rcfg);
     if (const char* e = std::getenv("GLGYM_GENERIC")) h->use_specialised = (e[0] == '1') ? 0 : 1;
+    if (const char* e = std::getenv("GLGYM_VERIFY"))          // default of glgym_set_verify: auto | always | never (A/B tests)
+        h->verify_mode = (e[0] == 'n') ? GLGYM_VERIFY_NEVER : (e[0] == 'a' && e[1] == 'l') ? GLGYM_VERIFY_ALWAYS : GLGYM_VERIFY_AUTO;
     // from here on a failure must release what was acquired: run the steps through one exit point
     int rc = [&]() -> int {
         HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));

@@ -771,6 +771,14 @@ static const int SC_FAST[9] = {1, 3, 5, 6, 7, 15, 16, 17, 20};
 /* tolerance of the per-sub-step error estimate: co2Top 12.5 mg m-3, temperatures 0.125 K (lamp 0.5 K), vapour pressures 12.5 Pa */
 static const double SC_TOL[9] = {12.5, 0.125, 0.125, 0.125, 0.125, 12.5, 12.5, 0.5, 0.125};
 
+/* The kernels integrate the three wet surfaces as DIFFERENCES to their air node (gl_model.hpp rhs_fast<WETDIFF>: slots 5, 7, 20 =
+ * tTop - tCovIn, tAir - tThScr, tAir - tBlScr; a linear change of variables, so the step itself is unchanged in exact
+ * arithmetic); the error estimate and the movement limiter therefore see the derivatives of those differences. */
+static double kz(const double *k, int i)
+{
+    return i == 5 ? k[3] - k[5] : i == 7 ? k[2] - k[7] : i == 20 ? k[2] - k[20] : k[i];
+}
+
 static double dsat_vp(double t) { return sat_vp(t) * 17.2694 * 238.3 / ((t + 238.3) * (t + 238.3)); }
 
 /* Upper bound on the fastest relaxation rate [1/s] of the ODE at state x (negative real spectrum; validated against the
@@ -937,7 +945,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         }
         if (it > 0) {
             double worst = 0.0;
-            for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - k1[SC_FAST[j]]) / SC_TOL[j]);
+            for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - kz(k1, SC_FAST[j])) / SC_TOL[j]);
             worst *= h_last * est_fac;
             if (getenv("SC_TRACE")) fprintf(stderr, "it %d h %.3f ratio %.4f lam %.3f\n", it, h_last, worst, lam);
             if (it <= n_grace) worst *= 1.0 / SC_GRACE_MUL;
@@ -953,7 +961,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
              * transients from far-off-equilibrium states accurate, where the rate bound of the window start goes stale
              * within the window (oracle/studies/stress_sc.py: 270 of 3 970 such tuples wrong without it, 4 with it). */
             double mv = 0.0;
-            for (int j = 0; j < 9; ++j) if (j != 7) mv = fmax(mv, fabs(k1[SC_FAST[j]]) / SC_TOL[j]);
+            for (int j = 0; j < 9; ++j) if (j != 7) mv = fmax(mv, fabs(kz(k1, SC_FAST[j])) / SC_TOL[j]);
             if (mv * hs > SC_MOVE) hs = SC_MOVE / mv;
         }
         const int capped = !(hs >= hmin);
@@ -972,7 +980,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
                 rhs_lagged(xs, ym, u, d, p, k4, pipe);
                 for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-                for (int j = 0; j < 9; ++j) est[j] = k4[SC_FAST[j]];
+                for (int j = 0; j < 9; ++j) est[j] = kz(k4, SC_FAST[j]);
             } else if (order == 3) {
                 /* Bogacki-Shampine 3(2): with k1' = f(y_{n+1}) (the next sub-step's first stage) the embedded second-order
                  * solution differs from the third-order one by  h (-5/72 k1 + 1/12 k2 + 1/9 k3 - 1/8 k1')  =
@@ -983,12 +991,12 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                 rhs_lagged(xs, ym, u, d, p, k3, pipe);
                 for (int i = 0; i < GL_NX; ++i) x[i] += h * ((2.0 / 9.0) * k1[i] + (1.0 / 3.0) * k2[i] + (4.0 / 9.0) * k3[i]);
                 for (int j = 0; j < 9; ++j)
-                    est[j] = (-5.0 / 9.0) * k1[SC_FAST[j]] + (2.0 / 3.0) * k2[SC_FAST[j]] + (8.0 / 9.0) * k3[SC_FAST[j]];
+                    est[j] = (-5.0 / 9.0) * kz(k1, SC_FAST[j]) + (2.0 / 3.0) * kz(k2, SC_FAST[j]) + (8.0 / 9.0) * kz(k3, SC_FAST[j]);
             } else {
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
                 rhs_lagged(xs, ym, u, d, p, k2, pipe);
                 for (int i = 0; i < GL_NX; ++i) x[i] += h * k2[i];
-                for (int j = 0; j < 9; ++j) est[j] = 2.0 * k2[SC_FAST[j]] - k1[SC_FAST[j]];
+                for (int j = 0; j < 9; ++j) est[j] = 2.0 * kz(k2, SC_FAST[j]) - kz(k1, SC_FAST[j]);
             }
             n_steps += 1.0;
         }

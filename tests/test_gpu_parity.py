@@ -13,6 +13,22 @@ from conftest import scaled_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _scheme_arithmetic_not_the_verified_ladder():
+    """This module checks the kernels' SCHEME at a given n_sub against the oracle's restatement of that scheme and against the
+    fixtures, also through glgym_evalF / step_raw_control -- entry points that by default integrate step-doubling VERIFIED
+    (they would return the 2 n_sub attempt; include/glgym.h glgym_verify).  GLGYM_VERIFY=never makes every handle created
+    here start unverified; the verified ladder has its own tests (test_gpu_jump.py, test_gpu_storm.py, test_gpu_fuzz.py)."""
+    import os
+    old = os.environ.get("GLGYM_VERIFY")
+    os.environ["GLGYM_VERIFY"] = "never"
+    yield
+    if old is None:
+        os.environ.pop("GLGYM_VERIFY", None)
+    else:
+        os.environ["GLGYM_VERIFY"] = old
+
+
 @pytest.fixture(scope="module")
 def models():
     from gl_gym_amd import GreenLight
@@ -55,18 +71,32 @@ def test_evalF_signature_and_value(models, golden, oracle):
     assert scaled_err(got_b, got64[:16]) < 1e-12
 
 
-def test_n_sub_4_is_unstable_and_flagged(golden):
-    """BASELINE config 3 asks for 'RK4 with 4 sub-steps': the ODE is stiff (lambda_max ~ 0.67 1/s), so that diverges.
-    The kernel must flag it like the reference flags a failed integration: done = 1, state unchanged."""
+def test_n_sub_4_is_refined_to_what_the_ode_needs_or_flagged(golden, oracle):
+    """BASELINE config 3 asks for 'RK4 with 4 sub-steps': the ODE is stiff (lambda_max ~ 0.67 1/s), a fixed step of 225 s
+    overflows at once.  n_sub is the NOMINAL count: the stability control inserts the >= 224 sub-steps the fast block needs (since
+    round 3 down to 1/64 of the nominal sub-step), such an attempt is 'heavy' and gets verified by step doubling.  What n_sub = 4
+    then still sets is the length of the slow tier's windows (450 s), which costs accuracy: 3e-4 against a fine solve, outside
+    the 1e-4 bar that n_sub = 320 meets -- or the env-step is flagged like a failed CVODES call (done = 1, state unchanged).
+    Never a non-finite or silently wild state."""
     from gl_gym_amd.tomato_env import TomatoVecEnv
     w = golden("rollout_10day")["weather"]
     env = TomatoVecEnv(64, weather=w, dtype="float32", n_sub=4, season_length=1, auto_reset=False)
     env.reset()
     x_before = env.x.double().cpu().numpy().copy()
     obs, r, done, info = env.step(np.zeros((64, 6), np.float32))
-    assert done.all()
-    assert np.array_equal(env.x.double().cpu().numpy(), x_before)
-    assert env.metrics()["n_ode_fail"] == 64
+    x_after = env.x.double().cpu().numpy()
+    m = env.metrics()
+    assert np.all(np.isfinite(x_after))
+    truth = oracle.rk4(x_before[0], np.zeros(6), w[0], env.p.astype(np.float64), 900.0, 16384)
+    for b in range(64):
+        if done[b]:
+            assert np.array_equal(x_after[b], x_before[b])
+        else:
+            assert scaled_err(x_after[b][None], truth[None]) < 1e-3, b
+    assert m["n_ode_fail"] == done.sum()
+    assert m["n_refined_substeps"] >= 64 * 220 or done.all()        # the stability floor was inserted, per lane
+    print(f"n_sub 4: {int(done.sum())} of 64 flagged; others {scaled_err(x_after[~done], np.repeat(truth[None], (~done).sum(), 0)) if (~done).any() else 0:.1e} "
+          f"from the fine solve with {m['n_refined_substeps'] / 64:.0f} inserted sub-steps per env")
     env.close()
 
 
@@ -306,7 +336,7 @@ def test_stability_control_in_storm(golden, oracle):
     for k in range(12):
         x_prev = env.x.double().cpu().numpy().copy()
         env.step_raw_control(ctrl)
-        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2, verify=True)   # raw control: verified
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2)
         plain_failed |= not np.all(np.isfinite(oracle.rk4_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256)))
         assert np.all(np.isfinite(ref)) and not failed
         assert scaled_err(env.x[0].double().cpu().numpy(), ref) < 5e-5, k
