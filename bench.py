@@ -37,28 +37,40 @@ for p in (str(ROOT), str(ROOT / "greenlight-gym2_amd")):
 # strength-reduced.  RK4 does 4 evaluations per sub-step.
 F_RHS = 1502          # add/mul flops
 S_RHS = 219           # quarter-rate special-function ops (rcp, exp, log, sqrt, ...)
-# fp32 vector peaks of MI355X (MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz): 157.3 TFLOP/s counts packed FMA
-# (v_pk_fma_f32: 2 lanes-worth x 2 flops); non-packed FMA code tops out at 78.65, non-FMA (add / mul) code at 39.3.
-PEAKS_TFLOPS = {"packed_fma": 157.3, "fma": 78.65, "non_fma": 39.3}
+# fp32 vector peaks of MI355X (MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz): 157.3 TFLOP/s is the plain (non-packed)
+# FMA peak -- a wave64 v_fma_f32 issues every 2 cycles, and v_pk_fma_f32 takes 4, so packing buys no rate; add / mul code tops out
+# at half of it, transcendentals (quarter rate: 8 cycles per wave64 op) at 19.7 Tops.
+PEAKS_TFLOPS = {"fma": 157.3, "non_fma": 78.65, "transcendental_Tops": 19.7}
 PEAK_HBM_GBPS = 8000.0
 BYTES_PER_ENV_STEP = 351          # fp32 algorithmic minimum, without the obs block
 N_SIMD = 1024
-# Issue cost of one wave64 vector instruction on a SIMD, in cycles (tools/microbench.hip with verified wave placement,
-# profiles/r02_microbench_issue_rates.txt): with >= 2 co-resident waves a SIMD issues a plain fp32 op every 2.3-2.7 cycles
-# and a transcendental every 7.7; a LONE wave -- all this kernel can have at B = 65 536 = 1 024 waves on 1 024 SIMDs, and all
-# its ~320 registers allow -- gets one issued only every 5.0 / 8.4 cycles.
-CYC_PLAIN, CYC_TRANS = 2.3, 7.7                   # the SIMD's issue roof (what `frac` is measured against)
-# Recorded rocprofv3 PMC measurements of step_kernel on the DEFAULT workload (B = 65 536, fp32, RK4 n_sub 320), per launch:
-# bench.py cannot collect counters itself.  Written by tools/pmc_summary.py from the separate --pmc passes of
-# tools/profile_round.sh; the summary they come from is committed next to it.
-PMC_FILE = ROOT / "profiles" / "r02_pmc_constants.json"
+# Issue cost of one wave64 vector instruction on a SIMD, in cycles.  Two rulers:
+#   guide    (MI355X_MICROARCH.md: SIMD-32, wave64 op 2 cycles, transcendental 8, 2.4 GHz)            -> roofline.frac
+#   measured (tools/microbench.hip with verified wave placement, profiles/r02_microbench_issue_rates.txt: with >= 2 co-resident
+#            waves a SIMD issues a plain fp32 op every 2.3-2.7 cycles and a transcendental every 7.7; clock = the one recorded
+#            under the profiler)                                                                       -> roofline.frac_measured_ruler
+# A LONE wave -- all this kernel can have at B = 65 536 = 1 024 waves on 1 024 SIMDs -- gets one issued only every 5.0 / 8.4.
+CYC_PLAIN_GUIDE, CYC_TRANS_GUIDE, CLOCK_GUIDE_HZ = 2.0, 8.0, 2.4e9
+CYC_PLAIN, CYC_TRANS = 2.3, 7.7
+# Recorded rocprofv3 PMC measurements of step_kernel per launch at B = 65 536, one entry per shipped variant (bench.py cannot
+# collect counters itself).  Written by tools/pmc_summary.py from the separate --pmc passes of tools/profile_round.sh /
+# tools/profile_variants.sh; the summaries they come from are committed next to it.
+PMC_FILES = [ROOT / "profiles" / "r03_pmc_constants.json", ROOT / "profiles" / "r02_pmc_constants.json"]
 
 
-def load_pmc():
-    try:
-        return json.loads(PMC_FILE.read_text())
-    except (OSError, ValueError):
-        return None
+def load_pmc(variant: str):
+    """-> the recorded counters of `variant` ("f32_rk4", "f32_rk3", "f32_rk2", "f64_rk4", "f32_rk4_config5"), or None.
+    r03 file: {variant: {...}}; the r02 file holds the default variant only."""
+    for f in PMC_FILES:
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if variant in d:
+            return d[variant]
+        if "SQ_INSTS_VALU" in d and variant == "f32_rk4":
+            return d
+    return None
 
 
 DEFAULT_SCHEME = "rk4"
@@ -66,9 +78,16 @@ STAGES = {"rk4": 4, "rk2": 2, "rk3": 3}
 N_SUB = {"rk4": 320, "rk2": 376, "rk3": 354}
 
 
-def cpu_baseline(n_sub: int, budget_s: float = 10.0):
-    """Oracle (plain-C fp64 port of the same scheme, ODE step only) on a bounded sample: ONE host core (the contract's
-    `cpu_baseline`) and, beside it, all host cores (threads over env slices; ctypes releases the GIL)."""
+def cpu_baseline(n_sub: int, budget_s: float = 8.0):
+    """The CPU path beside the GPU number, on a bounded sample of the bench workload's env-steps (ODE step only), timed on THIS
+    box's host cores.  Four figures:
+      cpu_baseline                 the reference-like integrator: variable-order BDF + modified Newton + reused finite-difference
+                                   Jacobian at rtol = atol = 1e-6 (oracle/gl_oracle.c gl_oracle_bdf -- the algorithm family and
+                                   tolerances of greenlight_model.cpp:46-63; CasADi / CVODES themselves are absent), ONE core --
+                                   how the reference runs an env;
+      cpu_baseline_all_cores       the same on every core granted to this container (threads over env slices);
+      cpu_baseline_same_scheme     the kernels' own arithmetic as a plain-C fp64 port (RK4, n_sub sub-steps), one core;
+      cpu_baseline_same_scheme_all_cores."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     import numpy as np
@@ -80,17 +99,11 @@ def cpu_baseline(n_sub: int, budget_s: float = 10.0):
     rng = np.random.default_rng(1234)
     n = 256
     rows = rng.integers(0, 3000, n)
-    X = np.array([init_state(w[r]) * (1 + 1e-3 * rng.standard_normal(28)) for r in rows])
     U = rng.uniform(0, 1, (n, 6))
     D = w[rows]
-    O.rk4_batch(X[:8], U[:8], D[:8], p, 900.0, n_sub)       # warm-up
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        O.rk4_batch(X, U, D, p, 900.0, n_sub)
-        done += n
-    el = time.perf_counter() - t0
-    one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
+    # spun-up states (one env-step from the reset state under the same inputs): at the reset state every exchange law sits on
+    # its kink, which is not what a running env looks like
+    X = O.rk4_batch(np.array([init_state(w[r]) * (1 + 1e-3 * rng.standard_normal(28)) for r in rows]), U, D, p, 900.0, n_sub)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:        # a container may be granted fewer CPUs than it can see (cgroup v2 quota)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -98,25 +111,45 @@ def cpu_baseline(n_sub: int, budget_s: float = 10.0):
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    per = 64
 
-    def work(_):
-        O.rk4_batch(X[:per], U[:per], D[:per], p, 900.0, n_sub)
-        return per
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(work, range(cores)))                    # warm-up: library loaded in every thread
-        done, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s / 2:
-            done += sum(ex.map(work, range(2 * cores)))
-        el = time.perf_counter() - t0
-    allc = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{done} env-steps on {cores} threads (= CPUs granted to this container) in {el:.1f} s"}
-    return one, allc
+    def bdf_slice(lo, hi):
+        return O.bdf_batch(X[lo:hi], U[lo:hi], D[lo:hi], p, 900.0, 1e-6, 1e-6)[1]
+
+    def timed(one_call, per_call, workers, budget):
+        """one_call(k) does per_call env-steps and returns its RHS evaluations (or None)"""
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(one_call, range(workers)))                # warm-up: library loaded in every thread
+            done, evals, t0 = 0, 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget:
+                r = list(ex.map(one_call, range(2 * workers if workers > 1 else 1)))
+                done += per_call * len(r)
+                evals += sum(v for v in r if v is not None)
+            return done, evals, time.perf_counter() - t0
+
+    per = 32
+    done, evals, el = timed(lambda k: bdf_slice((k * per) % n, (k * per) % n + per), per, 1, budget_s)
+    bdf_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port-adaptive-implicit",
+               "rhs_evaluations_per_env_step": evals / done,
+               "sample": f"{done} env-steps (fp64 C restatement: variable-order BDF, rtol = atol = 1e-6, ODE step only) in {el:.1f} s"}
+    done, evals, el = timed(lambda k: bdf_slice((k * per) % n, (k * per) % n + per), per, cores, budget_s / 2)
+    bdf_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port-adaptive-implicit",
+               "rhs_evaluations_per_env_step": evals / done,
+               "sample": f"{done} env-steps on {cores} threads (= CPUs granted to this container) in {el:.1f} s"}
+
+    def rk(k):
+        O.rk4_batch(X[:64], U[:64], D[:64], p, 900.0, n_sub)
+    done, _, el = timed(rk, 64, 1, budget_s / 2)
+    rk_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "rhs_evaluations_per_env_step": 4 * n_sub,
+              "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
+    done, _, el = timed(rk, 64, cores, budget_s / 2)
+    rk_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port", "rhs_evaluations_per_env_step": 4 * n_sub,
+              "sample": f"{done} env-steps on {cores} threads in {el:.1f} s"}
+    return {"cpu_baseline": bdf_one, "cpu_baseline_all_cores": bdf_all, "cpu_baseline_same_scheme": rk_one,
+            "cpu_baseline_same_scheme_all_cores": rk_all}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
     # Defaults measure SUSTAINED throughput: under continuous load the MI355X settles at a lower clock within ~0.1 s, so a
     # 20-step (20 ms) timed region after an idle period reports the boost-clock burst (about 25 % higher; tools/
     # sustained_rate.py).  2 000 steps = 2.3 s timed after 0.25 s of warm-up; the whole default run takes about 40 s.
@@ -135,13 +168,38 @@ def main():
     ap.add_argument("--no-alt-scheme", action="store_true", help="skip the informational leg with the other sub-stepper")
     ap.add_argument("--uncertainty", type=float, default=0.0, help="crop-parameter noise scale (config 5: 0.2)")
     ap.add_argument("--vecnorm", action="store_true", help="also run the on-device VecNormalize (obs + reward) each step")
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node: one rank per GPU; without a launcher bench.py starts "
+                                                        "torch.distributed.run itself")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become the launcher.  Nothing in THIS process has touched the GPU yet (no HIP call, no
+    # torch.cuda.is_available(); device_count() does not initialise the runtime on this image), the ranks are fresh child
+    # processes, their one JSON line and exit code are forwarded.  Never an exec from a process that initialised the GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and os.environ.get("GLGYM_BENCH_SHARE_GPU") != "1":
+            print(f"bench.py: --gpus {args.gpus} but this node has {n_dev} GPU(s) (GLGYM_BENCH_SHARE_GPU=1 maps every rank to "
+                  "cuda:0 for control-flow tests)", file=sys.stderr)
+            sys.exit(2)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or (os.environ.get("GLGYM_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
@@ -155,6 +213,8 @@ def main():
         if share_gpu:
             dist.init_process_group(backend="gloo")
         else:
+            # "nccl" IS RCCL on ROCm.  Also taken at world size 1 under GLGYM_FORCE_DIST=1 (tests/test_gpu_multiproc.py), so that
+            # RCCL init, barrier and the all_gather of a device tensor have run on hardware even where only one GPU exists.
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
@@ -249,7 +309,9 @@ def main():
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
                            m.get("n_done", 0.0), kern_ms, m.get("n_guard_retries", 0.0), m.get("n_refined_substeps", 0.0),
-                           float(rank), float(666 + rank)], device=None if share_gpu else dev)
+                           float(rank), float(666 + rank), m.get("n_flag_err", 0.0), m.get("n_flag_branch", 0.0),
+                           m.get("n_flag_cap", 0.0), m.get("n_flag_heavy", 0.0)], device=None if share_gpu else dev,
+                          force_collective=use_dist)
     if rank == 0:
         agg = aggregate(rows)
         t_max, value, kern_ms_max = agg["t_max"], agg["value"], agg["kernel_ms_max"]
@@ -258,51 +320,55 @@ def main():
         specials = STAGES[args.scheme] * args.n_sub * S_RHS
         alg_tflops = per_gpu_kernel_rate * flops / 1e12
         alg_tops = per_gpu_kernel_rate * specials / 1e12
-        algorithmic_ratio = alg_tflops / PEAKS_TFLOPS["non_fma"] + alg_tops / (PEAKS_TFLOPS["non_fma"] / 4)
+        algorithmic_ratio = alg_tflops / PEAKS_TFLOPS["non_fma"] + alg_tops / PEAKS_TFLOPS["transcendental_Tops"]
         obs_bytes = 0 if args.no_obs else 4 * env.obs_dim
         hbm_gbps = per_gpu_kernel_rate * BYTES_PER_ENV_STEP * (2 if args.dtype == "f64" else 1) / 1e9
         # executed work: the recorded PMC instruction counts of the default workload, scaled to this run's batch / n_sub,
         # over the kernel time measured live with HIP events on the launch stream
-        pmc = load_pmc()
-        is_default = args.dtype == "f32" and args.scheme == "rk4" and not args.uncertainty
-        roof = {"bound": "valu", "kernel": "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["packed_fma"],
+        variant = f"{args.dtype}_{args.scheme}" + ("_config5" if args.uncertainty else "")
+        pmc = load_pmc(variant)
+        roof = {"bound": "valu", "kernel": "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["fma"],
                 "unit": "TFLOP/s", "frac": None, "traffic": None}
-        if pmc is not None and is_default:
-            scale = (B / 65536.0) * (args.n_sub / 320.0)
-            valu, trans = pmc["SQ_INSTS_VALU"] * scale, pmc["SQ_INSTS_VALU_TRANS_F32"] * scale
-            fma, mul, add = (pmc[k] * scale for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32",
-                                                      "SQ_INSTS_VALU_ADD_F32"))
-            # Shader clock of THIS run.  The recorded passes give the clock under the profiler (GRBM_GUI_ACTIVE / kernel time)
-            # and, independent of any clock, the cycles one wave spends in the kernel (SQ_WAVE_CYCLES counts 4-cycle
-            # quanta, summed over the 1 024 waves).  Unprofiled the kernel finishes sooner than those cycles would take
-            # at the profiler's clock, so the live clock is at least cycles-per-wave / live kernel time: take the larger of
-            # the two (the smaller fraction).
-            wave_cycles = 4.0 * pmc["SQ_WAVE_CYCLES"] / 1024.0 * (args.n_sub / 320.0) * max(1.0, B / 65536.0)   # rounds of waves
-            clock_hz = max(pmc["clock_ghz"] * 1e9, wave_cycles / (kern_ms_max * 1e-3))
-            avail = N_SIMD * kern_ms_max * 1e-3 * clock_hz                 # SIMD-cycles in one launch
+        if pmc is not None:
+            scale = (B / 65536.0) * (args.n_sub / float(pmc.get("n_sub", N_SUB[args.scheme])))
+            tkey = "SQ_INSTS_VALU_TRANS_F32" if args.dtype == "f32" else "SQ_INSTS_VALU_TRANS_F64"
+            valu, trans = pmc["SQ_INSTS_VALU"] * scale, pmc.get(tkey, 0.0) * scale
+            sfx = "_F32" if args.dtype == "f32" else "_F64"
+            fma, mul, add = (pmc.get(k + sfx, 0.0) * scale for k in ("SQ_INSTS_VALU_FMA", "SQ_INSTS_VALU_MUL", "SQ_INSTS_VALU_ADD"))
+            # fp64 vector ops issue at half the fp32 rate on this part (2x the cycles); the software transcendentals of the fp64
+            # kernels are ordinary FMA chains and are counted as such
+            wide = 2.0 if args.dtype == "f64" else 1.0
+            t_s = kern_ms_max * 1e-3
+            # ONE clock source per ruler, never the kernel time that is also the denominator: the guide's 2.4 GHz,
+            # and the clock recorded under the profiler (GRBM_GUI_ACTIVE / kernel time of that pass).  Both fractions are
+            # proportional to 1 / live kernel time.
+            need_guide = wide * ((valu - trans) * CYC_PLAIN_GUIDE + trans * CYC_TRANS_GUIDE)
+            need_meas = wide * ((valu - trans) * CYC_PLAIN + trans * CYC_TRANS)
             roof.update({
-                # executed fp32 flops (64 lanes; FMA = 2; packed ops are counted once by the PMC, so this is a lower bound)
-                "achieved": 64 * (2 * fma + mul + add) / (kern_ms_max * 1e-3) / 1e12,
-                "frac": ((valu - trans) * CYC_PLAIN + trans * CYC_TRANS) / avail,
-                "frac_note": "executed issue slots / available: ((INSTS_VALU - TRANS) x 2.3 + TRANS x 7.7 cycles) / (1024 "
-                             "SIMDs x kernel time x clock), the per-instruction costs being what a SIMD sustains with >= 2 "
-                             "co-resident waves (profiles/r02_microbench_issue_rates.txt); <= 1 by construction",
+                # executed flops (64 lanes; FMA = 2; packed ops are counted once by the PMC, so this is a lower bound)
+                "achieved": 64 * (2 * fma + mul + add) / t_s / 1e12,
+                "frac": need_guide / (N_SIMD * t_s * CLOCK_GUIDE_HZ),
+                "frac_note": "executed issue slots / available on the GUIDE's ruler: ((INSTS_VALU - TRANS) x 2 + TRANS x 8 cycles"
+                             + (", x 2 for fp64" if wide > 1 else "") + ") / (1024 SIMDs x live kernel time x 2.4 GHz), instruction "
+                             "counts from the recorded PMC passes of this variant; <= 1 by construction",
+                "frac_measured_ruler": need_meas / (N_SIMD * t_s * pmc["clock_ghz"] * 1e9),
+                "frac_measured_ruler_note": "same with the issue costs measured on this chip with >= 2 co-resident waves (2.3 / 7.7 "
+                                            "cycles, profiles/r02_microbench_issue_rates.txt) and the clock recorded under the "
+                                            "profiler (%.3f GHz)" % pmc["clock_ghz"],
                 "valu_busy_one_wave_per_simd": pmc.get("valu_busy"),
                 "valu_busy_note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the recorded profile: B = 65 536 is exactly one "
                                   "wave per SIMD and a lone wave is issued a vector instruction only every ~5 cycles "
                                   "(transcendental 8.4), so this -- not `frac` -- is how close the kernel is to the ceiling "
                                   "its launch geometry allows",
                 "traffic": pmc["traffic_bytes"] * (B / 65536.0),
-                "valu_insts_per_launch": valu, "trans_insts_per_launch": trans, "clock_ghz": clock_hz * 1e-9,
-                "clock_note": "max(clock under the profiler = %.3f GHz, recorded cycles per wave / live kernel time)"
-                              % pmc["clock_ghz"],
-                "pmc_source": pmc.get("source"),
+                "valu_insts_per_launch": valu, "trans_insts_per_launch": trans,
+                "pmc_source": pmc.get("source"), "pmc_variant": variant,
             })
         roof.update({
             "peaks_TFLOPs": PEAKS_TFLOPS,
             "algorithmic_ratio": algorithmic_ratio,
             "algorithmic_note": "SURVEY 8d figure: reference expression graph without CSE (stages x n_sub x (1502 flops + 219 "
-                                "special ops) per env-step) / kernel time, against the non-FMA peak and its quarter rate; > 1 "
+                                "special ops) per env-step) / kernel time, against the non-FMA peak (78.65) and the transcendental rate (19.7); > 1 "
                                 "because the kernel executes far less than that graph (hoisting, CSE, slow sub-expressions "
                                 "once per window)",
             "algorithmic_TFLOPs": alg_tflops, "algorithmic_special_Tops": alg_tops,
@@ -312,6 +378,8 @@ def main():
             "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
                     "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "obs_bytes_per_env_step": obs_bytes}})
         out = {
+            "collective": None if not use_dist else {"backend": dist.get_backend(), "world": world,
+                                                     "note": "one all_gather of 14 doubles per rank at the end of the run"},
             "metric": "TomatoEnv env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -329,11 +397,14 @@ def main():
                                  "flow, slow sub-expressions once per window at the predicted midpoint (DESIGN.md 2)"},
             "roofline": roof,
             "integrator_events": {"failed_integrations": agg["ode_failures"], "guard_retries": agg["guard_retries"],
-                                  "refined_substeps": agg["refined_substeps"],
+                                  "refined_substeps": agg["refined_substeps"], "first_attempt_flags": agg["first_attempt_flags"],
                                   "note": "failed integrations = env-steps reported like a failed CVODES call (done = 1, "
-                                          "state unchanged); guard retries = env-steps redone with 2x / 4x n_sub after a "
-                                          "non-finite result or an error estimate above tolerance; refined sub-steps = "
-                                          "sub-steps beyond n_sub inserted by the stability control"},
+                                          "state unchanged: no two attempts of the n_sub, 2x, 4x, 8x ladder agreed); guard retries "
+                                          "= extra attempts of that ladder; refined sub-steps = sub-steps beyond n_sub inserted by "
+                                          "the stability control; first_attempt_flags = why first attempts were not accepted as "
+                                          "they stood (error estimate / branch invariant / cap or non-finite / >= 3x the nominal "
+                                          "sub-steps).  The action path runs guarded but unverified (delta_u_max = 0.1; "
+                                          "include/glgym.h glgym_verify)"},
             "ranks": agg["ranks"],
             "other_scheme": None if alt is None else {
                 "integrator": alt[0], "n_sub": alt[1], "value": B * world * K / alt[2], "unit": "env-steps/s",
@@ -344,7 +415,7 @@ def main():
             "episodes_finished": agg["episodes_finished"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(N_SUB["rk4"])      # the RK4 C port at the default sub-step count
+            out.update(cpu_baseline(N_SUB["rk4"]))
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:

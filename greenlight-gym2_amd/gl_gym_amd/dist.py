@@ -15,12 +15,13 @@ def shard_range(global_batch: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_metrics(local: Sequence[float], device=None) -> List[List[float]]:
-    """all_gather a short float64 vector from every rank (identity when torch.distributed is not initialised)."""
+def gather_metrics(local: Sequence[float], device=None, force_collective: bool = False) -> List[List[float]]:
+    """all_gather a short float64 vector from every rank (identity when torch.distributed is not initialised).
+    force_collective: run the collective even at world size 1 (so that RCCL has executed on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
     mine = torch.tensor(list(local), dtype=torch.float64, device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return [mine.cpu().tolist()]
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
@@ -29,7 +30,8 @@ def gather_metrics(local: Sequence[float], device=None) -> List[List[float]]:
 
 def aggregate(rows: List[List[float]]) -> Dict[str, float]:
     """rows[r] = [elapsed_s, env_steps, sum_reward, failed integrations, episodes_done, kernel_ms,
-    (optional:) guard retries, refined sub-steps, rank, seed].
+    (optional:) guard retries, refined sub-steps, rank, seed, first-attempt flags: error estimate, branch invariant, cap /
+    non-finite, heavy].
     Whole-job throughput = all env-steps / the slowest rank's wall time."""
     t_max = max(r[0] for r in rows)
     steps = sum(r[1] for r in rows)
@@ -37,6 +39,8 @@ def aggregate(rows: List[List[float]]) -> Dict[str, float]:
     return {"value": steps / t_max, "t_max": t_max, "env_steps": steps, "sum_reward": sum(r[2] for r in rows),
             "ode_failures": sum(r[3] for r in rows), "episodes_finished": sum(r[4] for r in rows),
             "kernel_ms_max": max(r[5] for r in rows), "guard_retries": sum(col(6)), "refined_substeps": sum(col(7)),
+            "first_attempt_flags": {"error_estimate": sum(col(10)), "branch_invariant": sum(col(11)),
+                                    "cap_or_nonfinite": sum(col(12)), "heavy": sum(col(13))},
             "ranks": [{"rank": int(r[8]) if len(r) > 8 else i, "seed": int(r[9]) if len(r) > 9 else None,
                        "elapsed_s": r[0], "env_steps": r[1], "sum_reward": r[2], "kernel_ms": r[5]}
                       for i, r in enumerate(rows)]}

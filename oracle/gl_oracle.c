@@ -1122,10 +1122,14 @@ static int lu_factor(double *A, int *piv, int n)
 
 static void lu_solve(const double *A, const int *piv, int n, double *b)
 {
-    for (int k = 0; k < n; ++k) {
+    /* lu_factor swaps WHOLE rows (the multipliers already computed included), i.e. it holds P A = L U: apply all of P to b
+     * first, then eliminate.  (Interleaving swap k with elimination k -- what this function did until round 3 -- is only right
+     * when the earlier multipliers stay put; it went unnoticed because I - hJ rarely needs a pivot at the small h of the
+     * extrapolation solver.) */
+    for (int k = 0; k < n; ++k)
         if (piv[k] != k) { double t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
+    for (int k = 0; k < n; ++k)
         for (int i = k + 1; i < n; ++i) b[i] -= A[i * n + k] * b[k];
-    }
     for (int k = n - 1; k >= 0; --k) {
         for (int j = k + 1; j < n; ++j) b[k] -= A[k * n + j] * b[j];
         b[k] /= A[k * n + k];
@@ -1233,4 +1237,203 @@ long gl_oracle_stiff(const double *x0, const double *u, const double *d, const d
     memcpy(x1, x, sizeof x);
     if (n_steps_out) *n_steps_out = nsteps;
     return nfev;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Round 3: a variable-order (1-5), variable-step BDF with modified-Newton iterations and a finite-difference Jacobian that is
+ * reused until the iteration stops converging -- the ALGORITHM FAMILY of the reference's integrator (CasADi "cvodes", BDF +
+ * Newton, abstol = reltol = 1e-6, greenlight_model.cpp:46-63), restated from the published fixed-leading-coefficient scheme in
+ * difference form (Byrne & Hindmarsh 1975; Shampine & Reichelt 1997; the formulation scipy.integrate.BDF documents).  CVODES
+ * itself is absent here and on the GPU box ("parity unpinned" for the integrator); this is its stand-in for (i) the
+ * CPU baseline `bench.py` times beside the GPU (the reference's own CPU path is an adaptive implicit solve, ~200 RHS
+ * evaluations per env-step, not RK4-320's 1 280) and (ii) the tolerance band of the fixtures.  Thread-safe.
+ * Returns the number of RHS evaluations (negative: step size underflow); stats: [steps, Jacobians, LU factorisations, final order].
+ * ---------------------------------------------------------------------------------- */
+#define BDF_MAXORD 5
+static double bdf_rms(const double *v, const double *scale)
+{
+    double e = 0.0;
+    for (int i = 0; i < GL_NX; ++i) { const double r = v[i] / scale[i]; e += r * r; }
+    return sqrt(e / GL_NX);
+}
+
+static void bdf_compute_R(int order, double factor, double R[BDF_MAXORD + 1][BDF_MAXORD + 1])
+{
+    for (int i = 0; i <= order; ++i)
+        for (int j = 0; j <= order; ++j) R[i][j] = 0.0;
+    for (int j = 0; j <= order; ++j) R[0][j] = 1.0;
+    for (int i = 1; i <= order; ++i) {
+        R[i][0] = 0.0;
+        for (int j = 1; j <= order; ++j) R[i][j] = R[i - 1][j] * ((double)(i - 1) - factor * (double)j) / (double)i;
+    }
+    /* column 0 of the cumulative product: M[0][0] = 1, M[i][0] = 0 */
+    R[0][0] = 1.0;
+}
+
+static void bdf_change_D(double D[BDF_MAXORD + 3][GL_NX], int order, double factor)
+{
+    double R[BDF_MAXORD + 1][BDF_MAXORD + 1], U[BDF_MAXORD + 1][BDF_MAXORD + 1], RU[BDF_MAXORD + 1][BDF_MAXORD + 1];
+    double T[BDF_MAXORD + 1][GL_NX];
+    bdf_compute_R(order, factor, R);
+    bdf_compute_R(order, 1.0, U);
+    for (int i = 0; i <= order; ++i)
+        for (int j = 0; j <= order; ++j) {
+            double a = 0.0;
+            for (int k = 0; k <= order; ++k) a += R[i][k] * U[k][j];
+            RU[i][j] = a;
+        }
+    for (int i = 0; i <= order; ++i)
+        for (int c = 0; c < GL_NX; ++c) {
+            double a = 0.0;
+            for (int k = 0; k <= order; ++k) a += RU[k][i] * D[k][c];          /* RU^T D */
+            T[i][c] = a;
+        }
+    for (int i = 0; i <= order; ++i) memcpy(D[i], T[i], sizeof T[i]);
+}
+
+long gl_oracle_bdf(const double *x0, const double *u, const double *d, const double *p, double dt, double rtol, double atol,
+                   double *x1, double *stats)
+{
+    static const double kappa[BDF_MAXORD + 1] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
+    double gamma_[BDF_MAXORD + 1], alpha[BDF_MAXORD + 1], error_const[BDF_MAXORD + 2];
+    gamma_[0] = 0.0;
+    for (int k = 1; k <= BDF_MAXORD; ++k) gamma_[k] = gamma_[k - 1] + 1.0 / (double)k;
+    for (int k = 0; k <= BDF_MAXORD; ++k) alpha[k] = (1.0 - kappa[k]) * gamma_[k];
+    for (int k = 0; k <= BDF_MAXORD; ++k) error_const[k] = kappa[k] * gamma_[k] + 1.0 / (double)(k + 1);
+    const int NEWTON_MAXITER = 4;
+    const double newton_tol = fmax(10.0 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    double D[BDF_MAXORD + 3][GL_NX], y[GL_NX], f[GL_NX], J[GL_NX * GL_NX], LU[GL_NX * GL_NX], scale[GL_NX];
+    int piv[GL_NX];
+    long nfev = 0, nsteps = 0, njev = 0, nlu = 0;
+    memcpy(y, x0, sizeof y);
+    gl_oracle_rhs(y, u, d, p, f, NULL); ++nfev;
+    /* initial step (Hairer, Norsett & Wanner II.4, order 1) */
+    double h_abs;
+    {
+        double y1[GL_NX], f1[GL_NX], df[GL_NX];
+        for (int i = 0; i < GL_NX; ++i) scale[i] = atol + rtol * fabs(y[i]);
+        const double d0 = bdf_rms(y, scale), d1 = bdf_rms(f, scale);
+        const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        for (int i = 0; i < GL_NX; ++i) y1[i] = y[i] + h0 * f[i];
+        gl_oracle_rhs(y1, u, d, p, f1, NULL); ++nfev;
+        for (int i = 0; i < GL_NX; ++i) df[i] = f1[i] - f[i];
+        const double d2 = bdf_rms(df, scale) / h0;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.5);
+        h_abs = fmin(fmin(100.0 * h0, h1), dt);
+    }
+    fd_jacobian(y, f, u, d, p, J, &nfev); ++njev;
+    memset(D, 0, sizeof D);
+    memcpy(D[0], y, sizeof y);
+    for (int i = 0; i < GL_NX; ++i) D[1][i] = f[i] * h_abs;
+    int order = 1, n_equal_steps = 0, lu_valid = 0, current_jac = 1;
+    double t = 0.0;
+    while (t < dt * (1.0 - 1e-14)) {
+        if (h_abs > dt - t) {                                    /* land exactly on dt */
+            bdf_change_D(D, order, (dt - t) / h_abs);
+            h_abs = dt - t; n_equal_steps = 0; lu_valid = 0;
+        }
+        int step_accepted = 0;
+        double y_new[GL_NX], dd[GL_NX], error_norm = 0.0, safety = 0.9;
+        while (!step_accepted) {
+            if (h_abs < 1e-12 * dt) { memcpy(x1, D[0], sizeof y); return -nfev; }
+            const double t_new = t + h_abs;
+            double y_predict[GL_NX], psi[GL_NX];
+            for (int i = 0; i < GL_NX; ++i) {
+                double s = 0.0, ps = 0.0;
+                for (int k = 0; k <= order; ++k) s += D[k][i];
+                for (int k = 1; k <= order; ++k) ps += D[k][i] * gamma_[k];
+                y_predict[i] = s; psi[i] = ps / alpha[order];
+                scale[i] = atol + rtol * fabs(s);
+            }
+            const double c = h_abs / alpha[order];
+            int converged = 0, n_iter = 0;
+            while (!converged) {
+                if (!lu_valid) {
+                    for (int i = 0; i < GL_NX; ++i) {
+                        for (int j = 0; j < GL_NX; ++j) LU[i * GL_NX + j] = -c * J[i * GL_NX + j];
+                        LU[i * GL_NX + i] += 1.0;
+                    }
+                    lu_factor(LU, piv, GL_NX); ++nlu; lu_valid = 1;
+                }
+                /* modified Newton on  y - c f(y) + psi - y_predict ... in the form  (I - cJ) dy = c f(y) - psi - d */
+                memcpy(y_new, y_predict, sizeof y_new);
+                memset(dd, 0, sizeof dd);
+                double dy_norm_old = -1.0, rate = -1.0;
+                converged = 0;
+                for (n_iter = 0; n_iter < NEWTON_MAXITER; ++n_iter) {
+                    double fy[GL_NX], dy[GL_NX];
+                    gl_oracle_rhs(y_new, u, d, p, fy, NULL); ++nfev;
+                    int fin = 1;
+                    for (int i = 0; i < GL_NX; ++i) { fin &= isfinite(fy[i]) ? 1 : 0; dy[i] = c * fy[i] - psi[i] - dd[i]; }
+                    if (!fin) break;
+                    lu_solve(LU, piv, GL_NX, dy);
+                    const double dy_norm = bdf_rms(dy, scale);
+                    if (dy_norm_old >= 0.0) rate = dy_norm / dy_norm_old;
+                    if (getenv("BDF_TRACE")) fprintf(stderr, "   newton it %d dy_norm %.3e rate %.3f c %.4f lu_valid %d\n", n_iter, dy_norm, rate, c, lu_valid);
+                    if (rate >= 0.0 && (rate >= 1.0 || pow(rate, NEWTON_MAXITER - n_iter) / (1.0 - rate) * dy_norm > newton_tol)) break;
+                    for (int i = 0; i < GL_NX; ++i) { y_new[i] += dy[i]; dd[i] += dy[i]; }
+                    if (dy_norm == 0.0 || (rate >= 0.0 && rate / (1.0 - rate) * dy_norm < newton_tol)) { converged = 1; ++n_iter; break; }
+                    dy_norm_old = dy_norm;
+                }
+                if (!converged) {
+                    if (current_jac) break;
+                    gl_oracle_rhs(y_predict, u, d, p, f, NULL); ++nfev;
+                    fd_jacobian(y_predict, f, u, d, p, J, &nfev); ++njev;
+                    lu_valid = 0; current_jac = 1;
+                }
+            }
+            (void)t_new;
+            if (!converged) {
+                h_abs *= 0.5; bdf_change_D(D, order, 0.5); n_equal_steps = 0; lu_valid = 0;
+                continue;
+            }
+            safety = 0.9 * (2.0 * NEWTON_MAXITER + 1.0) / (2.0 * NEWTON_MAXITER + (double)n_iter);
+            double err[GL_NX];
+            for (int i = 0; i < GL_NX; ++i) { scale[i] = atol + rtol * fabs(y_new[i]); err[i] = error_const[order] * dd[i]; }
+            error_norm = bdf_rms(err, scale);
+            if (error_norm > 1.0) {
+                const double factor = fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1)));
+                h_abs *= factor; bdf_change_D(D, order, factor); n_equal_steps = 0; lu_valid = 0;
+            } else {
+                step_accepted = 1;
+            }
+        }
+        ++n_equal_steps; ++nsteps;
+        t += h_abs;
+        if (getenv("BDF_TRACE")) fprintf(stderr, "t %.4f h %.5f order %d err %.3f njev %ld nfev %ld\n", t, h_abs, order, error_norm, njev, nfev);
+        current_jac = 0;
+        for (int i = 0; i < GL_NX; ++i) { D[order + 2][i] = dd[i] - D[order + 1][i]; D[order + 1][i] = dd[i]; }
+        for (int k = order; k >= 0; --k)
+            for (int i = 0; i < GL_NX; ++i) D[k][i] += D[k + 1][i];
+        if (n_equal_steps < order + 1) continue;
+        double em = INFINITY, ep = INFINITY, tmp[GL_NX];
+        if (order > 1) { for (int i = 0; i < GL_NX; ++i) tmp[i] = error_const[order - 1] * D[order][i]; em = bdf_rms(tmp, scale); }
+        if (order < BDF_MAXORD) { for (int i = 0; i < GL_NX; ++i) tmp[i] = error_const[order + 1] * D[order + 2][i]; ep = bdf_rms(tmp, scale); }
+        const double fm = (em > 0.0 && isfinite(em)) ? pow(em, -1.0 / order) : (em == 0.0 ? INFINITY : 0.0);
+        const double f0 = error_norm > 0.0 ? pow(error_norm, -1.0 / (order + 1)) : INFINITY;
+        const double fp = (ep > 0.0 && isfinite(ep)) ? pow(ep, -1.0 / (order + 2)) : (ep == 0.0 ? INFINITY : 0.0);
+        int delta = 0; double best = f0;
+        if (fm > best) { best = fm; delta = -1; }
+        if (fp > best) { best = fp; delta = 1; }
+        order += delta;
+        const double factor = fmin(10.0, safety * best);
+        h_abs *= factor; bdf_change_D(D, order, factor); n_equal_steps = 0; lu_valid = 0;
+    }
+    memcpy(x1, D[0], sizeof y);
+    if (stats) { stats[0] = (double)nsteps; stats[1] = (double)njev; stats[2] = (double)nlu; stats[3] = (double)order; }
+    return nfev;
+}
+
+/* B independent env-steps with gl_oracle_bdf (row-major [B,*], shared p): the all-cores CPU baseline runs one call per thread.
+ * Returns the total number of RHS evaluations; rows whose solve failed are NaN. */
+long gl_oracle_bdf_batch(const double *x0, const double *u, const double *d, const double *p, int B, double dt, double rtol,
+                         double atol, double *x1)
+{
+    long total = 0;
+    for (int b = 0; b < B; ++b) {
+        const long n = gl_oracle_bdf(x0 + (size_t)b * GL_NX, u + (size_t)b * GL_NU, d + (size_t)b * GL_ND, p, dt, rtol, atol,
+                                     x1 + (size_t)b * GL_NX, NULL);
+        if (n < 0) { for (int i = 0; i < GL_NX; ++i) x1[(size_t)b * GL_NX + i] = NAN; total -= n; } else total += n;
+    }
+    return total;
 }

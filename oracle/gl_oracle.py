@@ -58,6 +58,10 @@ def lib():
         L.gl_oracle_rk4_batch.argtypes = [_dp] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_stiff.argtypes = [_dp] * 4 + [ctypes.c_double] * 3 + [_dp, ctypes.POINTER(ctypes.c_long)]
         L.gl_oracle_stiff.restype = ctypes.c_long
+        L.gl_oracle_bdf.argtypes = [_dp] * 4 + [ctypes.c_double] * 3 + [_dp, _dp]
+        L.gl_oracle_bdf.restype = ctypes.c_long
+        L.gl_oracle_bdf_batch.argtypes = [_dp] * 4 + [ctypes.c_int] + [ctypes.c_double] * 3 + [_dp]
+        L.gl_oracle_bdf_batch.restype = ctypes.c_long
         _lib = L
     return _lib
 
@@ -187,6 +191,27 @@ def stiff(x, u, d, p, dt=900.0, rtol=1e-6, atol=1e-6):
     if nfev < 0:
         raise RuntimeError("gl_oracle_stiff: step size underflow")
     return out, int(nfev)
+
+
+def bdf(x, u, d, p, dt=900.0, rtol=1e-6, atol=1e-6):
+    """Variable-order BDF with modified Newton and a reused finite-difference Jacobian (gl_oracle.c gl_oracle_bdf): the
+    algorithm family and tolerances of the reference's CVODES call.  Returns (x_next, n_rhs_evals, [steps, jacobians, LUs, order])."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+    out = np.empty(NX)
+    st = np.zeros(4)
+    nfev = lib().gl_oracle_bdf(_p(x), _p(u), _p(d), _p(p), float(dt), float(rtol), float(atol), _p(out), _p(st))
+    if nfev < 0:
+        raise RuntimeError("gl_oracle_bdf: step size underflow")
+    return out, int(nfev), st
+
+
+def bdf_batch(X, U, D, p, dt=900.0, rtol=1e-6, atol=1e-6):
+    """gl_oracle_bdf over the rows of X / U / D (shared p), inside one C call.  Returns (x_next [B, 28], total RHS evaluations)."""
+    X, U, D, p = _c(X), _c(U), _c(D), _c(p, NP)
+    B = X.shape[0]
+    out = np.empty((B, NX))
+    n = lib().gl_oracle_bdf_batch(_p(X), _p(U), _p(D), _p(p), B, float(dt), float(rtol), float(atol), _p(out))
+    return out, int(n)
 
 
 def scaled_rel_err(X, Xref):

@@ -18,17 +18,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# ---- two-rank bench on ONE GPU (tests/test_gpu_multiproc.py) ---------------------------------------------------------
-# The launcher (python -m torch.distributed.run ... bench.py --gpus 2) has to be a fresh child process started BEFORE this
-# process touches the GPU, so it is started here, at session start, and the test only collects its output.
-# torch.cuda.device_count() does not initialise the GPU.
+# ---- launcher jobs of tests/test_gpu_multiproc.py ------------------------------------------------------------------------
+# `python -m torch.distributed.run ... bench.py` has to be a fresh child process; the jobs are started once the collection
+# shows that their tests will run, and only collected by the tests.  Job "two_rank": bench.py --gpus 2 with both ranks on the
+# one GPU of the box (gloo gather).  Job "rccl_ws1": ONE rank with backend "nccl" (= RCCL): init, barrier and the all_gather
+# of a device tensor on hardware.  (torch.cuda.device_count() initialises the HIP runtime in this process on ROCm; harmless:
+# the launchers are children, nothing here is exec'ed.)
 TWO_RANK = {"proc": None, "log": None}
+RCCL_WS1 = {"proc": None, "log": None}
 
 
-def pytest_sessionstart(session):
+def _launch(job, nproc, extra_env, extra_args):
     import os
-    markexpr = getattr(session.config.option, "markexpr", "") or ""
-    if "gpu" not in markexpr or "not gpu" in markexpr or os.environ.get("GLGYM_SKIP_TWO_RANK") == "1":
+    import socket
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    log = tempfile.NamedTemporaryFile(prefix="glgym_launch_", suffix=".log", delete=False)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(nproc), "--steps", "6", "--warmup", "2",
+           "--batch", "4096", "--no-cpu-baseline", "--no-alt-scheme"] + extra_args
+    job["proc"] = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=str(ROOT))
+    job["log"] = log.name
+
+
+def pytest_collection_finish(session):
+    import os
+    names = {item.name for item in session.items}
+    if os.environ.get("GLGYM_SKIP_TWO_RANK") == "1" or not ({"test_two_rank_bench_on_one_gpu", "test_rccl_at_world_size_one"} & names):
         return
     try:
         import torch
@@ -36,18 +55,26 @@ def pytest_sessionstart(session):
             return
     except Exception:
         return
-    import socket
-    import tempfile
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    log = tempfile.NamedTemporaryFile(prefix="glgym_two_rank_", suffix=".log", delete=False)
-    env = dict(os.environ, GLGYM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--batch", "4096", "--no-cpu-baseline", "--no-alt-scheme"]
-    TWO_RANK["proc"] = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=str(ROOT))
-    TWO_RANK["log"] = log.name
+    if "test_two_rank_bench_on_one_gpu" in names:
+        _launch(TWO_RANK, 2, {"GLGYM_BENCH_SHARE_GPU": "1"}, [])
+    if "test_rccl_at_world_size_one" in names:
+        _launch(RCCL_WS1, 1, {"GLGYM_FORCE_DIST": "1"}, [])
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Never leave a launcher behind (a deselected / aborted test does not wait for it), and remove its log."""
+    import os
+    for job in (TWO_RANK, RCCL_WS1):
+        proc = job["proc"]
+        if proc is not None and proc.poll() is None:
+            proc.terminate()
+            try:
+                proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+        if job["log"] and os.path.exists(job["log"]):
+            os.unlink(job["log"])
+        job["proc"] = job["log"] = None
 
 
 @pytest.fixture(scope="session")

@@ -76,3 +76,23 @@ def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
         y32 = hostmath.step_guarded(X[i], U[i], D[i], p, True, 900.0, 320, 4, 2, verify=True)
         wrong, floor = judge(y32[0][None], XT[i][None], 2e-4)
         assert not y32[3] and wrong == 0, (i, sce(y32[0], XT[i]).max())
+
+
+def test_c_bdf_stand_in_for_cvodes(golden, oracle):
+    """oracle/gl_oracle.c gl_oracle_bdf (variable-order BDF, modified Newton, reused finite-difference Jacobian; rtol = atol =
+    1e-6 -- the algorithm family and tolerances of the reference's CVODES call, greenlight_model.cpp:46-63): what bench.py times
+    as `cpu_baseline`.  Against the tight truth it must sit where scipy's BDF at the same tolerances sits (the fixtures hold
+    that solution), at a comparable number of right-hand sides."""
+    p = golden("params_default")["p"].astype(np.float64)
+    g = golden("step_tight_jump")
+    n = 160
+    got, nfev = oracle.bdf_batch(g["X"][:n], g["U"][:n], g["D"][:n], p)
+    assert np.all(np.isfinite(got))
+    e_c, e_scipy = sce(got, g["X_tight"][:n]).max(axis=1), sce(g["X_bdf"][:n], g["X_tight"][:n]).max(axis=1)
+    print(f"C BDF on {n} jump tuples: max {e_c.max():.1e} median {np.median(e_c):.1e}, {nfev / n:.0f} RHS evaluations per env-step; "
+          f"scipy BDF: max {e_scipy.max():.1e} median {np.median(e_scipy):.1e}")
+    assert e_c.max() < 3 * max(e_scipy.max(), 2e-5) and np.median(e_c) < 3 * np.median(e_scipy) and nfev / n < 800
+    t = golden("step_tight")
+    for i in range(0, len(t["X"]), 5):
+        y, nf, st = oracle.bdf(t["X"][i], t["U"][i], t["D"][i], t["P"][i])
+        assert sce(y, t["X_tight"][i]).max() < 1e-4 and nf < 3 * t["nfev_bdf1e6"][i] + 100, (i, nf)
