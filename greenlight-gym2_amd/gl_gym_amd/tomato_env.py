@@ -179,7 +179,7 @@ class TomatoVecEnv:
         self.c = 86400
         self.nx, self.nu, self.num_params = L.NX, L.NU, L.NP
         weather_is_tensor = weather is not None and hasattr(weather, "data_ptr")          # a torch tensor (device table)
-        self.nd = L.ND if weather is None else int(weather.shape[1])
+        self.nd = L.ND if weather is None else int(np.shape(weather)[1])        # arrays and nested lists alike
         if model_variant not in ("ode", "ode_pipe"):
             raise ValueError("model_variant must be 'ode' or 'ode_pipe'")
         self.model_variant = model_variant
@@ -320,7 +320,7 @@ class TomatoVecEnv:
         L.check(self._lib.glgym_obs(self._h, C.byref(a), self._stream()), "glgym_obs")
 
     def _launch_step(self, raw_control: bool):
-        if self.crop_T is not None:       # noise.py: a fresh draw every step
+        if self.crop_T is not None and not getattr(self, "freeze_crop_noise", False):       # noise.py: a fresh draw every step
             L.check(self._lib.glgym_crop_noise(self._h, self.crop_T.data_ptr(), self.B, self.ld,
                                                self.uncertainty_scale, self.seed_value, self._draw, self._stream()),
                     "glgym_crop_noise")
@@ -378,6 +378,9 @@ class TomatoVecEnv:
                 if self._u_applied_T is None:                        # reset below zeroes for the finished envs
                     self._u_applied_T = self.torch.empty_like(self.u_T)
                 self._u_applied_T.copy_(self.u_T)
+                self._u_applied_valid = True
+            else:
+                self._u_applied_valid = False        # a later host_infos() must not report an EARLIER step's controls
             self._launch_reset(self.done_t)
             if want_obs:
                 self._launch_obs(self.obs_t, self.done_t, self.term_obs_t)
@@ -416,7 +419,7 @@ class TomatoVecEnv:
         # infos: SB3 wants a list of per-env dicts.  Built from two bulk D2H copies (info block, controls) with
         # zip over Python lists -- the cheapest pure-Python construction (about 1 us per env per key).
         rows = info_T.double().t().cpu().numpy()
-        applied = self._u_applied_T if (self.auto_reset and self._u_applied_T is not None) else self.u_T
+        applied = self._u_applied_T if (self.auto_reset and getattr(self, "_u_applied_valid", False)) else self.u_T
         ctrl = applied[:, :self.B].t().double().cpu().numpy()
         term = None
         if self.auto_reset and dones.any():

@@ -93,11 +93,14 @@ class VecMonitorGPU:
 
     def step_wait(self):
         t = self.torch
-        self.venv._keep_applied_u = True            # infos report the controls applied in this step
+        base = self.venv
+        while hasattr(base, "venv"):                # the env at the bottom of the wrapper stack owns the flag
+            base = base.venv
+        base._keep_applied_u = True                 # infos report the controls applied in this step
         try:
             obs_t, r_t, d_t, info_T = self.step_tensor(t.as_tensor(self._actions, device=self.venv.device))
         finally:
-            self.venv._keep_applied_u = False
+            base._keep_applied_u = False
         dones, infos = self.host_infos(d_t, info_T)
         return self.venv._obs_to_host(obs_t), r_t.float().cpu().numpy(), dones, infos
 

@@ -79,7 +79,7 @@ class TomatoVectorEnv(_Base):
         rewards = r_t.double().cpu().numpy()
         term = d_t.cpu().numpy().astype(bool)
         rows = info_T.double().cpu().numpy()                         # [11, B]
-        applied = v._u_applied_T if v._u_applied_T is not None else v.u_T
+        applied = v._u_applied_T if getattr(v, "_u_applied_valid", False) else v.u_T
         infos: Dict[str, Any] = {}
         all_true = np.ones(self.num_envs, dtype=bool)
         for i, key in enumerate(L.INFO_KEYS):

@@ -520,6 +520,7 @@ def _reference_env(season_length=1, uncertainty_scale=0.0, training=True, observ
 
         def evalF(self, x, u, d, p):
             self.n_calls += 1
+            self.last_p = np.array(p, dtype=np.float64)    # what TomatoEnv.step handed over (its local `params`, tomato_env.py:118)
             y, _ = tight_step(np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64),
                               np.asarray(d, dtype=np.float64), np.asarray(p, dtype=np.float64), dt=self.dt)
             return [float(v) for v in y]               # a Python list, like the pybind return
@@ -563,6 +564,8 @@ def g_refenv():
             rec["obs"].append(np.asarray(obs, dtype=np.float64)); rec["reward"].append(float(r))
             rec["info"].append([float(info[q]) for q in INFO]); rec["done"].append(bool(done))
             rec["doy"].append(env.day_of_year); rec["hod"].append(env.hour_of_day)
+            if tag == "un":                      # the parameter block this step was integrated with (tomato_env.py:118)
+                rec.setdefault("p", []).append(env.gl_model.last_p.copy())
             k += 1
         for q, v in rec.items():
             out[f"{tag}_{q}"] = np.array(v)

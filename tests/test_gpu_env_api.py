@@ -405,3 +405,25 @@ def test_weather_pipeline_on_the_device(golden, tmp_path):
     t_host = load_weather_data(str(tmp_path / "w"), "Testville", "GL", 2009, 0, 1, 1, 900.0, 10)
     assert np.max(np.abs(t_dev.cpu().numpy() - t_host) / np.maximum(np.abs(t_host).max(axis=0), 1e-30)) < 1e-12
     wp.close(); wp32.close()
+
+
+def test_host_infos_never_report_an_earlier_steps_controls_and_weather_may_be_a_list(golden):
+    """(advisor, round 2) After an SB3-style step_wait() a later step_tensor() + host_infos() must report the controls of THAT step,
+    not the copy kept for the earlier one; and `weather` may be a nested list."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"][:400]
+    env = TomatoVecEnv(8, weather=w.tolist(), dtype="float32", season_length=1, auto_reset=True)
+    assert env.nd == 10
+    env.reset()
+    rng = np.random.default_rng(0)
+    env.step_async(rng.uniform(-1, 1, (8, 6)).astype(np.float32))
+    _, _, _, infos = env.step_wait()
+    u_first = np.array([infos[b]["controls"] for b in range(8)])
+    out = env.step_tensor(torch.as_tensor(rng.uniform(-1, 1, (8, 6)).astype(np.float32), device=env.device))
+    dones, infos2 = env.host_infos(out[2], out[3])
+    u_now = env.u.double().cpu().numpy()
+    got = np.array([infos2[b]["controls"] for b in range(8)])
+    np.testing.assert_allclose(got, u_now, rtol=0, atol=1e-7)
+    assert np.abs(got - u_first).max() > 1e-3
+    env.close()

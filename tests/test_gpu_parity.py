@@ -319,6 +319,48 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
     env.close()
 
 
+def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
+    """BASELINE config 5 at ITS size (B = 65 536, fp32, the shipped scheme: RK4 n_sub 320 with stability control, guard and
+    per-env crop blocks re-drawn every step): properties that do not depend on the size -- every drawn block within +-10 %
+    (p144 derived), no failed integration over 40 steps, finite states, physical leaf mass -- and 24 environments picked across
+    the batch checked for one step against the oracle's restatement of the SAME controlled scheme fed their 208-vectors."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"]
+    B = 65536
+    env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=10, uncertainty_scale=0.2, seed=99, auto_reset=False)
+    assert env.n_sub == 320 and env.scheme == "rk4"
+    env.reset()
+    gen = torch.Generator(device=env.device); gen.manual_seed(17)
+    for k in range(39):
+        env.step_tensor(torch.rand(B, 6, generator=gen, device=env.device) * 2 - 1, want_obs=False)
+    pick = np.linspace(0, B - 1, 24).astype(int)
+    x_prev = env.x[pick].double().cpu().numpy().copy(); u_prev = env.u[pick].double().cpu().numpy().copy()
+    acts = torch.rand(B, 6, generator=gen, device=env.device) * 2 - 1
+    env.step_tensor(acts, want_obs=False)
+    crop = env.crop_T[:, :B].cpu().numpy()
+    ratio = crop / env.p[128:162, None]
+    assert np.all(np.abs(np.delete(ratio, 16, axis=0) - 1) <= 0.1 + 1e-6)
+    np.testing.assert_allclose(crop[16], crop[13] / crop[14], rtol=3e-7)                  # p144 = p141 / p142 (noise.py:22)
+    assert 0.04 < np.std(ratio[0]) < 0.07                                                # U(-0.1, 0.1): sigma 0.0577
+    xg = env.x[pick].double().cpu().numpy(); a = acts[pick].cpu().numpy()
+    worst = 0.0
+    for j, b in enumerate(pick):
+        p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
+        u = np.clip(u_prev[j] + a[j] * np.float32(0.1), 0, 1)
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 320, 4, 2)
+        assert not failed
+        worst = max(worst, scaled_err(xg[j], ref))
+    m = env.metrics()
+    print(f"config 5 at B = 65 536: 40 steps, failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}, refined sub-steps "
+          f"{m['n_refined_substeps']:.0f}; 24 envs vs the oracle's controlled scheme with their own blocks: {worst:.1e}")
+    assert worst < 5e-5
+    assert m["n_ode_fail"] == 0 and m["n_env_steps"] == 40 * B
+    cleaf = env.x[:, 23]
+    assert torch.isfinite(env.x).all() and float(cleaf.min()) > 5e4 and float(cleaf.max()) < 1.4e5
+    env.close()
+
+
 def test_stability_control_in_storm(golden, oracle):
     """Wind 19.5 m/s with vents and screens open pushes the top-compartment exchange rate past RK4-256's stability
     limit during the step: the plain fixed-step scheme overflows there.  The stability control gives those windows
