@@ -1415,7 +1415,7 @@ template <class T, bool PIPE> struct RhsStage {
         slow_coef<T>(ym, s, m, cr, q);
     }
 };
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_F64_INLINE)
 template <bool PIPE> struct RhsStage<double, PIPE> {
     static constexpr bool UNIFORM_CALLS = true;
     // once per integration: the per-env-step coefficients, the crop constants and (uniform) the model constants

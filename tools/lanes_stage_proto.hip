@@ -1,0 +1,385 @@
+// Whole-stage prototype of the north-star layout "several lanes per environment" (round-2 review, item 3): the COMPLETE fast
+// right-hand side of gl_model.hpp (rhs_fast: long-wave network, all exchange laws, screens, ventilation, air streams, saturation
+// pressures, condensation gates, transpiration, the 18 fast balances + the constant-rate states) evaluated by FOUR lanes per
+// environment, inside the dependent chain of classical RK4 sub-steps, against the product's one-lane-per-environment code
+// compiled from the same header in the same translation unit.
+//
+// Layout (16 environments per wavefront): lane r of a quad owns one PAIR of radiating surfaces -- the pairs the product
+// already packs into v_pk_* registers -- r = 0: (tCan, tPipe), 1: (tFlr, tLamp), 2: (tThScr, tBlScr), 3: (tCovIn, tCovE) --
+// plus a quarter of the slow / constant-rate states; the six air-side states (co2Air, co2Top, tAir, tTop, vpAir, vpTop) are
+// carried redundantly by all four lanes.  Every surface is one row of the same algebra with per-lane coefficients:
+//     net_i = src_i + sum_j C_ij (q_j - q_i) + C_i,sky (q_sky - q_i)            long wave, q = (T + 273.15)^4
+//             + cA_i |dA_i|^nA_i dA_i            exchange with its air node A (air | top | outside),  dA = T_A - T_i
+//             + L wet_i hecA_i gate(vp_A - satVp(T_i))                         condensation on the wet surfaces
+//             - cB_i |dB_i|^(1/3) dB_i           second exchange (screens -> top compartment),        dB = T_i - tTop
+//             -+ cP (T_x - T_y)                  conduction inside the pair (cover in / out)
+//             - L mvCanAir                       transpiration (canopy)
+// Lanes talk through DPP quad_perm only (full crossbar inside 4 lanes, no LDS): 8 moves gather the eight q's, 4 x 2 DPP adds
+// reduce the four sums the air / top balances need (heat and vapour to the air, heat and vapour to the top compartment).
+//
+// What is measured: n_sub classical RK4 sub-steps (4 stages each, fixed h, tier 2b frozen -- the product's inner loop without
+// its per-window control) from identical inputs, (a) product layout, (b) quad layout; max |difference| of the 28 states; time
+// per env-step at several batch sizes; fp32 and fp64.
+// Build:  hipcc -O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp --offload-arch=gfx950 -std=c++17 -Iinclude
+//               -Igreenlight-gym2_amd/csrc tools/lanes_stage_proto.hip -o tools/lanes_stage_proto
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "gl_model.hpp"
+
+using namespace glm;
+#define CHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 1; } } while (0)
+
+// ---- pairs: float -> one v_pk_* register pair, double -> two registers ------------------------------------------------------
+struct D2 { double x, y; };
+__device__ __forceinline__ D2 operator+(D2 a, D2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ D2 operator-(D2 a, D2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ D2 operator*(D2 a, D2 b) { return {a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ D2 operator-(D2 a) { return {-a.x, -a.y}; }
+template <class T> struct PairOf;
+typedef float pf2 __attribute__((ext_vector_type(2)));
+template <> struct PairOf<float> { typedef pf2 type; };
+template <> struct PairOf<double> { typedef D2 type; };
+template <class T> using P2 = typename PairOf<T>::type;
+template <class T> __device__ __forceinline__ P2<T> mk(T a, T b) { P2<T> r; r.x = a; r.y = b; return r; }
+template <class T> __device__ __forceinline__ P2<T> sp(T a) { return mk<T>(a, a); }
+#define PW(T, expr_x, expr_y) mk<T>((expr_x), (expr_y))
+
+// ---- DPP inside a quad ------------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp(double v)
+{
+    // two 32-bit DPP moves on the halves, kept apart from each other (hipcc 7.2 otherwise fuses them into a 64-bit DPP move,
+    // which gfx950 implements for row_newbcast only: the quad_perm pattern came back with garbage in this prototype)
+    unsigned lo = (unsigned)__builtin_bit_cast(unsigned long long, v), hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    asm volatile("" : "+v"(lo));
+    asm volatile("" : "+v"(hi));
+    unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+    asm volatile("" : "+v"(rl));
+    unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+    asm volatile("" : "+v"(rh));
+    return __builtin_bit_cast(double, ((unsigned long long)rh << 32) | rl);
+}
+template <int S, class T> __device__ __forceinline__ T bcast(T v) { return dpp<S * 0x55>(v); }       // lane S of the quad
+template <class T> __device__ __forceinline__ T quad_sum(T v) { v += dpp<0xB1>(v); v += dpp<0x4E>(v); return v; }
+
+// ---- per-lane coefficients (functions of the lane's role, the env-step's StepCoef and the window's SlowCoef) ----------------
+template <class T> struct LaneK {
+    P2<T> cA, nA, cA2, nA2;     // exchange with node A; the "2" set applies where dA < 0 (the floor's two regimes), else equal
+    P2<T> cB;                   // second exchange (to the top compartment): the two screens
+    P2<T> src, iCap, wetC, mAir, mTop, trK;
+    P2<T> firX[4], firY[4];     // C[own x|y][lane s .x] and C[own x|y][lane s .y]
+    P2<T> cSky;
+    T cP;                       // conduction inside the pair (cover)
+    int role;
+};
+
+template <class T>
+__device__ void make_lane(int role, const StepCoef<T>& s, const ModelConst<T>& m, const SlowCoef<T>& q, LaneK<T>& K)
+{
+    const T z = T(0), one = T(1), third = T(1.0 / 3.0);
+    // symmetric long-wave coefficient matrix over (Can, Pipe, Flr, Lamp, ThScr, BlScr, CovIn, CovE) + sky (FirBlock::run)
+    T C[8][8], S[8];
+    for (int i = 0; i < 8; ++i) { S[i] = z; for (int j = 0; j < 8; ++j) C[i][j] = z; }
+    auto set = [&](int i, int j, T c) { C[i][j] = c; C[j][i] = c; };
+    enum { CAN, PIPE, FLR, LAMP, TH, BL, CIN, CE };
+    set(CAN, CIN, q.kCanCovIn); set(CAN, TH, q.kCanThScr); set(CAN, FLR, q.kCanFlr); set(CAN, BL, q.kCanBlScr);
+    set(PIPE, CIN, q.kPipeCovIn); set(PIPE, TH, q.kPipeThScr); set(PIPE, BL, q.kPipeBlScr); set(PIPE, FLR, m.fPipeFlr);
+    set(PIPE, CAN, q.kPipeCan); set(FLR, CIN, q.kFlrCovIn); set(FLR, TH, q.kFlrThScr); set(FLR, BL, q.kFlrBlScr);
+    set(TH, CIN, s.cThScrCovIn); set(LAMP, FLR, q.kLampFlr); set(LAMP, PIPE, q.kLampPipe); set(LAMP, CAN, q.kLampCan);
+    set(LAMP, TH, s.cLampThScr); set(LAMP, CIN, s.cLampCovIn); set(LAMP, BL, s.cLampBlScr); set(BL, TH, s.cBlScrThScr);
+    set(BL, CIN, s.cBlScrCovIn);
+    S[CAN] = q.kCanSky; S[PIPE] = q.kPipeSky; S[FLR] = q.kFlrSky; S[TH] = s.cThScrSky; S[CE] = m.fCovESky; S[LAMP] = s.cLampSky;
+    S[BL] = s.cBlScrSky;
+    const int ix = 2 * role, iy = 2 * role + 1;
+    for (int l = 0; l < 4; ++l) { K.firX[l] = mk<T>(C[ix][2 * l], C[iy][2 * l]); K.firY[l] = mk<T>(C[ix][2 * l + 1], C[iy][2 * l + 1]); }
+    K.cSky = mk<T>(S[ix], S[iy]);
+    K.role = role;
+    K.cB = mk<T>(z, z); K.cP = z; K.wetC = mk<T>(z, z); K.trK = mk<T>(z, z);
+    K.mAir = mk<T>(one, one); K.mTop = mk<T>(z, z);
+    const T L64 = T(6.4e-9);
+    if (role == 0) {            // (canopy, pipe)
+        K.cA = mk<T>(q.hCanAirK, m.cPipeAir); K.nA = mk<T>(z, T(0.32)); K.cA2 = K.cA; K.nA2 = K.nA;
+        K.src = mk<T>(q.swCan + q.rGroPipeCan, s.hBoilPipe); K.iCap = mk<T>(q.iCapCan, m.iCapPipe);
+        K.trK = mk<T>(q.mvCanK, z);
+    } else if (role == 1) {     // (floor, lamp)
+        K.cA = mk<T>(T(1.3), m.cLampAir); K.nA = mk<T>(T(0.25), z); K.cA2 = mk<T>(T(1.7), m.cLampAir); K.nA2 = mk<T>(third, z);
+        K.src = mk<T>(q.swFlr - q.hFlrSo1, s.lampNet); K.iCap = mk<T>(m.iCapFlr, m.iCapLamp);
+    } else if (role == 2) {     // (thermal screen, blackout screen)
+        K.cA = mk<T>(s.hTh, s.hBl); K.nA = mk<T>(third, third); K.cA2 = K.cA; K.nA2 = K.nA;
+        K.cB = mk<T>(s.hTh, s.hBl); K.src = mk<T>(z, z); K.iCap = mk<T>(m.iCapThScr, m.iCapBlScr); K.wetC = mk<T>(L64, L64);
+    } else {                    // (cover inside, cover outside): node A = (top compartment, outside air)
+        K.cA = mk<T>(m.cTopCov, s.covOutK); K.nA = mk<T>(third, z); K.cA2 = K.cA; K.nA2 = K.nA;
+        K.src = mk<T>(z, s.sunCovE); K.iCap = mk<T>(m.iCapCov, m.iCapCov); K.wetC = mk<T>(L64, z); K.cP = m.cCovCond;
+        K.mAir = mk<T>(z, z); K.mTop = mk<T>(one, z);
+    }
+}
+
+// ---- one stage: own pair Tp, shared air-side states sh[6] = co2Air co2Top tAir tTop vpAir vpTop -> dTp, dsh[6] ----------------
+template <class T>
+__device__ __forceinline__ void stage_quad(P2<T> Tp, const T* sh, const LaneK<T>& K, const StepCoef<T>& s, const ModelConst<T>& m,
+                                           const SlowCoef<T>& q, P2<T>& dTp, T* dsh, T& tCanOut)
+{
+    using M = Math<T>;
+    const T one = T(1), eps = T(1e-10), c2k = Kelvin<T>::c2k(), third = T(1.0 / 3.0);
+    const T co2Air = sh[0], co2Top = sh[1], tAir = sh[2], tTop = sh[3], vpAir = sh[4], vpTop = sh[5];
+    // ---- long wave: gather the eight q's (8 DPP moves incl. the lane's own), 4 source lanes x 2 packed terms
+    const P2<T> kk = Tp + sp<T>(c2k), k2 = kk * kk, qp = k2 * k2;
+    P2<T> fir = K.cSky * (sp<T>(s.qSky) - qp);
+    {
+        const T q0x = bcast<0>(qp.x), q0y = bcast<0>(qp.y), q1x = bcast<1>(qp.x), q1y = bcast<1>(qp.y);
+        const T q2x = bcast<2>(qp.x), q2y = bcast<2>(qp.y), q3x = bcast<3>(qp.x), q3y = bcast<3>(qp.y);
+        fir = fir + K.firX[0] * (sp<T>(q0x) - qp) + K.firY[0] * (sp<T>(q0y) - qp);
+        fir = fir + K.firX[1] * (sp<T>(q1x) - qp) + K.firY[1] * (sp<T>(q1y) - qp);
+        fir = fir + K.firX[2] * (sp<T>(q2x) - qp) + K.firY[2] * (sp<T>(q2y) - qp);
+        fir = fir + K.firX[3] * (sp<T>(q3x) - qp) + K.firY[3] * (sp<T>(q3y) - qp);
+    }
+    // ---- exchange with node A
+    const bool cov = K.role == 3;
+    const P2<T> TA = mk<T>(cov ? tTop : tAir, cov ? s.tOut : tAir);
+    const P2<T> dA = TA - Tp;
+    const P2<T> nA = mk<T>(dA.x < T(0) ? K.nA2.x : K.nA.x, dA.y < T(0) ? K.nA2.y : K.nA.y);
+    const P2<T> cA = mk<T>(dA.x < T(0) ? K.cA2.x : K.cA.x, dA.y < T(0) ? K.cA2.y : K.cA.y);
+    const P2<T> hecA = cA * mk<T>(M::powa(M::abs(dA.x) + eps, nA.x), M::powa(M::abs(dA.y) + eps, nA.y));
+    const P2<T> fluxA = hecA * dA;                                   // into the surface
+    // ---- second exchange: screens -> top compartment
+    const P2<T> dB = Tp - sp<T>(tTop);
+    const P2<T> fluxB = K.cB * mk<T>(M::powa(M::abs(dB.x) + eps, third), M::powa(M::abs(dB.y) + eps, third)) * dB;
+    // ---- saturation pressure, condensation gate, transpiration
+    const P2<T> rr = mk<T>(M::rcp(Tp.x + T(238.3)), M::rcp(Tp.y + T(238.3)));
+    const P2<T> sv = sp<T>(T(610.78)) * mk<T>(M::expk(T(17.2694), Tp.x * rr.x), M::expk(T(17.2694), Tp.y * rr.y));
+    const P2<T> dv = mk<T>(cov ? vpTop : vpAir, vpAir) - sv;
+    const P2<T> g = dv * mk<T>(M::rcp(one + M::expk(T(-0.1), dv.x)), M::rcp(one + M::expk(T(-0.1), dv.y)));
+    const P2<T> mv = K.wetC * hecA * g;                              // vapour condensing on the surface
+    const T vpd = sv.x - vpAir;                                      // canopy lane: x = canopy
+    const T co2Dev = m.etaMgPpm * co2Air - T(200);
+    const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
+    const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
+    const T mvCan = vpd * K.trK.x * M::rcp(m.rB + s.rSK * rfCo2 * rfVp);
+    // ---- the pair's balances
+    const T cond = K.cP * (Tp.x - Tp.y);
+    const T L = m.latent;
+    P2<T> net = K.src + fir + fluxA + sp<T>(L) * mv - fluxB + mk<T>(-cond - L * mvCan, cond);
+    dTp = K.iCap * net;
+    // ---- sums the air / top balances need (4 x quad_sum)
+    const P2<T> fa = fluxA * K.mAir, ft = fluxA * K.mTop, ma = mv * K.mAir, mt = mv * K.mTop;
+    const T sHeatAir = quad_sum(-(fa.x + fa.y));                     // surfaces -> air
+    const T sHeatTop = quad_sum((fluxB.x + fluxB.y) - (ft.x + ft.y));
+    const T sVapAir = quad_sum(mvCan - (ma.x + ma.y));
+    const T sVapTop = quad_sum(-(mt.x + mt.y));
+    tCanOut = bcast<0>(Tp.x);
+    // ---- air side (identical in the four lanes): ventilation, screen air flux, air streams (rhs_fast)
+    const T dTOut = tAir - s.tOut;
+    const T buoy = m.gHVent * dTOut * M::rcp(tAir + s.tOutK2);
+    const T fVentRoof = s.ventK * M::sqrt(M::abs(buoy + s.windTerm)) + s.ventElse + s.leakTop;
+    const T tAirK = tAir + c2k, tTopK = tTop + c2k;
+    const T iAirK = M::rcp(tAirK), iTopK = M::rcp(tTopK);
+    const T rhoMean = T(0.5) * m.kRho * (iAirK + iTopK);
+    const T dRho = M::abs(m.kRho * (tTop - tAir) * iAirK * iTopK);
+    const T pw66 = M::powa(M::abs(tAir - tTop + eps), T(0.66));
+    const T iRhoMean = M::rcp(rhoMean);
+    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
+    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
+    const T fScrAbs = M::abs(M::min(fTh, fBl)), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
+    T vAirOverT, vTopOverT;
+    if (sizeof(T) == 8) { vAirOverT = vpAir * M::rcp(tAir + Kelvin<T>::c2kF32()); vTopOverT = vpTop * M::rcp(tTop + Kelvin<T>::c2kF32()); }
+    else { vAirOverT = vpAir * iAirK; vTopOverT = vpTop * iTopK; }
+    const T kMv = T(0.002165);
+    const T hAirTop = m.rhoCp * fScrAbs * (tAir - tTop), hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
+    const T mvAirTop = kMv * fScrAbs * (vAirOverT - vTopOverT), mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
+    const T mcAirTop = fScrAbs * (co2Air - co2Top), mcTopOut = fRoofAbs * (co2Top - s.co2Out);
+    const T mvAirOut = kMv * fSideAbs * (vAirOverT - s.vpOutOverT), mcAirOut = fSideAbs * (co2Air - s.co2Out);
+    const T hAirOut = s.hAirOutK * dTOut;
+    dsh[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
+    dsh[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
+    dsh[2] = m.iCapAir * (sHeatAir + q.swAir - hAirOut - hAirTop + q.hGroPipeAir);
+    dsh[3] = m.iCapTop * (sHeatTop + hAirTop - hTopOut);
+    dsh[4] = m.kCapVpAir * tAirK * (sVapAir - mvAirTop - mvAirOut);
+    dsh[5] = m.kCapVpTop * tTopK * (sVapTop + mvAirTop - mvTopOut);
+}
+
+// state index of the lane's pair, and of its four "other" states (slow / constant-rate): lane 0 carries tCan24, tCanSum
+__host__ __device__ constexpr int pair_ix(int role, int c) { return role == 0 ? (c ? 9 : 4) : role == 1 ? (c ? 17 : 8) : role == 2 ? (c ? 20 : 7) : (c ? 6 : 5); }
+__host__ __device__ constexpr int other_ix(int role, int j)
+{
+    return role == 0 ? (j == 0 ? 21 : j == 1 ? 26 : j == 2 ? 10 : 11) : role == 1 ? (j == 0 ? 12 : j == 1 ? 13 : j == 2 ? 14 : 19)
+           : role == 2 ? (j == 0 ? 22 : j == 1 ? 23 : j == 2 ? 24 : 25) : (j == 0 ? 18 : 27);   // lane 3: two slots unused
+}
+__host__ __device__ constexpr int sh_ix(int i) { return i < 4 ? i : 11 + i; }      // 0 1 2 3 15 16
+
+template <class T>
+__global__ __launch_bounds__(64) void quad_kernel(const T* __restrict__ X0, const T* __restrict__ U, const T* __restrict__ D,
+                                                  ModelConst<T> m, T* __restrict__ X1, int B, int n_sub, T h)
+{
+    const int gl = blockIdx.x * 64 + threadIdx.x, role = gl & 3;
+    const int b = min(gl >> 2, B - 1);
+    T x0[NX], u[NU], d[7];
+    for (int i = 0; i < NX; ++i) x0[i] = X0[(size_t)b * NX + i];
+    for (int i = 0; i < NU; ++i) u[i] = U[(size_t)b * NU + i];
+    for (int i = 0; i < 7; ++i) d[i] = D[(size_t)b * ND + i];
+    StepCoef<T> s; SlowCoef<T> q;
+    precompute(u, d, m, m.crop, s);
+    slow_coef(x0, s, m, m.crop, q);                       // tier 2b once (frozen: the product re-evaluates it per window)
+    LaneK<T> K;
+    make_lane(role, s, m, q, K);
+    P2<T> yP = mk<T>(x0[pair_ix(role, 0)], x0[pair_ix(role, 1)]);
+    T ysh[6], yo[4], ro[4];
+    for (int i = 0; i < 6; ++i) ysh[i] = x0[sh_ix(i)];
+    for (int j = 0; j < 4; ++j) yo[j] = x0[other_ix(role, j)];
+    // rates of the constant-rate states (tier 2b): soil layers, grow pipe, crop pools
+    T rate[NX];
+    for (int i = 0; i < NX; ++i) rate[i] = T(0);
+    rate[10] = q.dSo1; rate[11] = q.dSo2; rate[12] = q.dSo3; rate[13] = q.dSo4; rate[14] = q.dSo5; rate[19] = q.dGro;
+    rate[22] = q.dBuf; rate[23] = q.dLeaf; rate[24] = q.dStem; rate[25] = q.dFruit; rate[27] = T(1.0 / 86400.0);
+    for (int j = 0; j < 4; ++j) ro[j] = rate[other_ix(role, j)];
+    const T perDay = T(1.0 / 86400.0), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+    const bool lane0 = role == 0;
+    for (int it = 0; it < n_sub; ++it) {
+        P2<T> kP, accP, xP;
+        T ksh[6], accsh[6], xsh[6], ko[4], acco[4], xo[4], tCan;
+        auto eval = [&](P2<T> p, const T* shv, const T* ov) {
+            stage_quad<T>(p, shv, K, s, m, q, kP, ksh, tCan);
+            ko[0] = lane0 ? perDay * (tCan - ov[0]) : ro[0];      // lane 0: tCan24, tCanSum
+            ko[1] = lane0 ? perDay * tCan : ro[1];
+            ko[2] = ro[2]; ko[3] = ro[3];
+        };
+        eval(yP, ysh, yo);
+        accP = kP; xP = yP + sp<T>(h2) * kP;
+        for (int i = 0; i < 6; ++i) { accsh[i] = ksh[i]; xsh[i] = ysh[i] + h2 * ksh[i]; }
+        for (int j = 0; j < 4; ++j) { acco[j] = ko[j]; xo[j] = yo[j] + h2 * ko[j]; }
+        eval(xP, xsh, xo);
+        accP = accP + sp<T>(T(2)) * kP; xP = yP + sp<T>(h2) * kP;
+        for (int i = 0; i < 6; ++i) { accsh[i] += T(2) * ksh[i]; xsh[i] = ysh[i] + h2 * ksh[i]; }
+        for (int j = 0; j < 4; ++j) { acco[j] += T(2) * ko[j]; xo[j] = yo[j] + h2 * ko[j]; }
+        eval(xP, xsh, xo);
+        accP = accP + sp<T>(T(2)) * kP; xP = yP + sp<T>(h) * kP;
+        for (int i = 0; i < 6; ++i) { accsh[i] += T(2) * ksh[i]; xsh[i] = ysh[i] + h * ksh[i]; }
+        for (int j = 0; j < 4; ++j) { acco[j] += T(2) * ko[j]; xo[j] = yo[j] + h * ko[j]; }
+        eval(xP, xsh, xo);
+        yP = yP + sp<T>(h6) * (accP + kP);
+        for (int i = 0; i < 6; ++i) ysh[i] += h6 * (accsh[i] + ksh[i]);
+        for (int j = 0; j < 4; ++j) yo[j] += h6 * (acco[j] + ko[j]);
+    }
+    if ((gl >> 2) < B) {
+        T* o = X1 + (size_t)b * NX;
+        o[pair_ix(role, 0)] = yP.x; o[pair_ix(role, 1)] = yP.y;
+        for (int j = 0; j < (role == 3 ? 2 : 4); ++j) o[other_ix(role, j)] = yo[j];
+        if (role == 0) for (int i = 0; i < 6; ++i) o[sh_ix(i)] = ysh[i];
+    }
+}
+
+// the product layout: one lane per environment, rhs_fast as the kernels call it (packed FIR / screen / balance blocks in fp32)
+template <class T>
+__global__ __launch_bounds__(64) void one_kernel(const T* __restrict__ X0, const T* __restrict__ U, const T* __restrict__ D,
+                                                 ModelConst<T> m, T* __restrict__ X1, int B, int n_sub, T h)
+{
+    const int b = min((int)(blockIdx.x * 64 + threadIdx.x), B - 1);
+    T y[NX], xs[NX], k[NX], acc[NX], u[NU], d[7];
+    for (int i = 0; i < NX; ++i) y[i] = X0[(size_t)b * NX + i];
+    for (int i = 0; i < NU; ++i) u[i] = U[(size_t)b * NU + i];
+    for (int i = 0; i < 7; ++i) d[i] = D[(size_t)b * ND + i];
+    StepCoef<T> s; SlowCoef<T> q;
+    precompute(u, d, m, m.crop, s);
+    slow_coef(y, s, m, m.crop, q);
+    const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+    for (int it = 0; it < n_sub; ++it) {
+        rhs_fast<T, false, false, false, false>(y, q, s, m, m.crop, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = y[i] + h2 * k[i]; }
+        rhs_fast<T, false, false, false, false>(xs, q, s, m, m.crop, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h2 * k[i]; }
+        rhs_fast<T, false, false, false, false>(xs, q, s, m, m.crop, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = y[i] + h * k[i]; }
+        rhs_fast<T, false, false, false, false>(xs, q, s, m, m.crop, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] += h6 * (acc[i] + k[i]);
+    }
+    if ((int)(blockIdx.x * 64 + threadIdx.x) < B)
+        for (int i = 0; i < NX; ++i) X1[(size_t)b * NX + i] = y[i];
+}
+
+template <class T> int run(const char* name, const double* p, const std::vector<int>& batches, int n_sub)
+{
+    ModelConst<T> m;
+    memset(&m, 0, sizeof m);
+    make_model_const<T>(p, m);
+    const int Bmax = 65536;
+    std::vector<T> hx((size_t)Bmax * NX), hu((size_t)Bmax * NU), hd((size_t)Bmax * ND);
+    // a plausible night state (init_state-like) with per-env jitter; controls / weather varied per env
+    const double x0[NX] = {800, 790, 16.5, 15.0, 17.2, 9.0, 8.2, 15.6, 15.9, 45.0, 16.0, 15.5, 15.0, 14.5, 14.0, 1400, 1150, 18.0, 16.5,
+                           16.4, 15.7, 19.0, 8000, 95283, 251070, 55338, 3097.8, 0.1};
+    unsigned long long rs = 88172645463325252ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (double)(rs >> 11) / 9007199254740992.0; };
+    for (int b = 0; b < Bmax; ++b) {
+        for (int i = 0; i < NX; ++i) hx[(size_t)b * NX + i] = (T)(x0[i] * (1.0 + 0.02 * (rnd() - 0.5)));
+        const double uu[NU] = {rnd(), rnd(), rnd() * (b % 3 ? 1 : 0), rnd(), rnd(), rnd() * (b % 2)};
+        for (int i = 0; i < NU; ++i) hu[(size_t)b * NU + i] = (T)uu[i];
+        const double tout = 2.0 + 12.0 * rnd();
+        const double dd[ND] = {b % 4 ? 0.0 : 300.0 * rnd(), tout, 600 + 400 * rnd(), 730 + 40 * rnd(), 1 + 9 * rnd(), tout - 5 - 10 * rnd(), 10.0,
+                               5.0, 0, 0};
+        for (int i = 0; i < ND; ++i) hd[(size_t)b * ND + i] = (T)dd[i];
+    }
+    T *dx, *du, *dd_, *o1, *o4;
+    CHK(hipMalloc(&dx, hx.size() * sizeof(T))); CHK(hipMalloc(&du, hu.size() * sizeof(T))); CHK(hipMalloc(&dd_, hd.size() * sizeof(T)));
+    CHK(hipMalloc(&o1, hx.size() * sizeof(T))); CHK(hipMalloc(&o4, hx.size() * sizeof(T)));
+    CHK(hipMemcpy(dx, hx.data(), hx.size() * sizeof(T), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(du, hu.data(), hu.size() * sizeof(T), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(dd_, hd.data(), hd.size() * sizeof(T), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const T h = (T)(900.0 / n_sub);
+    if (getenv("N_IT")) n_sub = atoi(getenv("N_IT"));
+    printf("%s: %d classical RK4 sub-steps (4 stages each) per env-step, h = %.4f s\n", name, n_sub, (double)h);
+    for (int B : batches) {
+        float ms1 = 0, ms4 = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(one_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, 0, dx, du, dd_, m, o1, B, n_sub, h);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms1, e0, e1));
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(quad_kernel<T>, dim3((4 * B + 63) / 64), dim3(64), 0, 0, dx, du, dd_, m, o4, B, n_sub, h);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms4, e0, e1));
+        }
+        CHK(hipGetLastError());
+        std::vector<T> a((size_t)B * NX), c((size_t)B * NX);
+        CHK(hipMemcpy(a.data(), o1, a.size() * sizeof(T), hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(c.data(), o4, c.size() * sizeof(T), hipMemcpyDeviceToHost));
+        double worst = 0; int wi = -1; bool fin = true; long nan1 = 0, nan4 = 0;
+        for (size_t i = 0; i < a.size(); ++i) {
+            if ((i % NX) == 18) continue;                          // interlight temperature: not integrated by the quad layout (inactive)
+            const double sc = fmax(fabs((double)a[i]), 1e-3 * fabs(x0[i % NX]) + 1e-30);
+            const double e = fabs((double)a[i] - (double)c[i]) / sc;
+            fin = fin && std::isfinite((double)a[i]) && std::isfinite((double)c[i]);
+            nan1 += !std::isfinite((double)a[i]); nan4 += !std::isfinite((double)c[i]);
+            if (e > worst) { worst = e; wi = (int)(i % NX); }
+        }
+        printf("  B = %6d: one lane per env %8.3f ms (%.3e env-steps/s) | four lanes per env %8.3f ms (%.3e env-steps/s) | x%.2f | max scaled "
+               "|difference| %.1e (state %d)", B, ms1, B / (ms1 * 1e-3), ms4, B / (ms4 * 1e-3), ms1 / ms4, worst, wi);
+        if (!fin) printf("  NON-FINITE entries: one-lane %ld, four-lane %ld; first env one-lane x[2..6] = %g %g %g %g %g, four-lane %g %g %g %g %g", nan1, nan4,
+                         (double)a[2], (double)a[3], (double)a[4], (double)a[5], (double)a[6], (double)c[2], (double)c[3], (double)c[4], (double)c[5], (double)c[6]);
+        printf("\n");
+        if (!fin && getenv("DUMP")) { for (int i = 0; i < NX; ++i) printf("      x[%d] one %.10g four %.10g\n", i, (double)a[i], (double)c[i]); }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    // the default parameter block comes from the Python side: argv[1] = file with 208 doubles (text)
+    double p[NP];
+    FILE* f = fopen(argc > 1 ? argv[1] : "tools/params_default.txt", "r");
+    if (!f) { printf("usage: lanes_stage_proto params_default.txt\n"); return 2; }
+    for (int i = 0; i < NP; ++i) if (fscanf(f, "%lf", &p[i]) != 1) { printf("bad parameter file\n"); return 2; }
+    fclose(f);
+    const int n_sub = getenv("N_SUB") ? atoi(getenv("N_SUB")) : 320;
+    if (run<float>("fp32", p, {8, 64, 1024, 4096, 16384, 65536}, n_sub)) return 1;
+    if (run<double>("fp64", p, {8, 1024, 4096, 16384}, n_sub)) return 1;
+    return 0;
+}
