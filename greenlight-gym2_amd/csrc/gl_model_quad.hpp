@@ -1,0 +1,470 @@
+// gl_model_quad.hpp -- the north-star layout: SEVERAL LANES PER ENVIRONMENT (four), for batches that leave SIMDs idle.
+//
+// gl_model.hpp integrates one environment per lane: 28 states, ~370 vector instructions per stage, and a lone wavefront is
+// issued one of them only every ~5 cycles -- 1 ms per env-step whether the batch holds 8 environments or 65 536.  Below 16 384
+// environments most of the chip's 1 024 SIMDs hold no wave at all.  Here a QUAD of lanes integrates one environment (16 per
+// wavefront); the stage's instruction stream shrinks to what one lane of the quad has to do:
+//   lane r owns one PAIR of radiating surfaces -- the pairs gl_model.hpp already packs into v_pk_* registers -- r = 0: (tCan,
+//   tPipe), 1: (tFlr, tLamp), 2: (tThScr, tBlScr), 3: (tCovIn, tCovE) -- and a quarter of the slow / constant-rate states; the six
+//   air-side states (co2Air, co2Top, tAir, tTop, vpAir, vpTop) are carried redundantly by all four lanes.  Every surface is one
+//   row of the same algebra with per-lane coefficients (LaneK):
+//       net_i = src_i + sum_j C_ij (q_j - q_i) + C_i,sky (q_sky - q_i)          long wave, q = (T + 273.15)^4
+//               + cA_i |dA_i|^nA_i dA_i          exchange with its air node A (air | top | outside),  dA = T_A - T_i
+//               + L wet_i hecA_i gate(vp_A - satVp(T_i))                        condensation on the wet surfaces
+//               - cB_i |dB_i|^(1/3) dB_i         second exchange (screens -> top compartment),        dB = T_i - tTop
+//               -+ cP (T_x - T_y)                conduction inside the pair (cover in / out)
+//               - L mvCanAir                     transpiration (canopy)
+//   Lanes talk through DPP quad_perm only (a full crossbar inside four lanes, no LDS): 8 moves gather the eight q's per stage,
+//   4 x 2 DPP adds reduce the four sums the air / top balances need; per window ~20 more broadcast the inputs of tier 2b and
+//   of the rate bound.
+// Same scheme as rk_delta / rk4_delta_guarded of gl_model.hpp, decision for decision (windows, tier 2b at the predicted
+// midpoint, exact harvest sub-flow, wet surfaces as differences to their air node, rate bound -> sub-steps per window, movement
+// limiter, embedded error estimate, branch invariant, closing evaluation, step-doubling ladder): the oracle's restatement
+// (oracle/gl_oracle.c rk_sc_impl) is the reference for both layouts.  Classical RK4, default ODE variant, shared crop parameters,
+// interlights off (what the reference configures); everything else stays on the one-lane kernels.
+// Measured (tools/lanes_stage_proto.hip, profiles/r03_lanes_stage_proto.txt): the bare RK4 chain runs 1.48x (fp32) / 1.43x (fp64)
+// the env-steps per second of the one-lane layout for B <= 16 384 and 0.73x at B = 65 536 -- hence the dispatch by batch size.
+#pragma once
+#include "gl_model.hpp"
+
+#if defined(__HIPCC__)
+namespace glm {
+
+// ---- pairs: float -> one v_pk_* register pair, double -> two registers ------------------------------------------------------
+struct gq_d2 { double x, y; };
+__device__ __forceinline__ gq_d2 operator+(gq_d2 a, gq_d2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ gq_d2 operator-(gq_d2 a, gq_d2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ gq_d2 operator*(gq_d2 a, gq_d2 b) { return {a.x * b.x, a.y * b.y}; }
+typedef float gq_f2 __attribute__((ext_vector_type(2)));
+template <class T> struct GqPair;
+template <> struct GqPair<float> { typedef gq_f2 type; };
+template <> struct GqPair<double> { typedef gq_d2 type; };
+template <class T> using P2 = typename GqPair<T>::type;
+template <class T> __device__ __forceinline__ P2<T> gq_mk(T a, T b) { P2<T> r; r.x = a; r.y = b; return r; }
+template <class T> __device__ __forceinline__ P2<T> gq_sp(T a) { return gq_mk<T>(a, a); }
+
+// ---- DPP inside a quad --------------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ int gq_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float gq_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double gq_dpp(double v)
+{
+    // two 32-bit DPP moves on the halves, kept apart: hipcc 7.2 otherwise fuses them into a 64-bit DPP move, which gfx950
+    // implements for row_newbcast only -- quad_perm came back with garbage (profiles/r03_lanes_stage_proto.txt)
+    unsigned lo = (unsigned)__builtin_bit_cast(unsigned long long, v), hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    asm volatile("" : "+v"(lo));
+    asm volatile("" : "+v"(hi));
+    unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+    asm volatile("" : "+v"(rl));
+    unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+    asm volatile("" : "+v"(rh));
+    return __builtin_bit_cast(double, ((unsigned long long)rh << 32) | rl);
+}
+template <int S, class T> __device__ __forceinline__ T gq_bcast(T v) { return gq_dpp<S * 0x55>(v); }       // lane S of the quad
+template <class T> __device__ __forceinline__ T gq_sum(T v) { v += gq_dpp<0xB1>(v); v += gq_dpp<0x4E>(v); return v; }
+template <class T> __device__ __forceinline__ T gq_max(T v)
+{
+    v = Math<T>::max(v, gq_dpp<0xB1>(v)); v = Math<T>::max(v, gq_dpp<0x4E>(v)); return v;
+}
+__device__ __forceinline__ int gq_or(int v) { v |= gq_dpp<0xB1>(v); v |= gq_dpp<0x4E>(v); return v; }
+
+// ---- who owns what -------------------------------------------------------------------------------------------------------------
+// pair of lane `role` (component c); its four "other" states; the six shared ones.  In the integrator's coordinates slots 5, 7, 20
+// are the differences tTop - tCovIn, tAir - tThScr, tAir - tBlScr (gl_model.hpp rhs_fast<WETDIFF>).
+__host__ __device__ constexpr int gq_pair_ix(int role, int c) { return role == 0 ? (c ? 9 : 4) : role == 1 ? (c ? 17 : 8) : role == 2 ? (c ? 20 : 7) : (c ? 6 : 5); }
+__host__ __device__ constexpr int gq_other_ix(int role, int j)
+{
+    return role == 0 ? (j == 0 ? 21 : j == 1 ? 26 : j == 2 ? 10 : 11) : role == 1 ? (j == 0 ? 12 : j == 1 ? 13 : j == 2 ? 14 : 19)
+           : role == 2 ? (j == 0 ? 22 : j == 1 ? 23 : j == 2 ? 24 : 25) : (j == 0 ? 18 : 27);   // lane 3: slots 2, 3 unused
+}
+__host__ __device__ constexpr int gq_sh_ix(int i) { return i < 4 ? i : 11 + i; }                 // 0 1 2 3 15 16
+
+template <class T> struct QVec { P2<T> p; T sh[6]; T o[4]; };
+
+// ---- per-lane coefficients: functions of the lane's role, the env-step's StepCoef and the window's SlowCoef ---------------------
+template <class T> struct LaneK {
+    P2<T> cA, nA, cA2, nA2, sgA;   // exchange with node A: c |sg dA + eps|^n dA; the "2" set applies where dA < 0 (the floor's two regimes)
+    P2<T> cB;                      // second exchange (to the top compartment): the two screens
+    P2<T> src, iCap, wetC, mAir, mTop, trK;
+    P2<T> firX[4], firY[4];        // C[own x|y][lane s .x] and C[own x|y][lane s .y]
+    P2<T> cSky;
+    T cP;                          // conduction inside the pair (cover)
+    T ro[4];                       // rates of the lane's constant-rate states (tier 2b)
+};
+
+template <class T>
+__device__ __forceinline__ void gq_make_lane(int role, const StepCoef<T>& s, const ModelConst<T>& m, const SlowCoef<T>& q, LaneK<T>& K)
+{
+    const T z = T(0), one = T(1), third = T(1.0 / 3.0), L64 = T(6.4e-9);
+    auto pk = [&](T a0, T a1, T a2, T a3) { return role == 0 ? a0 : role == 1 ? a1 : role == 2 ? a2 : a3; };
+    // rows of the symmetric long-wave matrix over (Can, Pipe | Flr, Lamp | ThScr, BlScr | CovIn, CovE) (FirBlock::run), by source lane
+    //                      own x = Can            Flr             ThScr           CovIn         own y = Pipe         Lamp            BlScr           CovE
+    K.firX[0] = gq_mk<T>(pk(z, q.kCanFlr, q.kCanThScr, q.kCanCovIn), pk(q.kPipeCan, q.kLampCan, q.kCanBlScr, z));                 // source Can
+    K.firY[0] = gq_mk<T>(pk(q.kPipeCan, m.fPipeFlr, q.kPipeThScr, q.kPipeCovIn), pk(z, q.kLampPipe, q.kPipeBlScr, z));            // source Pipe
+    K.firX[1] = gq_mk<T>(pk(q.kCanFlr, z, q.kFlrThScr, q.kFlrCovIn), pk(m.fPipeFlr, q.kLampFlr, q.kFlrBlScr, z));                 // source Flr
+    K.firY[1] = gq_mk<T>(pk(q.kLampCan, q.kLampFlr, s.cLampThScr, s.cLampCovIn), pk(q.kLampPipe, z, s.cLampBlScr, z));            // source Lamp
+    K.firX[2] = gq_mk<T>(pk(q.kCanThScr, q.kFlrThScr, z, s.cThScrCovIn), pk(q.kPipeThScr, s.cLampThScr, s.cBlScrThScr, z));       // source ThScr
+    K.firY[2] = gq_mk<T>(pk(q.kCanBlScr, q.kFlrBlScr, s.cBlScrThScr, s.cBlScrCovIn), pk(q.kPipeBlScr, s.cLampBlScr, z, z));       // source BlScr
+    K.firX[3] = gq_mk<T>(pk(q.kCanCovIn, q.kFlrCovIn, s.cThScrCovIn, z), pk(q.kPipeCovIn, s.cLampCovIn, s.cBlScrCovIn, z));       // source CovIn
+    K.firY[3] = gq_mk<T>(z, z);                                                                                                   // source CovE: sky only
+    K.cSky = gq_mk<T>(pk(q.kCanSky, q.kFlrSky, s.cThScrSky, z), pk(q.kPipeSky, s.cLampSky, s.cBlScrSky, m.fCovESky));
+    K.cA = gq_mk<T>(pk(q.hCanAirK, T(1.3), s.hTh, m.cTopCov), pk(m.cPipeAir, m.cLampAir, s.hBl, s.covOutK));
+    K.cA2 = gq_mk<T>(pk(q.hCanAirK, T(1.7), s.hTh, m.cTopCov), K.cA.y);
+    K.nA = gq_mk<T>(pk(z, T(0.25), third, third), pk(T(0.32), z, third, z));
+    K.nA2 = gq_mk<T>(pk(z, third, third, third), K.nA.y);
+    K.sgA = gq_mk<T>(one, pk(-one, one, one, one));      // the product's orientation of |dT + 1e-10| (the floor: by the sign of dA)
+    K.cB = gq_mk<T>(pk(z, z, s.hTh, z), pk(z, z, s.hBl, z));
+    K.src = gq_mk<T>(pk(q.swCan + q.rGroPipeCan, q.swFlr - q.hFlrSo1, z, z), pk(s.hBoilPipe, s.lampNet, z, s.sunCovE));
+    K.iCap = gq_mk<T>(pk(q.iCapCan, m.iCapFlr, m.iCapThScr, m.iCapCov), pk(m.iCapPipe, m.iCapLamp, m.iCapBlScr, m.iCapCov));
+    K.wetC = gq_mk<T>(pk(z, z, L64, L64), pk(z, z, L64, z));
+    K.mAir = gq_mk<T>(pk(one, one, one, z), pk(one, one, one, z));
+    K.mTop = gq_mk<T>(pk(z, z, z, one), z);
+    K.trK = gq_mk<T>(pk(q.mvCanK, z, z, z), z);
+    K.cP = pk(z, z, z, m.cCovCond);
+    K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
+    K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
+}
+
+// what the rate bound / branch invariant need from a stage, per lane (gl_model.hpp rhs_fast<RATES>)
+template <class T> struct QRates { P2<T> hecA, hecB, sv, rr, g, Tsurf; T fScrAbs, fRoofAbs, tTopK; };
+
+// ---- one stage.  y: the lane's states in the integrator's coordinates; k: derivatives in the same coordinates ------------------
+template <class T, bool RATES>
+__device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK<T>& K, const StepCoef<T>& s, const ModelConst<T>& m,
+                                         const SlowCoef<T>& q, QVec<T>& k, QRates<T>* R)
+{
+    using M = Math<T>;
+    const T one = T(1), eps = T(1e-10), c2k = Kelvin<T>::c2k(), third = T(1.0 / 3.0);
+    const T co2Air = y.sh[0], co2Top = y.sh[1], tAir = y.sh[2], tTop = y.sh[3], vpAir = y.sh[4], vpTop = y.sh[5];
+    const bool cov = role == 3, scr = role == 2, lane0 = role == 0;
+    // physical temperatures of the pair: lanes 2 / 3 carry differences to their air node (rhs_fast<WETDIFF>)
+    const P2<T> Tp = gq_mk<T>(scr ? tAir - y.p.x : cov ? tTop - y.p.x : y.p.x, scr ? tAir - y.p.y : y.p.y);
+    // ---- long wave: gather the eight q's, 4 source lanes x 2 packed terms
+    const P2<T> kk = Tp + gq_sp<T>(c2k), k2 = kk * kk, qp = k2 * k2;
+    P2<T> fir = K.cSky * (gq_sp<T>(s.qSky) - qp);
+    {
+        const T q0x = gq_bcast<0>(qp.x), q0y = gq_bcast<0>(qp.y), q1x = gq_bcast<1>(qp.x), q1y = gq_bcast<1>(qp.y);
+        const T q2x = gq_bcast<2>(qp.x), q2y = gq_bcast<2>(qp.y), q3x = gq_bcast<3>(qp.x);
+        fir = fir + K.firX[0] * (gq_sp<T>(q0x) - qp) + K.firY[0] * (gq_sp<T>(q0y) - qp);
+        fir = fir + K.firX[1] * (gq_sp<T>(q1x) - qp) + K.firY[1] * (gq_sp<T>(q1y) - qp);
+        fir = fir + K.firX[2] * (gq_sp<T>(q2x) - qp) + K.firY[2] * (gq_sp<T>(q2y) - qp);
+        fir = fir + K.firX[3] * (gq_sp<T>(q3x) - qp);
+    }
+    // ---- exchange with node A (dA = T_A - T_i: exactly the carried difference on the wet lanes)
+    const P2<T> dA = gq_mk<T>(scr || cov ? y.p.x : tAir - Tp.x, scr ? y.p.y : (cov ? s.tOut : tAir) - Tp.y);
+    const bool negx = dA.x < T(0), negy = dA.y < T(0);
+    const P2<T> nA = gq_mk<T>(negx ? K.nA2.x : K.nA.x, negy ? K.nA2.y : K.nA.y), cA = gq_mk<T>(negx ? K.cA2.x : K.cA.x, negy ? K.cA2.y : K.cA.y);
+    const T sgx = role == 1 ? (negx ? -one : one) : K.sgA.x;
+    const P2<T> hecA = cA * gq_mk<T>(M::powa(M::abs(sgx * dA.x + eps), nA.x), M::powa(M::abs(K.sgA.y * dA.y + eps), nA.y));
+    const P2<T> fluxA = hecA * dA;                                   // into the surface
+    // ---- second exchange: screens -> top compartment
+    const P2<T> dB = Tp - gq_sp<T>(tTop);
+    const P2<T> hecB = K.cB * gq_mk<T>(M::powa(M::abs(dB.x + eps), third), M::powa(M::abs(dB.y + eps), third));
+    const P2<T> fluxB = hecB * dB;
+    // ---- saturation pressure, condensation gate, transpiration
+    const P2<T> rr = gq_mk<T>(M::rcp(Tp.x + T(238.3)), M::rcp(Tp.y + T(238.3)));
+    const P2<T> sv = gq_sp<T>(T(610.78)) * gq_mk<T>(M::expk(T(17.2694), Tp.x * rr.x), M::expk(T(17.2694), Tp.y * rr.y));
+    const P2<T> dv = gq_mk<T>(cov ? vpTop : vpAir, vpAir) - sv;
+    const P2<T> g = dv * gq_mk<T>(M::rcp(one + M::expk(T(-0.1), dv.x)), M::rcp(one + M::expk(T(-0.1), dv.y)));
+    const P2<T> mv = K.wetC * hecA * g;                              // vapour condensing on the surface
+    const T vpd = sv.x - vpAir;                                      // lane 0: x = canopy
+    const T co2Dev = m.etaMgPpm * co2Air - T(200);
+    const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
+    const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
+    const T mvCan = vpd * K.trK.x * M::rcp(m.rB + s.rSK * rfCo2 * rfVp);
+    // ---- the pair's balances
+    const T cond = K.cP * (Tp.x - Tp.y), L = m.latent;
+    const P2<T> net = K.src + fir + fluxA + gq_sp<T>(L) * mv - fluxB + gq_mk<T>(-cond - L * mvCan, cond);
+    const P2<T> dTp = K.iCap * net;
+    // ---- sums the air / top balances need
+    const P2<T> fa = fluxA * K.mAir, ft = fluxA * K.mTop, ma = mv * K.mAir, mt = mv * K.mTop;
+    const T sHeatAir = gq_sum(-(fa.x + fa.y));
+    const T sHeatTop = gq_sum((fluxB.x + fluxB.y) - (ft.x + ft.y));
+    const T sVapAir = gq_sum(mvCan - (ma.x + ma.y));
+    const T sVapTop = gq_sum(-(mt.x + mt.y));
+    const T tCan = gq_bcast<0>(Tp.x);
+    // ---- air side (identical in the four lanes): ventilation, screen air flux, air streams (rhs_fast)
+    const T dTOut = tAir - s.tOut;
+    const T buoy = m.gHVent * dTOut * M::rcp(tAir + s.tOutK2);
+    const T fVentRoof = s.ventK * M::sqrt(M::abs(buoy + s.windTerm)) + s.ventElse + s.leakTop;
+    const T tAirK = tAir + c2k, tTopK = tTop + c2k;
+    const T iAirK = M::rcp(tAirK), iTopK = M::rcp(tTopK);
+    const T rhoMean = T(0.5) * m.kRho * (iAirK + iTopK);
+    const T dRho = M::abs(m.kRho * (tTop - tAir) * iAirK * iTopK);
+    const T pw66 = M::powa(M::abs(tAir - tTop + eps), T(0.66));
+    const T iRhoMean = M::rcp(rhoMean);
+    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
+    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
+    const T fScrAbs = M::abs(M::min(fTh, fBl)), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
+    T vAirOverT, vTopOverT;
+    if (sizeof(T) == 8) { vAirOverT = vpAir * M::rcp(tAir + Kelvin<T>::c2kF32()); vTopOverT = vpTop * M::rcp(tTop + Kelvin<T>::c2kF32()); }
+    else { vAirOverT = vpAir * iAirK; vTopOverT = vpTop * iTopK; }
+    const T kMv = T(0.002165);
+    const T hAirTop = m.rhoCp * fScrAbs * (tAir - tTop), hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
+    const T mvAirTop = kMv * fScrAbs * (vAirOverT - vTopOverT), mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
+    const T mcAirTop = fScrAbs * (co2Air - co2Top), mcTopOut = fRoofAbs * (co2Top - s.co2Out);
+    const T mvAirOut = kMv * fSideAbs * (vAirOverT - s.vpOutOverT), mcAirOut = fSideAbs * (co2Air - s.co2Out);
+    const T hAirOut = s.hAirOutK * dTOut;
+    k.sh[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
+    k.sh[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
+    k.sh[2] = m.iCapAir * (sHeatAir + q.swAir - hAirOut - hAirTop + q.hGroPipeAir);
+    k.sh[3] = m.iCapTop * (sHeatTop + hAirTop - hTopOut);
+    k.sh[4] = m.kCapVpAir * tAirK * (sVapAir - mvAirTop - mvAirOut);
+    k.sh[5] = m.kCapVpTop * tTopK * (sVapTop + mvAirTop - mvTopOut);
+    // the pair in the integrator's coordinates: d(tAir - T)/dt on the screens, d(tTop - tCovIn)/dt on the cover
+    k.p = gq_mk<T>(scr ? k.sh[2] - dTp.x : cov ? k.sh[3] - dTp.x : dTp.x, scr ? k.sh[2] - dTp.y : dTp.y);
+    const T perDay = T(1.0 / 86400.0);
+    k.o[0] = lane0 ? perDay * (tCan - y.o[0]) : K.ro[0];             // lane 0: tCan24, tCanSum; lane 3: tIntLamp (off), time
+    k.o[1] = lane0 ? perDay * tCan : cov ? perDay : K.ro[1];
+    k.o[2] = K.ro[2]; k.o[3] = K.ro[3];
+    if (RATES) { R->hecA = hecA; R->hecB = hecB; R->sv = sv; R->rr = rr; R->g = g; R->Tsurf = Tp; R->fScrAbs = fScrAbs; R->fRoofAbs = fRoofAbs; R->tTopK = tTopK; }
+}
+
+// ---- rate bound + branch-invariant bits from the first stage of a window (gl_model.hpp rhs_fast<RATES>, term for term) ------------
+template <class T>
+__device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVec<T>& k, const QRates<T>& R, const LaneK<T>& K,
+                                           const StepCoef<T>& s, const ModelConst<T>& m, T h_nominal, int* side)
+{
+    using M = Math<T>;
+    const T f43 = T(4.0 / 3.0), kMv = T(0.002165), L = m.latent, LK = L * T(6.4e-9), kDs = T(1.1 * 17.2694 * 238.3);
+    const bool cov = role == 3, scr = role == 2;
+    // values the top-compartment rows need from the cover lane (3) and the screen lane (2)
+    const T hTopCovAbs = M::abs(gq_bcast<3>(R.hecA.x)), hecThTop = gq_bcast<2>(R.hecB.x), hecBlTop = gq_bcast<2>(R.hecB.y);
+    const T fAir = R.fScrAbs + R.fRoofAbs;
+    const T r1 = m.iCapCo2Top * fAir;
+    const T r3 = m.iCapTop * (m.rhoCp * (R.fRoofAbs + T(5.0 / 3.0) * R.fScrAbs) + f43 * (hTopCovAbs + hecThTop + hecBlTop));
+    const T r16 = m.kCapVpTop * (kMv * fAir + R.tTopK * T(6.4e-9 * 1.1) * hTopCovAbs);
+    const T rOther = M::max(M::max(r1, r3), M::max(r16, s.rateCovE));
+    // the lane's own wet surfaces: x (and y on the screen lane).  Lane 3: cover; lane 2: thermal, blackout screen
+    auto wet_smooth = [&](T hec, T sv, T r) { return LK * hec * (kDs * sv * r * r); };
+    int sbits = 0;
+    T rows = T(0);
+    auto surface = [&](bool on, int j, T iCap, T hcoef, T hecAbs, T g, T tSurf, T dT, T ddT, T base) {
+        // harm gate, side bits and (second pass) the pinned rate: gl_model.hpp harmful() / sc_pinned_rate()
+        const T tc = M::min(M::max(M::abs(tSurf), T(2)), T(40));
+        const T kap = iCap * M::abs(hcoef), G = LK * M::max(g, T(0));
+        const T kG = kap * G, rfree = ddT + iCap * hecAbs * (dT + LK * g), kG3 = kG * kG * kG;
+        sbits |= (on && dT > T(0)) ? (8 << j) : 0;
+        sbits |= (on && (dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
+        const bool harm = on && (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
+                          (kG3 > T(0.3) * rfree * rfree);
+        T row = iCap * (base + f43 * hecAbs);
+        if (GL_WAVE_ANY(harm)) row = sc_pinned_rate<T>(harm, iCap, hcoef, hecAbs, LK * g, dT, ddT, row, T(4) * h_nominal);
+        rows = M::max(rows, on ? row : T(0));
+    };
+    // x component: cover (lane 3) | thermal screen (lane 2)
+    {
+        const T hecAbs = M::abs(R.hecA.x);
+        const T base = cov ? T(2) * m.cCovCond + wet_smooth(hecAbs, R.sv.x, R.rr.x) + s.firCovIn
+                           : f43 * R.hecB.x + wet_smooth(hecAbs, R.sv.x, R.rr.x) + s.firTh;
+        surface(cov || scr, cov ? 0 : 1, cov ? m.iCapCov : m.iCapThScr, cov ? m.cTopCov : s.hTh, hecAbs, R.g.x, R.Tsurf.x, y.p.x, k.p.x, base);
+    }
+    // y component: blackout screen (lane 2)
+    {
+        const T hecAbs = M::abs(R.hecA.y);
+        const T base = f43 * R.hecB.y + wet_smooth(hecAbs, R.sv.y, R.rr.y) + s.firBl;
+        surface(scr, 2, m.iCapBlScr, s.hBl, hecAbs, R.g.y, R.Tsurf.y, y.p.y, k.p.y, base);
+    }
+    *side = gq_or(sbits);
+    return M::max(rOther, gq_max(rows));
+}
+
+// 1 / tolerance of the error estimate / movement limiter for the lane's pair (sc_fast / sc_itol of gl_model.hpp: the fast states are
+// co2Top tTop | z5 tCovE z7 | vpAir vpTop | tLamp | z20; the lamp is exempt from the movement limiter)
+template <class T> struct QTol { P2<T> est, mov; };
+template <class T> __device__ __forceinline__ QTol<T> gq_tol(int role)
+{
+    const T z = T(0), t8 = T(1.0 / 0.125), tl = T(1.0 / 0.5);
+    QTol<T> t;
+    t.est = gq_mk<T>(role >= 2 ? t8 : z, role >= 2 ? t8 : role == 1 ? tl : z);
+    t.mov = gq_mk<T>(role >= 2 ? t8 : z, role >= 2 ? t8 : z);
+    return t;
+}
+// shared fast states: co2Top (sh 1), tTop (sh 3), vpAir (sh 4), vpTop (sh 5)
+template <class T> __device__ __forceinline__ T gq_fast_max(const QVec<T>& a, P2<T> tolP)
+{
+    using M = Math<T>;
+    T w = M::max(M::max(M::abs(a.sh[1]) * T(1.0 / 12.5), M::abs(a.sh[3]) * T(1.0 / 0.125)),
+                 M::max(M::abs(a.sh[4]) * T(1.0 / 12.5), M::abs(a.sh[5]) * T(1.0 / 12.5)));
+    return M::max(w, M::max(M::abs(a.p.x) * tolP.x, M::abs(a.p.y) * tolP.y));
+}
+
+// ---- the sub-stepper: rk_delta<T, false, 4, WIN> of gl_model.hpp over the quad ---------------------------------------------------
+template <class T, int WIN>
+__device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
+                              int n_sub, QVec<T>& del, ScStat<T>& st)
+{
+    using M = Math<T>;
+    const int n_win = (n_sub + WIN - 1) / WIN;
+    const T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WIN);
+    const T S = T(SC_SAFETY * 2.785), est_fac = T(1.0 / 6.0), hmin = hnom * T(1.0 / SC_MAX_REFINE);
+    const QTol<T> tol = gq_tol<T>(role);
+    const bool lane0 = role == 0, crop = role == 2;
+    QVec<T> y, xs, k, acc, est, dprev, dwin;
+    auto zero = [](QVec<T>& v) { v.p = gq_sp<T>(T(0)); for (int i = 0; i < 6; ++i) v.sh[i] = T(0); for (int j = 0; j < 4; ++j) v.o[j] = T(0); };
+    zero(del); zero(dprev); zero(est); zero(dwin);
+    int n_steps = 0, flags = 0, side_prev = 0;
+    bool capped_prev = false;
+    T t_cap = T(0), h_last = hnom;
+    // harvest: cLeaf = x23, cFruit = x25 live on lane 2 (o[1], o[3])
+    auto harvest = [&](T hh) {
+        const T a = harvest_flow(z0.o[1] + del.o[1], cr.cLeafMax, hh), b = harvest_flow(z0.o[3] + del.o[3], cr.cFruitMax, hh);
+        del.o[1] += crop ? a : T(0); del.o[3] += crop ? b : T(0);
+    };
+    harvest(hw2);
+    const int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
+    auto state_now = [&]() { y.p = z0.p + del.p; for (int i = 0; i < 6; ++i) y.sh[i] = z0.sh[i] + del.sh[i]; for (int j = 0; j < 4; ++j) y.o[j] = z0.o[j] + del.o[j]; };
+    SlowCoef<T> q;
+    LaneK<T> K;
+    for (int it = 0; it <= n_win; ++it) {
+        flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
+        if (flags & SC_FLAG_CAP) break;
+        // ---- window start: tier 2b at the predicted window midpoint; every lane evaluates it from the gathered inputs
+        state_now();
+        {
+            QVec<T> mid;
+            mid.p = y.p + gq_sp<T>(T(0.5)) * dprev.p;
+            for (int i = 0; i < 6; ++i) mid.sh[i] = y.sh[i] + T(0.5) * dprev.sh[i];
+            for (int j = 0; j < 4; ++j) mid.o[j] = y.o[j] + T(0.5) * dprev.o[j];
+            dwin = del;
+            T ym[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ym[i] = T(0);
+            ym[0] = mid.sh[0]; ym[2] = mid.sh[2];
+            ym[4] = gq_bcast<0>(mid.p.x); ym[21] = gq_bcast<0>(mid.o[0]); ym[26] = gq_bcast<0>(mid.o[1]); ym[10] = gq_bcast<0>(mid.o[2]);
+            ym[11] = gq_bcast<0>(mid.o[3]);
+            ym[8] = gq_bcast<1>(mid.p.x); ym[12] = gq_bcast<1>(mid.o[0]); ym[13] = gq_bcast<1>(mid.o[1]); ym[14] = gq_bcast<1>(mid.o[2]);
+            ym[19] = gq_bcast<1>(mid.o[3]);
+            ym[22] = gq_bcast<2>(mid.o[0]); ym[23] = gq_bcast<2>(mid.o[1]); ym[24] = gq_bcast<2>(mid.o[2]); ym[25] = gq_bcast<2>(mid.o[3]);
+            slow_coef<T>(ym, s, m, cr, q);
+            gq_make_lane<T>(role, s, m, q, K);
+        }
+        // ---- first stage of the window's first sub-step with the rate bound; branch invariant; error estimate of the last sub-step
+        QRates<T> R;
+        gq_stage<T, true>(role, y, K, s, m, q, k, &R);
+        int side = 0;
+        const T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, hnom, &side);
+        flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
+        side_prev = side;
+        if (it > 0) {
+            QVec<T> dif;
+            dif.p = est.p - k.p;
+            for (int i = 0; i < 6; ++i) dif.sh[i] = est.sh[i] - k.sh[i];
+            const T worst = gq_max(gq_fast_max(dif, tol.est));
+            const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
+            flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;
+        }
+        if (it == n_win) break;
+        T hs = M::min(S * M::rcp(lam), hnom);
+        {
+            const T mv = gq_max(gq_fast_max(k, tol.mov));
+            hs = (mv * hs > T(SC_MOVE)) ? T(SC_MOVE) * M::rcp(mv) : hs;
+        }
+        const bool capped = !(hs >= hmin);
+        hs = capped ? hmin : hs;
+        t_cap += capped ? hw : T(0);
+        capped_prev = capped;
+        T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
+        const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+        h_last = h;
+        // one classical RK4 sub-step from (y, k = f(y)); full update of the pair, the shared states and lane 0's / lane 3's
+        // first two "others" (tCan24, tCanSum | tIntLamp, time), constant rate for the rest
+        auto sub_step = [&]() {
+            auto fill = [&](T c) {
+                xs.p = y.p + gq_sp<T>(c) * k.p;
+                for (int i = 0; i < 6; ++i) xs.sh[i] = y.sh[i] + c * k.sh[i];
+                xs.o[0] = y.o[0] + c * k.o[0]; xs.o[1] = y.o[1] + c * k.o[1]; xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
+            };
+            acc = k; fill(h2);
+            gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
+            acc.p = acc.p + gq_sp<T>(T(2)) * k.p;
+            for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
+            acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
+            fill(h2);
+            gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
+            acc.p = acc.p + gq_sp<T>(T(2)) * k.p;
+            for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
+            acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
+            fill(h);
+            gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
+            del.p = del.p + gq_sp<T>(h6) * (acc.p + k.p);
+            for (int i = 0; i < 6; ++i) del.sh[i] += h6 * (acc.sh[i] + k.sh[i]);
+            const bool full01 = lane0 || role == 3;
+            del.o[0] += full01 ? h6 * (acc.o[0] + k.o[0]) : h * k.o[0];
+            del.o[1] += full01 ? h6 * (acc.o[1] + k.o[1]) : h * k.o[1];
+            del.o[2] += h * k.o[2]; del.o[3] += h * k.o[3];
+            ++n_steps;
+        };
+        sub_step();
+        est = k;
+        for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
+            state_now();
+            gq_stage<T, false>(role, y, K, s, m, q, k, nullptr);
+            sub_step();
+            est = k;
+        }
+        // ---- window end
+        dprev.p = del.p - dwin.p;
+        for (int i = 0; i < 6; ++i) dprev.sh[i] = del.sh[i] - dwin.sh[i];
+        for (int j = 0; j < 4; ++j) dprev.o[j] = del.o[j] - dwin.o[j];
+        harvest((it == n_win - 1) ? hw2 : hw);
+    }
+    if (role == 3) del.o[1] = dt * T(1.0 / 86400.0);          // x27 = time [days]
+    st.n_steps = n_steps;
+    st.flags = flags;
+}
+
+// physical increments of the lane's fast states (for the agreement test of the guard) and finiteness
+template <class T> __device__ __forceinline__ void gq_phys_pair(int role, const QVec<T>& del, P2<T>& out)
+{
+    out = gq_mk<T>(role == 2 ? del.sh[2] - del.p.x : role == 3 ? del.sh[3] - del.p.x : del.p.x, role == 2 ? del.sh[2] - del.p.y : del.p.y);
+}
+
+// ---- the guard: rk4_delta_guarded of gl_model.hpp over the quad (same ladder, same acceptance rules) ---------------------------------
+template <class T, int WIN>
+__device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
+                                      T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps, bool verify, int* first_flags)
+{
+    using M = Math<T>;
+    const QTol<T> tol = gq_tol<T>(role);
+    int n = n_sub, extra = 0, total = 0;
+    bool done = false, ok = false, have_prev = false;
+    QVec<T> prev;
+    prev.p = gq_sp<T>(T(0));
+    for (int i = 0; i < 6; ++i) prev.sh[i] = T(0);
+    for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
+        if (done) break;                                   // uniform inside the quad: every decision below is
+        ScStat<T> st;
+        rk_delta_quad<T, WIN>(role, z0, s, m, cr, dt, n, del, st);
+        total += st.n_steps;
+        const int n_nom = ((n + WIN - 1) / WIN) * WIN;
+        if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);
+        T chk = (del.p.x + del.p.y) * T(0);
+        for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
+        for (int j = 0; j < 4; ++j) chk += del.o[j] * T(0);
+        const bool finite = gq_or((chk == T(0)) ? 0 : 1) == 0;
+        const bool complete = finite && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE));
+        const bool clean = complete && st.flags == 0 && st.n_steps < SC_HEAVY * n_nom;
+        QVec<T> now;
+        gq_phys_pair<T>(role, del, now.p);
+        for (int i = 0; i < 6; ++i) now.sh[i] = del.sh[i];
+        QVec<T> dif;
+        dif.p = now.p - prev.p;
+        for (int i = 0; i < 6; ++i) dif.sh[i] = now.sh[i] - prev.sh[i];
+        const T worst = gq_max(gq_fast_max(dif, tol.est));
+        ok = (clean && !verify) || (complete && have_prev && worst <= T(SC_AGREE));
+        done = ok || attempt == SC_ATTEMPTS - 1;
+        have_prev = complete;
+        prev = now;
+        extra += done ? 0 : 1;
+        n *= 2;
+    }
+    *failed = !ok;
+    if (extra_steps) { const int ex = total - ((n_sub + WIN - 1) / WIN) * WIN; *extra_steps = ex > 0 ? ex : 0; }
+    return extra;
+}
+
+}  // namespace glm
+#endif

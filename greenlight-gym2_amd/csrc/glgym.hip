@@ -20,6 +20,7 @@
 
 #include "glgym.h"
 #include "gl_model.hpp"
+#include "gl_model_quad.hpp"
 
 using namespace glm;
 
@@ -290,6 +291,132 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         for (int i = 0; i < GLGYM_NMETRIC; ++i) {
             const float sum = wave_sum(mv[i]);
             if (lane == 0) atomicAdd(mrep + i, sum);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// fused env-step, FOUR LANES PER ENVIRONMENT (gl_model_quad.hpp): 16 environments per wavefront; for batches that leave SIMDs
+// idle (B <= 16 384: profiles/r03_lanes_stage_proto.txt).  Same prologue / epilogue as step_kernel; lane 0 of a quad writes the
+// per-env outputs, every lane the states it owns.  Classical RK4, default ODE, shared crop parameters, interlights off.
+// ---------------------------------------------------------------------------------------------------
+template <class T, bool DEFAULT_P>
+__global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
+{
+    const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
+    const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3;
+    const int b = gl >> 2;
+    const bool live = b < a.B;
+    const int bb = live ? b : a.B - 1;        // out-of-range quads shadow the last env, stores are masked
+    T u[NU];
+    if (a.action) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const float inc = a.action[(size_t)bb * NU + j] * a.du;               // f32 product, as tomato_env.py:113
+            const T v = a.u[(size_t)j * a.ld + bb] + T(inc);
+            u[j] = Math<T>::min(Math<T>::max(v, T(a.u_min[j])), T(a.u_max[j]));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) u[j] = a.control[(size_t)j * a.ld + bb];
+    }
+    const int ts = a.timestep[bb];
+    int row = a.w_off[bb] + ts;
+    row = row < 0 ? 0 : (row >= a.weather_rows ? a.weather_rows - 1 : row);
+    T d[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) d[j] = a.weather[(size_t)row * a.nd + j];
+    const CropConst<T>& cr = m.crop;
+    StepCoef<T> s;
+    precompute(u, d, m, cr, s);
+    // the lane's states, in the integrator's coordinates (screens / inner cover face as differences to their air node)
+    auto X = [&](int i) { return a.x[(size_t)i * a.ld + bb]; };
+    QVec<T> x0, z0, del;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x0.sh[i] = X(role == 0 ? gq_sh_ix(i) : role == 1 ? gq_sh_ix(i) : role == 2 ? gq_sh_ix(i) : gq_sh_ix(i));
+    x0.p = gq_mk<T>(X(role == 0 ? 4 : role == 1 ? 8 : role == 2 ? 7 : 5), X(role == 0 ? 9 : role == 1 ? 17 : role == 2 ? 20 : 6));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ix = role == 0 ? gq_other_ix(0, j) : role == 1 ? gq_other_ix(1, j) : role == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1);
+        x0.o[j] = X(ix);
+    }
+    z0 = x0;
+    z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x, role == 2 ? x0.sh[2] - x0.p.y : x0.p.y);
+    if (live && role == 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
+    }
+    bool bad;
+    int extra_steps, first_flags = 0;
+    const int retries = rk4_delta_guarded_quad<T, RK4_WINDOW<T>::value>(role, z0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps,
+                                                                       a.verify != 0, &first_flags);
+    // ---- new state: physical increments of what the lane owns
+    P2<T> dP;
+    gq_phys_pair<T>(role, del, dP);
+    QVec<T> x1;
+    x1.p = gq_mk<T>(bad ? x0.p.x : x0.p.x + dP.x, bad ? x0.p.y : x0.p.y + dP.y);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x1.sh[i] = bad ? x0.sh[i] : x0.sh[i] + del.sh[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x1.o[j] = bad ? x0.o[j] : x0.o[j] + del.o[j];
+    if (role == 3) {    // x27 = time [days since reset]: exact from the step counter (step_kernel)
+        const double per_step = (double)a.dt / 86400.0;
+        double t_start = (double)x0.o[1] - (double)ts * per_step;
+        if (fabs(t_start) < 5e-4) t_start = 0.0;
+        if (!bad) x1.o[1] = T(t_start + ((double)ts + 1.0) * per_step);
+    }
+    const T dFruit = gq_bcast<2>(del.o[3]);                 // cFruit lives on lane 2
+    // ---- reward epilogue (step_kernel): every lane has what it needs, lane 0 writes
+    const T co2ppm = rw.kPpm * (x1.sh[2] + T(273.15)) * x1.sh[0];
+    const T rh = Math<T>::min(Math<T>::max(T(100) * x1.sh[4] / sat_vp_exact(x1.sh[2]), T(0)), T(100));
+    const T o3[3] = {co2ppm, x1.sh[2], rh};
+    T viol[3], pen = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        viol[i] = Math<T>::max(rw.lo[i] - o3[i], T(0)) + Math<T>::max(o3[i] - rw.hi[i], T(0));
+        pen += viol[i] * rw.invMaxViol[i];
+    }
+    const T heat = u[0] * rw.heatK, elec = u[4] * rw.elecK, co2c = u[1] * rw.co2K;
+    const T varc = heat + co2c + elec;
+    const T gains = (bad ? T(0) : dFruit) * rw.gainK;
+    const T profit = gains - varc;
+    const T reward = (profit - rw.minProfit) * rw.invRange - pen;
+    const bool term = bad || (ts >= a.N);
+    if (live) {
+        auto W = [&](int i, T v) { a.x[(size_t)i * a.ld + b] = v; };
+        W(role == 0 ? 4 : role == 1 ? 8 : role == 2 ? 7 : 5, x1.p.x);
+        W(role == 0 ? 9 : role == 1 ? 17 : role == 2 ? 20 : 6, x1.p.y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (role != 3 || j < 2) W(role == 0 ? gq_other_ix(0, j) : role == 1 ? gq_other_ix(1, j) : role == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1), x1.o[j]);
+        if (role == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) W(gq_sh_ix(i), x1.sh[i]);
+            a.timestep[b] = ts + 1;
+            a.reward[b] = reward;
+            a.done[b] = term ? 1 : 0;
+            if (a.info) {
+                const T inf[GLGYM_NINFO] = {profit, gains, varc, rw.fixedCosts, co2c, heat, elec, viol[1], viol[0], viol[2], T(0)};
+#pragma unroll
+                for (int i = 0; i < GLGYM_NINFO; ++i) a.info[(size_t)i * a.ld + b] = inf[i];
+            }
+        }
+    }
+    if (a.metrics) {
+        const bool cnt = live && role == 0;
+        const float w = cnt ? 1.f : 0.f;
+        float mv[GLGYM_NMETRIC] = {w * (float)reward, w * (float)profit, (cnt && term) ? 1.f : 0.f,
+                                   (cnt && bad) ? 1.f : 0.f, w * (float)viol[0], w * (float)viol[1],
+                                   w * (float)viol[2], w, w * (float)retries, w * (float)extra_steps,
+                                   (cnt && (first_flags & SC_FLAG_ERR)) ? 1.f : 0.f, (cnt && (first_flags & SC_FLAG_BRANCH)) ? 1.f : 0.f,
+                                   (cnt && (first_flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE))) ? 1.f : 0.f,
+                                   (cnt && (first_flags & 16)) ? 1.f : 0.f};
+        float* mrep = a.metrics + (size_t)(blockIdx.x % GLGYM_METRIC_REPLICAS) * GLGYM_METRIC_STRIDE;
+#pragma unroll
+        for (int i = 0; i < GLGYM_NMETRIC; ++i) {
+            const float sum = wave_sum(mv[i]);
+            if (threadIdx.x == 0) atomicAdd(mrep + i, sum);
         }
     }
 }
@@ -1236,6 +1363,24 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
         GL_LAUNCH_T((step_kernel<T, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
+    }
+    // Layout by batch size: four lanes per environment while the batch leaves SIMDs idle (GLGYM_LAYOUT = one | quad overrides).
+    // The quad kernels integrate classical RK4 of the default ODE with shared crop parameters and the interlights off, in fp32:
+    // in fp64 the quad's ten 12-entry state vectors + the coefficient blocks need 512 registers + 336 B of scratch, and hipcc 7.2's
+    // spill code is not to be trusted on this kernel either (right with a printf in the loop, failed integrations without:
+    // DESIGN.md section 5) -- the fp64 quad layout waits for the coefficient blocks to move to LDS.
+    if constexpr (sizeof(T) == 4) {
+        const char* le_ = std::getenv("GLGYM_LAYOUT");          // read per launch: tests and tools switch it between steps
+        const int layout_env = !le_ ? 0 : (le_[0] == 'q' ? 2 : 1);
+        const bool quad_ok = h->scheme == GLGYM_SCHEME_RK4 && !a->crop_p && !m.intLampActive;
+        if (quad_ok && (layout_env == 2 || (layout_env == 0 && a->B <= 4 * h->n_simd * 4))) {
+            const dim3 qgrid((4 * a->B + WAVE - 1) / WAVE);
+            const bool qdef = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+            if (qdef) hipLaunchKernelGGL((step_kernel_quad<T, true>), qgrid, block, 0, st, k, m, rw);
+            else hipLaunchKernelGGL((step_kernel_quad<T, false>), qgrid, block, 0, st, k, m, rw);
+            HIPCHK(hipGetLastError());
+            return GLGYM_OK;
+        }
     }
     // fp64 (parity configuration) always takes the generic kernel: its RHS is an out-of-line call that receives the
     // constant block by address, and only the kernarg copy has a usable one.

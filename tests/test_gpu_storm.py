@@ -131,3 +131,52 @@ def test_ode_pipe_tracking_at_dt_900_is_refined_not_unstable(golden, oracle):
         assert e < 1e-4, (i, e)
         assert abs(got[9] - D14[i, 10]) < 1e-6                      # after 900 s the pipe sits on the measured temperature
     m.close()
+
+
+def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
+    """The north-star layout (gl_model_quad.hpp: a quad of lanes per environment, DPP inside the quad; taken for fp32 batches up to
+    16 384) against the one-lane-per-environment kernel on the same inputs: storm and raw-jump tuples (refined lanes, ladder
+    attempts, verified mode), a batch that is not a multiple of 16, through glgym_step with raw controls and with actions.  Same
+    scheme decision for decision, so the states agree to fp32 rounding through the kinks and the integrator events are identical."""
+    import os
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g, j = golden("step_tight_storm"), golden("step_tight_jump")
+    X = np.concatenate([g["X"][:90], j["X"][:110]]); U = np.concatenate([g["U"][:90], j["U"][:110]])
+    D = np.concatenate([g["D"][:90], j["D"][:110]]); XT = np.concatenate([g["X_tight"][:90], j["X_tight"][:110]])
+    B = len(X)                                                   # 200 = 12 full quads-of-16 + 8
+    w = np.repeat(D, 4, axis=0)
+    out = {}
+    old = os.environ.get("GLGYM_LAYOUT")
+    try:
+        for layout in ("one", "quad"):
+            os.environ["GLGYM_LAYOUT"] = layout
+            env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=320, season_length=0.02, pred_horizon=0, auto_reset=False)
+            env.reset()
+            env.w_off_t.copy_(torch.arange(B, dtype=torch.int32, device=env.device) * 4)
+            env.x.copy_(torch.as_tensor(X, dtype=env.tdtype, device=env.device))
+            env.metrics_t.zero_()
+            obs, r, done, infos = env.step_raw_control(U)                                   # verified integration
+            x_raw, m_raw = env.x.double().cpu().numpy().copy(), env.metrics()
+            env.x.copy_(torch.as_tensor(X, dtype=env.tdtype, device=env.device))
+            env.u.copy_(torch.as_tensor(U, dtype=env.tdtype, device=env.device))
+            env.timestep_t.zero_(); env.metrics_t.zero_()
+            obs2, r2, done2, _ = env.step(np.zeros((B, 6), np.float32))                      # action path: guarded, unverified
+            out[layout] = (x_raw, m_raw, r.copy(), env.x.double().cpu().numpy().copy(), env.metrics(), r2.copy(), done.copy())
+            env.close()
+    finally:
+        if old is None:
+            os.environ.pop("GLGYM_LAYOUT", None)
+        else:
+            os.environ["GLGYM_LAYOUT"] = old
+    a, b = out["one"], out["quad"]
+    e_raw, e_act = scaled_err(b[0], a[0]), scaled_err(b[3], a[3])
+    print(f"quad vs one lane per env (fp32, {B} storm / jump tuples): raw-control step {e_raw:.1e}, action step {e_act:.1e}; "
+          f"vs truth: one {scaled_err(a[0], XT):.1e}, quad {scaled_err(b[0], XT):.1e}; extra attempts {a[1]['n_guard_retries']:.0f} / "
+          f"{b[1]['n_guard_retries']:.0f}, refined {a[1]['n_refined_substeps']:.0f} / {b[1]['n_refined_substeps']:.0f}")
+    assert e_raw < 2e-5 and e_act < 2e-5
+    assert np.max(np.abs(a[2] - b[2])) < 1e-5 and np.max(np.abs(a[5] - b[5])) < 1e-5 and np.array_equal(a[6], b[6])
+    for k in ("n_ode_fail", "n_done", "n_env_steps"):
+        assert a[1][k] == b[1][k] and a[4][k] == b[4][k], k
+    assert abs(a[1]["n_refined_substeps"] - b[1]["n_refined_substeps"]) <= 0.02 * a[1]["n_refined_substeps"] + 64
+    assert scaled_err(b[0], XT) < 2e-4
