@@ -1574,6 +1574,11 @@ template <> struct RkVec<float> {
 #ifndef SC_MAX_REFINE
 #define SC_MAX_REFINE 64
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GL_COEF_FENCE(on) do { if (on) asm volatile("" : : "v"(&s) : "memory"); } while (0)     /* the address escapes: no forwarding */
+#else
+#define GL_COEF_FENCE(on) do { } while (0)
+#endif
 // After a control jump the fast states legitimately move by kelvins within seconds (the estimate decays 5x per window,
 // e.g. 0.16 K -> 0.034 -> 0.006 after a 0 -> 1 actuator jump at n_sub = 320): the estimate tolerance is SC_GRACE_MUL x
 // looser during the first SC_GRACE_S seconds of an env-step.  An instability keeps growing and is caught after that.
@@ -1594,7 +1599,10 @@ template <class T> struct ScStat {
     int flags;        // SC_FLAG_*
 };
 
-template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
+// LDSCOEF = true: the per-env-step coefficient block `s` lives in LDS (the two-waves-per-SIMD build of step_kernel: 69 registers
+// less per lane).  A compiler-level memory fence in front of every stage makes hipcc RE-READ the coefficients there (merged into
+// ds_read_b64 / b128 where adjacent) instead of hoisting 69 loads out of the loops and spilling them to scratch again.
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool LDSCOEF = false>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                     int n_sub, T* del, ScStat<T>& st)
 {
@@ -1653,7 +1661,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
         T lam = hnom;                                             // in: nominal sub-step; out: the rate bound
         int side = 0;
-        rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam, &side);
+        GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam, &side);
         // branch invariant (rhs_fast<RATES>): a wet surface that was below its air node at the last look and now sits above
         // it inside the bistable regime with positive drive has jumped branches -- acted on only where the sub-step could not
         // follow the rate bound (the window just taken was capped at SC_MAX_REFINE): a crossing inside a RESOLVED window is
@@ -1698,17 +1706,17 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
                         r.st(acc, r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
                         r.st(acc, r.ld(acc) + r.sp(T(2)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
                         r.st(acc, r.ld(acc) + r.sp(T(2)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 = k4 for the constant-rate states
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
@@ -1724,14 +1732,14 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
                         r.st(acc, r.sp(T(2.0 / 9.0)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] += T(2.0 / 3.0) * k[sc_fast(j)];
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
                         r.st(acc, r.ld(acc) + r.sp(T(1.0 / 3.0)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h34) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 for the constant-rate states
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
@@ -1743,7 +1751,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
@@ -1767,7 +1775,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) keep[j] = est[j];
                 state_now();
-                rhs_stage<T, PIPE>(y, q, s, m, cr, k);
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(y, q, s, m, cr, k);
                 sub_step();
                 n_steps -= (act || (flags & SC_FLAG_CAP)) ? 0 : 1;
 #pragma unroll
@@ -1777,7 +1785,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         } else {
             for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
                 state_now();
-                rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(y, q, s, m, cr, k);                // same tier 2b
                 sub_step();
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
@@ -1826,7 +1834,7 @@ template <class T> GL_HD bool all_finite(const T* v)
     return chk == T(0);
 }
 
-template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool LDSCOEF = false>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                             int n_sub, T* del, bool* failed, int* extra_steps = nullptr, bool verify = false,
                             int* first_flags = nullptr)
@@ -1845,7 +1853,7 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
         ScStat<T> st;
         T tmp[NX];
         T* dst = UNIFORM ? tmp : del;
-        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, dst, st);
+        rk_delta<T, PIPE, ORDER, WIN, LDSCOEF>(x0, s, m, cr, dt, n, dst, st);
         if (!done) {
             if (UNIFORM) {
 #pragma unroll

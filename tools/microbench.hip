@@ -20,12 +20,17 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
 {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     __shared__ float lds[256];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ f4 lds4[KIND == 18 || KIND == 19 ? 8 * 64 : 1];    // KIND 18 / 19: per-lane coefficient tiles, float4 SoA (8 KB per wave)
     float a0 = in[threadIdx.x], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float c = in[64], d = in[65];
     float vc = c + 0.f * threadIdx.x, vd = d + 0.f * threadIdx.x;     // the same two constants in VGPRs (KIND 14..17)
     asm volatile("" : "+v"(vc), "+v"(vd));
     lds[threadIdx.x] = a0; lds[threadIdx.x + 64] = a1; lds[threadIdx.x + 128] = a2; lds[threadIdx.x + 192] = a3;
+    if (KIND == 18 || KIND == 19)
+        for (int b = 0; b < 8; ++b) { f4 v = {c, c + 1e-7f * b, c, c - 1e-7f * b}; lds4[b * 64 + threadIdx.x] = v; }
     __syncthreads();
+    f4 cur0 = {c, c, c, c}, cur1 = cur0;                              // KIND 18: the coefficients in use, read one block ahead
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pc = {c, c}, pd = {d, d};
     // KIND 10 / 11: the v_fma_f32 body with only the lower 32 / 16 lanes of the wave active (does a half-empty EXEC mask
@@ -61,6 +66,15 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
             const int t = threadIdx.x;
             a0 = fmaf(a0, l[t], d); a1 = fmaf(a1, l[t + 64], d); a2 = fmaf(a2, l[t + 128], d); a3 = fmaf(a3, l[t + 192], d);
             a4 = fmaf(a4, l[t], d); a5 = fmaf(a5, l[t + 64], d); a6 = fmaf(a6, l[t + 128], d); a7 = fmaf(a7, l[t + 192], d);
+        } else if (KIND == 18) {  // 8 x v_fma with PER-LANE coefficients from LDS: two ds_read_b128 per eight, issued one block ahead
+            const f4 nx0 = lds4[((2 * rep) & 7) * 64 + threadIdx.x], nx1 = lds4[((2 * rep + 1) & 7) * 64 + threadIdx.x];
+            a0 = fmaf(a0, cur0.x, d); a1 = fmaf(a1, cur0.y, d); a2 = fmaf(a2, cur0.z, d); a3 = fmaf(a3, cur0.w, d);
+            a4 = fmaf(a4, cur1.x, d); a5 = fmaf(a5, cur1.y, d); a6 = fmaf(a6, cur1.z, d); a7 = fmaf(a7, cur1.w, d);
+            cur0 = nx0; cur1 = nx1;
+        } else if (KIND == 19) {  // the same without the look-ahead: each block of eight waits for its own two ds_read_b128
+            const f4 nx0 = lds4[((2 * rep) & 7) * 64 + threadIdx.x], nx1 = lds4[((2 * rep + 1) & 7) * 64 + threadIdx.x];
+            a0 = fmaf(a0, nx0.x, d); a1 = fmaf(a1, nx0.y, d); a2 = fmaf(a2, nx0.z, d); a3 = fmaf(a3, nx0.w, d);
+            a4 = fmaf(a4, nx1.x, d); a5 = fmaf(a5, nx1.y, d); a6 = fmaf(a6, nx1.z, d); a7 = fmaf(a7, nx1.w, d);
         } else if (KIND == 7) {   // dependent fma chain (latency)
             a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d);
             a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d); a0 = fmaf(a0, c, d);
@@ -100,7 +114,7 @@ template <int KIND> __global__ __launch_bounds__(64) void k(float* out, const fl
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
       }
     }
-    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + cur0.x + cur1.w + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (g_rec && threadIdx.x == 0) {
         WaveRec r;
         r.hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
@@ -223,6 +237,8 @@ int main()
     run<4>("(v_readlane + v_fma) x8", out, in, 16);
     run<5>("(ds_read bcast + v_fma) x8", out, in, 16);
     run<6>("(ds_read per-lane + v_fma) x8", out, in, 16);
+    run<18>("8 v_fma + 2 ds_read_b128 ahead (per 8 fma)", out, in, 8);
+    run<19>("8 v_fma + 2 ds_read_b128 in place", out, in, 8);
     run<7>("dependent v_fma chain x8", out, in, 8);
     run<12>("(ds_bpermute lane^1 + v_fma) x8", out, in, 16);
     run<13>("(DPP quad_perm lane^1 + v_fma) x8", out, in, 16);
