@@ -20,16 +20,19 @@ for k in sorted(out):
 if len(sys.argv) > 1 and sys.argv[1] == "--constants":
     import json
     dst, label, files = sys.argv[2], sys.argv[3], sys.argv[4:]
+    import os
+    pattern = os.environ.get("PMC_KERNEL", "step_kernel<float, false, true, false, 0")      # which instantiation (tools/profile_r03.sh)
     vals = collections.defaultdict(list)
     dur = []
     for f in files:
         for r in csv.DictReader(open(f)):
-            if "step_kernel<float, false, true, false, 0" not in r.get("Kernel_Name", ""):
+            if pattern not in r.get("Kernel_Name", ""):
                 continue
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     c = {k: sum(v) / len(v) for k, v in vals.items()}
     out = {k: c[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32",
-                             "SQ_INSTS_VALU_ADD_F32", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES",
+                             "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+                             "SQ_INSTS_VALU_ADD_F64", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES",
                              "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE") if k in c}
     # gfx950: FETCH_SIZE reports half of the fetched bytes (MI355X_MICROARCH.md, HBM section); both counters are in KiB
     out["traffic_bytes"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024

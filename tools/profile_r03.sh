@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round 3: PMC constants for EVERY shipped variant of step_kernel (so that no bench line carries roofline.frac = null), the
+# kernel-trace summary + bench line of the default workload, at B = 65 536.  Separate --pmc passes, --kernel-trace only (the guide's
+# recipe).  Writes gpurun_out/r03_prof/<variant>/..., profiles-ready files gpurun_out/r03_prof/r03_*.  TAG=r03 bash tools/profile_r03.sh
+export TMPDIR=/tmp
+OUT=gpurun_out/r03_prof
+mkdir -p $OUT
+variant() {   # name, kernel-name pattern, n_sub, counter suffix, bench args...
+  name=$1; pat=$2; nsub=$3; sfx=$4; shift 4
+  V=$OUT/$name; mkdir -p $V
+  i=0
+  for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" \
+             "SQ_INSTS_VALU_ADD_$sfx SQ_INSTS_VALU_MUL_$sfx SQ_INSTS_VALU_FMA_$sfx SQ_INSTS_VALU_TRANS_$sfx" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $V/pmc$i -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-scheme "$@" > $V/pmc$i.log 2>&1 || echo "$name pass $i failed"
+  done
+  python tools/pmc_summary.py $V/pmc*/*/*counter_collection.csv > $OUT/r03_${name}_pmc_summary.csv
+  PMC_KERNEL="$pat" python tools/pmc_summary.py --constants $V/constants.json profiles/r03_${name}_pmc_summary.csv $V/pmc*/*/*counter_collection.csv
+  python - <<PY
+import csv, glob, json
+d = json.load(open("$V/constants.json"))
+durs = []
+for f in glob.glob("$V/pmc6/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "$pat" in r["Kernel_Name"]:
+            durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+if durs and "GRBM_GUI_ACTIVE" in d:
+    d["kernel_ns_under_pmc"] = sum(durs) / len(durs)
+    d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["kernel_ns_under_pmc"]      # the counter is summed over the 8 XCDs
+d["n_sub"] = $nsub
+d["kernel"] = "$pat"
+json.dump(d, open("$V/constants.json", "w"), indent=1)
+print("$name", {k: d.get(k) for k in ("SQ_INSTS_VALU", "valu_busy", "clock_ghz", "kernel_ns_under_pmc", "traffic_bytes")})
+PY
+  rm -rf $V/pmc?
+}
+# default workload: kernel-trace --stats summary + bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 > $OUT/bench_stats.log 2>&1
+grep "^{" $OUT/bench_stats.log > $OUT/r03_rk4_bench_line.json
+f=$(ls $OUT/stats/*/*kernel_stats.csv | head -1); python tools/condense_stats.py $f $OUT/r03_rk4_bench_kernel_stats.csv; rm -rf $OUT/stats
+variant f32_rk4 "step_kernel<float, false, true, false, 0, 1>" 320 F32
+variant f32_rk3 "step_kernel<float, false, true, false, 2, 1>" 354 F32 --scheme rk3
+variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 376 F32 --scheme rk2
+variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 320 F32 --uncertainty 0.2
+variant f64_rk4 "step_kernel<double, false, false, false, 0, 1>" 320 F64 --dtype f64
+python - <<PY
+import json
+out = {}
+for v in ("f32_rk4", "f32_rk3", "f32_rk2", "f32_rk4_config5", "f64_rk4"):
+    try:
+        out[v] = json.load(open("$OUT/%s/constants.json" % v))
+    except OSError:
+        pass
+json.dump(out, open("$OUT/r03_pmc_constants.json", "w"), indent=1)
+print(sorted(out))
+PY
+cat $OUT/r03_rk4_bench_kernel_stats.csv | head -6
