@@ -292,9 +292,14 @@ template <class T> __device__ __forceinline__ T gq_fast_max(const QVec<T>& a, P2
 }
 
 // ---- the sub-stepper: rk_delta<T, false, 4, WIN> of gl_model.hpp over the quad ---------------------------------------------------
-template <class T, int WIN>
-__device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                              int n_sub, QVec<T>& del, ScStat<T>& st)
+// LDSQ = true (the fp64 build): the env-step's coefficient block `s` (one copy per quad) and the lane's `LaneK` record live in LDS;
+// a compiler fence in front of every stage, whose operands are their addresses, makes hipcc re-read them there instead of
+// hoisting ~115 doubles into registers -- in fp64 that is the difference between 512 registers + scratch (whose spill code hipcc
+// 7.2 gets wrong on this kernel too) and a kernel that fits.
+#define GQ_FENCE() do { if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K) : "memory"); } while (0)
+template <class T, int WIN, bool LDSQ>
+__device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
+                                              const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st)
 {
     using M = Math<T>;
     const int n_win = (n_sub + WIN - 1) / WIN;
@@ -317,7 +322,6 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     const int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     auto state_now = [&]() { y.p = z0.p + del.p; for (int i = 0; i < 6; ++i) y.sh[i] = z0.sh[i] + del.sh[i]; for (int j = 0; j < 4; ++j) y.o[j] = z0.o[j] + del.o[j]; };
     SlowCoef<T> q;
-    LaneK<T> K;
     for (int it = 0; it <= n_win; ++it) {
         flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
         if (flags & SC_FLAG_CAP) break;
@@ -343,7 +347,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         }
         // ---- first stage of the window's first sub-step with the rate bound; branch invariant; error estimate of the last sub-step
         QRates<T> R;
-        gq_stage<T, true>(role, y, K, s, m, q, k, &R);
+        GQ_FENCE(); gq_stage<T, true>(role, y, K, s, m, q, k, &R);
         int side = 0;
         const T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, hnom, &side);
         flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
@@ -378,17 +382,17 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                 xs.o[0] = y.o[0] + c * k.o[0]; xs.o[1] = y.o[1] + c * k.o[1]; xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
             };
             acc = k; fill(h2);
-            gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
+            GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
             acc.p = acc.p + gq_sp<T>(T(2)) * k.p;
             for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
             acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
             fill(h2);
-            gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
+            GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
             acc.p = acc.p + gq_sp<T>(T(2)) * k.p;
             for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
             acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
             fill(h);
-            gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
+            GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
             del.p = del.p + gq_sp<T>(h6) * (acc.p + k.p);
             for (int i = 0; i < 6; ++i) del.sh[i] += h6 * (acc.sh[i] + k.sh[i]);
             const bool full01 = lane0 || role == 3;
@@ -401,7 +405,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         est = k;
         for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
             state_now();
-            gq_stage<T, false>(role, y, K, s, m, q, k, nullptr);
+            GQ_FENCE(); gq_stage<T, false>(role, y, K, s, m, q, k, nullptr);
             sub_step();
             est = k;
         }
@@ -423,9 +427,10 @@ template <class T> __device__ __forceinline__ void gq_phys_pair(int role, const 
 }
 
 // ---- the guard: rk4_delta_guarded of gl_model.hpp over the quad (same ladder, same acceptance rules) ---------------------------------
-template <class T, int WIN>
-__device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
-                                      T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps, bool verify, int* first_flags)
+template <class T, int WIN, bool LDSQ>
+__device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
+                                                      const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps,
+                                                      bool verify, int* first_flags)
 {
     using M = Math<T>;
     const QTol<T> tol = gq_tol<T>(role);
@@ -437,7 +442,7 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         if (done) break;                                   // uniform inside the quad: every decision below is
         ScStat<T> st;
-        rk_delta_quad<T, WIN>(role, z0, s, m, cr, dt, n, del, st);
+        rk_delta_quad<T, WIN, LDSQ>(role, z0, s, K, m, cr, dt, n, del, st);
         total += st.n_steps;
         const int n_nom = ((n + WIN - 1) / WIN) * WIN;
         if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);

@@ -345,8 +345,22 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
 #pragma unroll
     for (int j = 0; j < 7; ++j) d[j] = a.weather[(size_t)row * a.nd + j];
     const CropConst<T>& cr = m.crop;
-    StepCoef<T> s;
-    precompute(u, d, m, cr, s);
+    // fp64: the coefficient blocks live in LDS (rk_delta_quad<LDSQ>): StepCoef once per quad, LaneK per lane, records padded to an
+    // odd number of 8-byte words (conflict-free ds_read_b64 across the lanes)
+    constexpr bool LDSQ = sizeof(T) == 8;
+    struct SRec { StepCoef<T> s; T pad[(sizeof(StepCoef<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
+    struct KRec { LaneK<T> k; T pad[(sizeof(LaneK<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
+    __shared__ SRec sh_s[LDSQ ? WAVE / 4 : 1];
+    __shared__ KRec sh_k[LDSQ ? WAVE : 1];
+    StepCoef<T> s_reg;
+    LaneK<T> k_reg;
+    if (!LDSQ || role == 0) precompute(u, d, m, cr, s_reg);
+    if (LDSQ) {
+        if (role == 0) sh_s[threadIdx.x >> 2].s = s_reg;
+        __syncthreads();                       // one wavefront per block: orders the LDS writes before the quad's reads
+    }
+    const StepCoef<T>& s = LDSQ ? sh_s[threadIdx.x >> 2].s : s_reg;
+    LaneK<T>& K = LDSQ ? sh_k[threadIdx.x].k : k_reg;
     // the lane's states, in the integrator's coordinates (screens / inner cover face as differences to their air node)
     auto X = [&](int i) { return a.x[(size_t)i * a.ld + bb]; };
     QVec<T> x0, z0, del;
@@ -366,8 +380,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     }
     bool bad;
     int extra_steps, first_flags = 0;
-    const int retries = rk4_delta_guarded_quad<T, RK4_WINDOW<T>::value>(role, z0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps,
-                                                                       a.verify != 0, &first_flags);
+    const int retries = rk4_delta_guarded_quad<T, RK4_WINDOW<T>::value, LDSQ>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps,
+                                                                             a.verify != 0, &first_flags);
     // ---- new state: physical increments of what the lane owns
     P2<T> dP;
     gq_phys_pair<T>(role, del, dP);
@@ -1382,17 +1396,17 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
         return GLGYM_OK;
     }
     // Layout by batch size: four lanes per environment while the batch leaves SIMDs idle (GLGYM_LAYOUT = one | quad overrides).
-    // The quad kernels integrate classical RK4 of the default ODE with shared crop parameters and the interlights off, in fp32:
-    // in fp64 the quad's ten 12-entry state vectors + the coefficient blocks need 512 registers + 336 B of scratch, and hipcc 7.2's
-    // spill code is not to be trusted on this kernel either (right with a printf in the loop, failed integrations without:
-    // DESIGN.md section 5) -- the fp64 quad layout waits for the coefficient blocks to move to LDS.
-    if constexpr (sizeof(T) == 4) {
+    // The quad kernels integrate classical RK4 of the default ODE with shared crop parameters and the interlights off.  fp64: the
+    // coefficient blocks live in LDS (rk_delta_quad<LDSQ>) -- with them in registers the kernel needed 512 registers + 336 B of
+    // scratch and hipcc 7.2's spill code failed on it (failed integrations from the reset state; correct with a printf in the
+    // loop); in LDS: 479 registers, no scratch, every fp64 parity test green, 5.8 ms per env-step against the mailbox kernel's 8.8.
+    {
         const char* le_ = std::getenv("GLGYM_LAYOUT");          // read per launch: tests and tools switch it between steps
         const int layout_env = !le_ ? 0 : (le_[0] == 'q' ? 2 : 1);
         const bool quad_ok = h->scheme == GLGYM_SCHEME_RK4 && !a->crop_p && !m.intLampActive;
         if (quad_ok && (layout_env == 2 || (layout_env == 0 && a->B <= 4 * h->n_simd * 4))) {
             const dim3 qgrid((4 * a->B + WAVE - 1) / WAVE);
-            const bool qdef = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+            const bool qdef = h->use_specialised && sizeof(T) == 4 && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
             if (qdef) hipLaunchKernelGGL((step_kernel_quad<T, true>), qgrid, block, 0, st, k, m, rw);
             else hipLaunchKernelGGL((step_kernel_quad<T, false>), qgrid, block, 0, st, k, m, rw);
             HIPCHK(hipGetLastError());

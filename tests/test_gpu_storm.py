@@ -179,4 +179,5 @@ def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
     for k in ("n_ode_fail", "n_done", "n_env_steps"):
         assert a[1][k] == b[1][k] and a[4][k] == b[4][k], k
     assert abs(a[1]["n_refined_substeps"] - b[1]["n_refined_substeps"]) <= 0.02 * a[1]["n_refined_substeps"] + 64
-    assert scaled_err(b[0], XT) < 2e-4
+    from test_jump_fixture import judge
+    assert judge(b[0], XT, 2e-4)[0] == 0                       # and both are inside the bar of the tight truth (fp32 floor rule)
