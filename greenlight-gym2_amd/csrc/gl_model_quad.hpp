@@ -19,8 +19,8 @@
 //   of the rate bound.
 // Same scheme as rk_delta / rk4_delta_guarded of gl_model.hpp, decision for decision (windows, tier 2b at the predicted
 // midpoint, exact harvest sub-flow, wet surfaces as differences to their air node, rate bound -> sub-steps per window, movement
-// limiter, embedded error estimate, branch invariant, closing evaluation, step-doubling ladder): the oracle's restatement
-// (oracle/gl_oracle.c rk_sc_impl) is the reference for both layouts.  Classical RK4, default ODE variant, shared crop parameters,
+// limiter, embedded error estimate, branch invariant, closing evaluation, step-doubling ladder): the CPU checker's restatement of
+// that scheme is the reference for both layouts (tests/).  Classical RK4, default ODE variant, shared crop parameters,
 // interlights off (what the reference configures); everything else stays on the one-lane kernels.
 // Measured (tools/lanes_stage_proto.hip, profiles/r03_lanes_stage_proto.txt): the bare RK4 chain runs 1.48x (fp32) / 1.43x (fp64)
 // the env-steps per second of the one-lane layout for B <= 16 384 and 0.73x at B = 65 536 -- hence the dispatch by batch size.
