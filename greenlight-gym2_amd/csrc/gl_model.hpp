@@ -1259,7 +1259,10 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         // (or goes unstable at the refinement cap) does, and then STAYS on the wrong branch: finite, smooth, kelvins off.
         // sbits: bit 3 + j = surface j below its air node, bit j = above it inside the bistable regime with positive drive.
         // rk_delta flags a window that took a surface from the first to the second.  (Cubes instead of the cube root.)
+        // (the second kind of bit is only ever acted on after a capped window -- *side carries that on entry -- so the wavefront
+        // skips its arithmetic otherwise)
         int sbits = 0;
+        const bool want_far = side && GL_WAVE_ANY(*side != 0);
         auto harmful = [&](T iCap, T hcoef, T hec, T g, T tSurf, T dT, T ddT, int j) {
             const T tc = M::min(M::max(M::abs(tSurf), T(2)), T(40));
             const T kap = iCap * M::abs(hcoef), G = LK * M::max(g, T(0));
@@ -1267,7 +1270,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
             const T rfree = ddT + iCap * hec * (dT + LK * g);
             const T kG3 = kG * kG * kG;
             sbits |= (dT > T(0)) ? (8 << j) : 0;
-            sbits |= ((dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
+            if (want_far) sbits |= ((dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
             return (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
                    (kG3 > T(0.3) * rfree * rfree);
         };
@@ -1383,7 +1386,7 @@ __device__ __noinline__ inline void rhs_stage_f64()
     StepCoef<double> s; SlowCoef<double> q; CropConst<double> cr; ModelConst<double> m;
     f64_get(s, GL_F64_S); f64_get(q, GL_F64_Q); f64_get_model(m); f64_get_crop(cr, m);
     double lam = RATES ? gl_lds64[GL_F64_LAM * 64 + threadIdx.x] : 0.0;
-    int side = 0;
+    int side = RATES ? (int)gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] : 0;
     rhs_fast<double, false, PIPE, RATES, true>(x, q, s, m, cr, dx, RATES ? &lam : nullptr, RATES ? &side : nullptr);
 #pragma unroll
     for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x] = dx[i];
@@ -1436,7 +1439,7 @@ template <bool PIPE> struct RhsStage<double, PIPE> {
     {
 #pragma unroll
         for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] = x[i];
-        if (RATES) gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = *lam;
+        if (RATES) { gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = *lam; gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] = (double)*side; }
         rhs_stage_f64<PIPE, RATES>();
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[i] = gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x];
@@ -1660,7 +1663,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             if (gl_slow_slot(i) >= 0) { xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)]; dwin[gl_slow_slot(i)] = del[i]; }
         RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
         T lam = hnom;                                             // in: nominal sub-step; out: the rate bound
-        int side = 0;
+        int side = capped_prev ? 1 : 0;                           // in: was the window just taken capped?  out: the side bits
         GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, true>(y, q, s, m, cr, k, &lam, &side);
         // branch invariant (rhs_fast<RATES>): a wet surface that was below its air node at the last look and now sits above
         // it inside the bistable regime with positive drive has jumped branches -- acted on only where the sub-step could not

@@ -240,6 +240,7 @@ __device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVe
     // the lane's own wet surfaces: x (and y on the screen lane).  Lane 3: cover; lane 2: thermal, blackout screen
     auto wet_smooth = [&](T hec, T sv, T r) { return LK * hec * (kDs * sv * r * r); };
     int sbits = 0;
+    const bool want_far = GL_WAVE_ANY(*side != 0);          // in: was the window just taken capped? (rhs_fast<RATES>)
     T rows = T(0);
     auto surface = [&](bool on, int j, T iCap, T hcoef, T hecAbs, T g, T tSurf, T dT, T ddT, T base) {
         // harm gate, side bits and (second pass) the pinned rate: gl_model.hpp harmful() / sc_pinned_rate()
@@ -247,7 +248,7 @@ __device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVe
         const T kap = iCap * M::abs(hcoef), G = LK * M::max(g, T(0));
         const T kG = kap * G, rfree = ddT + iCap * hecAbs * (dT + LK * g), kG3 = kG * kG * kG;
         sbits |= (on && dT > T(0)) ? (8 << j) : 0;
-        sbits |= (on && (dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
+        if (want_far) sbits |= (on && (dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
         const bool harm = on && (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
                           (kG3 > T(0.3) * rfree * rfree);
         T row = iCap * (base + f43 * hecAbs);
@@ -348,7 +349,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         // ---- first stage of the window's first sub-step with the rate bound; branch invariant; error estimate of the last sub-step
         QRates<T> R;
         GQ_FENCE(); gq_stage<T, true>(role, y, K, s, m, q, k, &R);
-        int side = 0;
+        int side = capped_prev ? 1 : 0;
         const T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, hnom, &side);
         flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
         side_prev = side;
