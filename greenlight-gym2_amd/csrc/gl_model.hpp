@@ -1874,9 +1874,11 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
             // ... and the finest attempt is taken as it stands when nothing flagged it: where consecutive attempts disagree although
             // each is resolved (env-steps that start ON a kink -- the reset state -- or pass a bifurcation: which branch a wet
             // screen ends on is sensitive at the 1e-4 level for any solver), the best available answer beats a failed episode
-            // (agreement verifies an attempt that was merely heavy or tripped the error estimate; it does NOT launder the branch
-            // invariant: a capped sub-step that took a wet surface across lands on the same wrong equilibrium at n and 2 n alike)
-            ok = (clean && !verify) || (complete && have_prev && !(st.flags & SC_FLAG_BRANCH) && worst <= T(SC_AGREE)) ||
+            // (agreement verifies flagged attempts too, the branch flag included: on 6 500 raw-jump tuples with half-hour spin-ups,
+            // tools/gpu_stress.py, 81 env-steps carried it at every level -- 80 agreeing with the fine truth, one agreeing on the
+            // wrong branch at 320 ... 2 560 sub-steps, where scipy's BDF at 1e-6 lands on the same wrong branch.  Refusing them all
+            // would trade one silent error for 80 false failures: profiles/r03_gpu_stress.txt)
+            ok = (clean && !verify) || (complete && have_prev && worst <= T(SC_AGREE)) ||
                  (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
             done = ok || attempt == SC_ATTEMPTS - 1;
             have_prev = complete;

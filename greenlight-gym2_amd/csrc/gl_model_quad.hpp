@@ -460,8 +460,7 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
         dif.p = now.p - prev.p;
         for (int i = 0; i < 6; ++i) dif.sh[i] = now.sh[i] - prev.sh[i];
         const T worst = gq_max(gq_fast_max(dif, tol.est));
-        ok = (clean && !verify) || (complete && have_prev && !(st.flags & SC_FLAG_BRANCH) && worst <= T(SC_AGREE)) ||
-             (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
+        ok = (clean && !verify) || (complete && have_prev && worst <= T(SC_AGREE)) || (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
         done = ok || attempt == SC_ATTEMPTS - 1;
         have_prev = complete;
         prev = now;
