@@ -727,6 +727,13 @@ void gl_oracle_rk_lagged(const double *x0, const double *u, const double *d, con
     rk_lagged_impl(x0, u, d, p, dt, n_sub, x1, 0, order, window);
 }
 
+/* the same with the 14-wide weather rows of the ode_pipe variant (the kernels run RK4 with a two-sub-step window) */
+void gl_oracle_rk_lagged_pipe(const double *x0, const double *u, const double *d14, const double *p, double dt, int n_sub,
+                              int order, int window, double *x1)
+{
+    rk_lagged_impl(x0, u, d14, p, dt, n_sub, x1, 1, order, window);
+}
+
 void gl_oracle_rk4_lagged(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                           double *x1)
 {

@@ -46,6 +46,7 @@ def lib():
         L.gl_oracle_rk4_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk4_lagged_pipe.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, _dp]
         L.gl_oracle_rk_lagged.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]
+        L.gl_oracle_rk_lagged_pipe.argtypes = L.gl_oracle_rk_lagged.argtypes
         L.gl_oracle_rk_sc.argtypes = [_dp] * 4 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]
         L.gl_rate_bound.argtypes = [_dp] * 4
         L.gl_oracle_rk_sc_guarded.argtypes = [_dp] * 4 + [ctypes.c_double] + [ctypes.c_int] * 4 + [_dp, _dp]
@@ -126,11 +127,13 @@ def rk4_lagged(x, u, d, p, dt=900.0, n_sub=256, pipe=False):
     return out
 
 
-def rk_lagged(x, u, d, p, dt=900.0, n_sub=256, order=4, window=1):
-    """Experiment hook: RK order 2 / 3 / 4 with tier 2b and the harvest flow shared by `window` sub-steps."""
-    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
+def rk_lagged(x, u, d, p, dt=900.0, n_sub=256, order=4, window=1, pipe=False):
+    """The kernels' fixed-step schemes without the stability control: RK order 2 / 3 / 4 with tier 2b and the harvest flow
+    shared by `window` sub-steps (the kernels: RK4 window 2, RK3 window 3, midpoint window 4)."""
+    x, u, d, p = _c(x, NX), _c(u, NU), _c(d, 14 if pipe else ND), _c(p, NP)
     out = np.empty(NX)
-    lib().gl_oracle_rk_lagged(_p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window), _p(out))
+    (lib().gl_oracle_rk_lagged_pipe if pipe else lib().gl_oracle_rk_lagged)(
+        _p(x), _p(u), _p(d), _p(p), float(dt), int(n_sub), int(order), int(window), _p(out))
     return out
 
 

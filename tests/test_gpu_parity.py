@@ -58,14 +58,22 @@ def test_evalF_signature_and_value(models, golden, oracle):
     out = m64.evalF(X[0], U[0], D[0], P[0])
     assert isinstance(out, list) and len(out) == 28 and all(isinstance(v, float) for v in out)
     ok = np.ones(len(X), dtype=bool)          # every tuple, incl. the harvest-switch zone (exact sub-flow)
-    ref = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
+    ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, 256, 4, 2) for i in range(len(X))])
     got64 = np.array([m64.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
     got32 = np.array([m32.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
     assert scaled_err(got64[ok], ref[ok]) < 1e-9
     assert scaled_err(got32[ok], ref[ok]) < 2e-5
-    # RK4-256 vs the tight stiff solve on perturbed (off-equilibrium) tuples; the CVODES-tolerance proxy
-    # (BDF rtol=atol=1e-6) sits at 1.3e-5 on the same tuples, so RK4-256 is inside the reference's own band
-    assert scaled_err(got64[ok], XT[ok]) < 1.3e-5
+    # vs the tight stiff solve on perturbed (off-equilibrium) tuples; the CVODES-tolerance proxy (BDF rtol=atol=1e-6) sits
+    # at 1.3e-5 on the same tuples.  With 256 sub-steps the two-sub-step tier-2b window is 7 s long and the kernel lands
+    # just outside that band; at the default 320 sub-steps (5.6 s windows) it is inside it.
+    assert scaled_err(got64[ok], XT[ok]) < 1.5e-5
+    from gl_gym_amd import GreenLight
+    m_def = GreenLight(28, 6, 10, 208, 900.0, dtype="float64")
+    assert m_def.n_sub == 320
+    e_def = scaled_err(m_def.evalF_batch(X, U, D, P), XT)
+    m_def.close()
+    print(f"fp64 RK4 vs tight one-step solutions: n_sub 256 {scaled_err(got64[ok], XT[ok]):.2e}, default 320 {e_def:.2e}")
+    assert e_def < 1.3e-5
     # batched call with per-row crop parameters == row-by-row calls
     got_b = m64.evalF_batch(X[:16], U[:16], D[:16], P[:16])
     assert scaled_err(got_b, got64[:16]) < 1e-12
@@ -228,7 +236,7 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
             xg = env.x.double().cpu().numpy()
             for b in range(0, 64, 9):
                 u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-                ref = oracle.rk4_lagged(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256)
+                ref = oracle.rk_lagged(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256, 4, 2)
                 assert scaled_err(xg[b], ref) < tol, (dtype, k, b)
         env.close()
 
@@ -249,7 +257,7 @@ def test_config1_rule_based_day_against_fixture(golden):
     X, R, U, INFO, OBS = g["x"], g["reward"], g["u"], g["info"], g["obs"]
     keys = [str(k) for k in g["info_keys"]]
     ctrl = RuleBasedController()
-    for n_sub, tol in ((512, 1e-6), (256, 6e-5)):
+    for n_sub, tol in ((1024, 1e-6), (256, 6e-5)):     # 1024: tier-2b windows of 1.76 s
         env = TomatoVecEnv(8, weather=g["weather"], params=g["p"], dtype="float64", n_sub=n_sub, season_length=1,
                            start_rows=[0], start_days=[0.0], auto_reset=False)
         obs = env.reset()
@@ -299,7 +307,7 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
         for b in range(0, B, 11):
             p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
             u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-            ref = oracle.rk4_lagged(x_prev[b], u, w[k], p, 900.0, 256)
+            ref = oracle.rk_lagged(x_prev[b], u, w[k], p, 900.0, 256, 4, 2)
             assert scaled_err(xg[b], ref) < 5e-5
     assert len(np.unique(crop[1])) > B // 2                                            # envs really differ
     assert env.metrics()["n_ode_fail"] == 0
@@ -379,7 +387,7 @@ def test_stability_control_in_storm(golden, oracle):
         x_prev = env.x.double().cpu().numpy().copy()
         env.step_raw_control(ctrl)
         ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2)
-        plain_failed |= not np.all(np.isfinite(oracle.rk4_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256)))
+        plain_failed |= not np.all(np.isfinite(oracle.rk_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 2)))
         assert np.all(np.isfinite(ref)) and not failed
         assert scaled_err(env.x[0].double().cpu().numpy(), ref) < 5e-5, k
     m = env.metrics()
@@ -508,7 +516,7 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     for k in range(env.N + 1):
         u = rng.uniform(0, 1, 6)
         xs, term = env.step_raw_control_pipeinput(np.repeat(u[None], 4, 0))
-        x = oracle.rk4_lagged(x, u, w14[k], p64, 300.0, 256, pipe=True)
+        x = oracle.rk_lagged(x, u, w14[k], p64, 300.0, 256, 4, 2, pipe=True)
         assert scaled_err(xs[0], x) < 1e-9 and np.array_equal(xs[0], xs[3])
         assert bool(term[0]) == (k == env.N)
     env.close(); ref_env.close()
@@ -555,7 +563,7 @@ def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
     assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3").n_sub == 120 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2").n_sub == 376
 
 
-@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 1), ("rk2", 2, 4), ("rk3", 3, 3)])
+@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 2), ("rk2", 2, 4), ("rk3", 3, 3)])
 def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win):
     """The fp64 step kernels spill heavily and hipcc 7.2 has miscompiled them before (rk_delta's
     SUM_INCS note): every env-step of a short rollout must agree with the oracle's restatement of the same scheme to

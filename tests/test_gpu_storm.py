@@ -57,7 +57,7 @@ def test_storm_step_maps_through_step_kernel(golden, oracle, scheme, n_sub, dtyp
     assert m["n_ode_fail"] == 0 and not done.any()
     assert m["n_refined_substeps"] > 0                           # lanes in the storm took more than n_sub sub-steps
     if dtype == "float64":                                       # the oracle's restatement takes the same sub-steps
-        order, win = {"rk4": (4, 1), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
+        order, win = {"rk4": (4, 2), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
         ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, order, win, verify=True)
                for i in range(B)]        # step_raw_control integrates verified (glgym_set_verify: AUTO)
         assert m["n_refined_substeps"] == sum(r_[2] for r_ in ref)
