@@ -73,6 +73,18 @@ def load_pmc(variant: str):
     return None
 
 
+def workload_label(args, B, world):
+    """Which BASELINE.json config this run is (index into `configs`), or that it is a variant of the headline."""
+    if args.scheme == "rk4" and not args.vecnorm:
+        if args.uncertainty:
+            return "BASELINE configs[4]" if (B == 65536 and args.dtype == "f32") else "variant of BASELINE configs[4]"
+        if args.dtype == "f64":
+            return "BASELINE configs[1]" if B == 4096 else "variant of BASELINE configs[1]"
+        if B == 65536:
+            return "BASELINE configs[2]" if world == 1 else "BASELINE configs[2] per GPU (configs[3] at 8 GPUs)"
+    return "variant of BASELINE configs[2]"
+
+
 DEFAULT_SCHEME = "rk4"
 STAGES = {"rk4": 4, "rk2": 2, "rk3": 3}
 N_SUB = {"rk4": 320, "rk2": 376, "rk3": 354}
@@ -326,11 +338,24 @@ def main():
         # executed work: the recorded PMC instruction counts of the default workload, scaled to this run's batch / n_sub,
         # over the kernel time measured live with HIP events on the launch stream
         variant = f"{args.dtype}_{args.scheme}" + ("_config5" if args.uncertainty else "")
+        # batches up to 16 384 run the four-lanes-per-environment kernel (glgym.hip launch_step; GLGYM_LAYOUT overrides): another
+        # kernel, other counters
+        layout = os.environ.get("GLGYM_LAYOUT", "")
+        if args.scheme == "rk4" and not args.uncertainty and (layout == "quad" or (layout == "" and B <= 16384)):
+            variant += "_quad"
         pmc = load_pmc(variant)
         roof = {"bound": "valu", "kernel": "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["fma"],
                 "unit": "TFLOP/s", "frac": None, "traffic": None}
         if pmc is not None:
-            scale = (B / 65536.0) * (args.n_sub / float(pmc.get("n_sub", N_SUB[args.scheme])))
+            pmc_batch = float(pmc.get("batch", 65536))
+            scale = (B / pmc_batch) * (args.n_sub / float(pmc.get("n_sub", N_SUB[args.scheme])))
+            # the clock recorded under the profiler (GRBM_GUI_ACTIVE / kernel time of that pass); a value above the part's
+            # 2.4 GHz is a counter artefact (seen on the 18 ms fp64 launches) -- the guide's clock then
+            clk = pmc.get("clock_ghz") or 0.0
+            clk_note = "the clock recorded under the profiler (%.3f GHz)" % clk
+            if not (0.5 <= clk <= 2.45):
+                clk_note = "the guide's 2.4 GHz (the profiler pass recorded an implausible %.2f GHz)" % clk
+                clk = CLOCK_GUIDE_HZ / 1e9
             tkey = "SQ_INSTS_VALU_TRANS_F32" if args.dtype == "f32" else "SQ_INSTS_VALU_TRANS_F64"
             valu, trans = pmc["SQ_INSTS_VALU"] * scale, pmc.get(tkey, 0.0) * scale
             sfx = "_F32" if args.dtype == "f32" else "_F64"
@@ -351,16 +376,15 @@ def main():
                 "frac_note": "executed issue slots / available on the GUIDE's ruler: ((INSTS_VALU - TRANS) x 2 + TRANS x 8 cycles"
                              + (", x 2 for fp64" if wide > 1 else "") + ") / (1024 SIMDs x live kernel time x 2.4 GHz), instruction "
                              "counts from the recorded PMC passes of this variant; <= 1 by construction",
-                "frac_measured_ruler": need_meas / (N_SIMD * t_s * pmc["clock_ghz"] * 1e9),
+                "frac_measured_ruler": need_meas / (N_SIMD * t_s * clk * 1e9),
                 "frac_measured_ruler_note": "same with the issue costs measured on this chip with >= 2 co-resident waves (2.3 / 7.7 "
-                                            "cycles, profiles/r02_microbench_issue_rates.txt) and the clock recorded under the "
-                                            "profiler (%.3f GHz)" % pmc["clock_ghz"],
+                                            "cycles, profiles/r02_microbench_issue_rates.txt) and " + clk_note,
                 "valu_busy_one_wave_per_simd": pmc.get("valu_busy"),
                 "valu_busy_note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the recorded profile: B = 65 536 is exactly one "
                                   "wave per SIMD and a lone wave is issued a vector instruction only every ~5 cycles "
                                   "(transcendental 8.4), so this -- not `frac` -- is how close the kernel is to the ceiling "
                                   "its launch geometry allows",
-                "traffic": pmc["traffic_bytes"] * (B / 65536.0),
+                "traffic": pmc["traffic_bytes"] * (B / pmc_batch),
                 "valu_insts_per_launch": valu, "trans_insts_per_launch": trans,
                 "pmc_source": pmc.get("source"), "pmc_variant": variant,
             })
@@ -383,8 +407,9 @@ def main():
             "metric": "TomatoEnv env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: TomatoEnv batch 65536/GPU, RK4 sub-stepped, synthetic "
-                                   "weather year (KNMI Amsterdam files absent), random actions U(-1,1)",
+            "config": {"workload": workload_label(args, B, world) + ": TomatoEnv batch %d/GPU, %s %s sub-stepped, synthetic "
+                                   "weather year (KNMI Amsterdam files absent), random actions U(-1,1)"
+                                   % (B, "fp32" if args.dtype == "f32" else "fp64", args.scheme.upper()),
                        "batch_per_gpu": B, "global_batch": B * world, "integrator": args.scheme, "n_sub": args.n_sub,
                        "dt_s": 900,
                        "obs_kernel": not args.no_obs, "obs_dim": env.obs_dim, "auto_reset": True, "hip_graph": bool(args.graph),

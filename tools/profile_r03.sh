@@ -28,6 +28,7 @@ if durs and "GRBM_GUI_ACTIVE" in d:
     d["kernel_ns_under_pmc"] = sum(durs) / len(durs)
     d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["kernel_ns_under_pmc"]      # the counter is summed over the 8 XCDs
 d["n_sub"] = $nsub
+d["batch"] = ${PBATCH:-65536}
 d["kernel"] = "$pat"
 json.dump(d, open("$V/constants.json", "w"), indent=1)
 print("$name", {k: d.get(k) for k in ("SQ_INSTS_VALU", "valu_busy", "clock_ghz", "kernel_ns_under_pmc", "traffic_bytes")})
@@ -43,10 +44,15 @@ variant f32_rk3 "step_kernel<float, false, true, false, 2, 1>" 354 F32 --scheme 
 variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 376 F32 --scheme rk2
 variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 320 F32 --uncertainty 0.2
 variant f64_rk4 "step_kernel<double, false, false, false, 0, 1>" 320 F64 --dtype f64
+# the four-lanes-per-environment kernels (what batches up to 16 384 run), recorded at B = 4 096 (config 2 in fp64)
+PBATCH=4096
+variant f64_rk4_quad "step_kernel_quad<double, false>" 320 F64 --dtype f64 --batch 4096
+variant f32_rk4_quad "step_kernel_quad<float, true>" 320 F32 --batch 4096
+PBATCH=65536
 python - <<PY
 import json
 out = {}
-for v in ("f32_rk4", "f32_rk3", "f32_rk2", "f32_rk4_config5", "f64_rk4"):
+for v in ("f32_rk4", "f32_rk3", "f32_rk2", "f32_rk4_config5", "f64_rk4", "f64_rk4_quad", "f32_rk4_quad"):
     try:
         out[v] = json.load(open("$OUT/%s/constants.json" % v))
     except OSError:
