@@ -55,6 +55,10 @@ sce = lambda a, b: np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * COLMAX)
 ok = np.isfinite(T2).all(axis=1) & np.isfinite(T1).all(axis=1) & (sce(np.nan_to_num(T1), np.nan_to_num(T2)).max(axis=1) < 2e-7)
 print(f"truth runs (fp64 kernel, n_sub 2 560 / 5 120, unverified guard): {int(np.isnan(T1).any(axis=1).sum())} / {int(np.isnan(T2).any(axis=1).sum())} rows reported as failed integrations")
 print(f"{ok.sum()} of {N} tuples with truth ({time.time() - t0:.0f} s); wind up to {D[:, 4].max():.0f} m/s")
+if "dump4" in sys.argv:        # the review-recipe tuples with their truth, for offline studies of the guard (oracle restatement)
+    k4 = ok & (kind == 4)
+    np.savez("gpurun_out/r03_kind4_tuples.npz", x=XS[k4], u=U[k4], d=D[k4], truth=T2[k4])
+    print(f"dumped {int(k4.sum())} review-recipe tuples"); sys.exit(0)
 for scheme in ("rk4", "rk3", "rk2"):
     for dtype in ("float64", "float32"):
         m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme)
