@@ -1403,14 +1403,20 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // The quad kernels integrate classical RK4 of the default ODE with shared crop parameters and the interlights off.  fp64: the
     // coefficient blocks live in LDS (rk_delta_quad<LDSQ>) -- with them in registers the kernel needed 512 registers + 336 B of
     // scratch and hipcc 7.2's spill code failed on it (failed integrations from the reset state; correct with a printf in the
-    // loop); in LDS: 479 registers, no scratch, every fp64 parity test green, 5.8 ms per env-step against the mailbox kernel's 8.8 (4.7 against 7.3 with the two-sub-step window).
+    // loop); in LDS: 479 registers, no scratch, every fp64 parity test green, 5.8 ms per env-step against the mailbox kernel's 8.8 (4.7
+    // against 7.3 with the two-sub-step window, 3.9 with the default parameter block compiled in).  fp64 takes the quad kernel at
+    // LARGE batches too: it has no scratch / mailbox traffic and scales with the batch (16 384 environments per 4.07 ms round: 16.2 ms
+    // at 65 536), where the one-lane kernel goes memory-bound (7.3 ms up to 16 384, 8.9 at 32 768, 17.7 at 65 536); only between
+    // 16 384 and 28 672 is one lane per environment ahead (7.9 against 8.4 ms).  profiles/r03_small_batch_rate_fp64.txt
     {
         const char* le_ = std::getenv("GLGYM_LAYOUT");          // read per launch: tests and tools switch it between steps
         const int layout_env = !le_ ? 0 : (le_[0] == 'q' ? 2 : 1);
         const bool quad_ok = h->scheme == GLGYM_SCHEME_RK4 && !a->crop_p && !m.intLampActive;
-        if (quad_ok && (layout_env == 2 || (layout_env == 0 && a->B <= 4 * h->n_simd * 4))) {
+        const int b_small = 4 * h->n_simd * 4;                   // 16 384 on MI355X: one quad-kernel round
+        const bool by_size = a->B <= b_small || (sizeof(T) == 8 && 4 * a->B > 7 * b_small);
+        if (quad_ok && (layout_env == 2 || (layout_env == 0 && by_size))) {
             const dim3 qgrid((4 * a->B + WAVE - 1) / WAVE);
-            const bool qdef = h->use_specialised && sizeof(T) == 4 && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+            const bool qdef = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
             if (qdef) hipLaunchKernelGGL((step_kernel_quad<T, true>), qgrid, block, 0, st, k, m, rw);
             else hipLaunchKernelGGL((step_kernel_quad<T, false>), qgrid, block, 0, st, k, m, rw);
             HIPCHK(hipGetLastError());

@@ -46,7 +46,7 @@ variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 320 F32 --
 variant f64_rk4 "step_kernel<double, false, false, false, 0, 1>" 320 F64 --dtype f64
 # the four-lanes-per-environment kernels (what batches up to 16 384 run), recorded at B = 4 096 (config 2 in fp64)
 PBATCH=4096
-variant f64_rk4_quad "step_kernel_quad<double, false>" 320 F64 --dtype f64 --batch 4096
+variant f64_rk4_quad "step_kernel_quad<double, true>" 320 F64 --dtype f64 --batch 4096
 variant f32_rk4_quad "step_kernel_quad<float, true>" 320 F32 --batch 4096
 PBATCH=65536
 python - <<PY

@@ -11,7 +11,8 @@ if len(sys.argv) > 2:                                   # child: one layout
     from gl_gym_amd.utils import synthetic_weather
     dtype = sys.argv[1]
     w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
-    for B in (8, 64, 1024, 4096, 16384, 65536):
+    sizes = [int(v) for v in os.environ["GLGYM_RATE_SIZES"].split(",")] if os.environ.get("GLGYM_RATE_SIZES") else (8, 64, 1024, 4096, 16384, 65536)
+    for B in sizes:
         env = TomatoVecEnv(B, weather=w, dtype=dtype, season_length=60, pred_horizon=0.5, seed=1, start_rows=np.arange(0, 20000, 96),
                            auto_reset=True)
         env.reset_tensor()
