@@ -181,3 +181,45 @@ def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
     assert abs(a[1]["n_refined_substeps"] - b[1]["n_refined_substeps"]) <= 0.02 * a[1]["n_refined_substeps"] + 64
     from test_jump_fixture import judge
     assert judge(b[0], XT, 2e-4)[0] == 0                       # and both are inside the bar of the tight truth (fp32 floor rule)
+
+
+def test_fp64_large_batches_take_the_quad_kernel_and_equal_one_lane_per_environment(golden):
+    """fp64 batches beyond 28 672 are dispatched to the four-lanes-per-environment kernel as well (it has no scratch / mailbox
+    traffic and scales with the batch; glgym.hip launch_step).  40 000 environments -- 2.4 rounds of the quad kernel, a ragged last
+    wave -- three env-steps from different start days with random actions: the default dispatch against GLGYM_LAYOUT=one, states
+    to fp64 rounding, rewards, terminal flags and integrator events equal."""
+    import os
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"]
+    B = 40000
+    rng = np.random.default_rng(3)
+    acts = [torch.as_tensor(rng.uniform(-1, 1, (B, 6)).astype(np.float32)) for _ in range(3)]
+    out = {}
+    old = os.environ.get("GLGYM_LAYOUT")
+    try:
+        for layout in ("one", None):
+            if layout is None:
+                os.environ.pop("GLGYM_LAYOUT", None)
+            else:
+                os.environ["GLGYM_LAYOUT"] = layout
+            env = TomatoVecEnv(B, weather=w, dtype="float64", season_length=2, start_rows=[0, 96, 300, 480], seed=11, auto_reset=False)
+            env.reset()
+            rew = []
+            for a in acts:
+                _, r, done, _ = env.step_tensor(a.to(env.device), want_obs=False)
+                rew.append(r.double().cpu().numpy().copy())
+            out[layout] = (env.x.double().cpu().numpy().copy(), np.array(rew), done.cpu().numpy().copy(), env.metrics())
+            env.close()
+    finally:
+        if old is None:
+            os.environ.pop("GLGYM_LAYOUT", None)
+        else:
+            os.environ["GLGYM_LAYOUT"] = old
+    a, b = out["one"], out[None]
+    err = scaled_err(b[0], a[0])
+    print(f"fp64 B = {B}: default dispatch (quad kernel) vs one lane per environment after 3 env-steps: {err:.1e}; "
+          f"refined sub-steps {a[3]['n_refined_substeps']:.0f} / {b[3]['n_refined_substeps']:.0f}")
+    assert err < 1e-10 and np.max(np.abs(a[1] - b[1])) < 1e-9 and np.array_equal(a[2], b[2])
+    for k in ("n_ode_fail", "n_done", "n_env_steps", "n_guard_retries", "n_refined_substeps"):
+        assert a[3][k] == b[3][k], k
