@@ -12,7 +12,7 @@
 //               + cA_i |dA_i|^nA_i dA_i          exchange with its air node A (air | top | outside),  dA = T_A - T_i
 //               + L wet_i hecA_i gate(vp_A - satVp(T_i))                        condensation on the wet surfaces
 //               - cB_i |dB_i|^(1/3) dB_i         second exchange (screens -> top compartment),        dB = T_i - tTop
-//               -+ cP (T_x - T_y)                conduction inside the pair (cover in / out)
+//   (the conduction inside the cover pair is not a row term: the integrator treats it exactly -- rk_delta_quad, COVEXP of gl_model.hpp)
 //               - L mvCanAir                     transpiration (canopy)
 //   Lanes talk through DPP quad_perm only (a full crossbar inside four lanes, no LDS): 8 moves gather the eight q's per stage,
 //   4 x 2 DPP adds reduce the four sums the air / top balances need; per window ~20 more broadcast the inputs of tier 2b and
@@ -90,8 +90,10 @@ template <class T> struct LaneK {
     P2<T> src, iCap, wetC, mAir, mTop, trK;
     P2<T> firX[4], firY[4];        // C[own x|y][lane s .x] and C[own x|y][lane s .y]
     P2<T> cSky;
-    T cP;                          // conduction inside the pair (cover)
     T ro[4];                       // rates of the lane's constant-rate states (tier 2b)
+    // ETD coefficients of the pair's y component for the sub-step in use (rk_delta_quad; part of this record so that the fp64
+    // build keeps them in LDS with the rest of it): cover lane a = 2 cCovCond / capCov, every other lane a = 0 = classical RK4
+    EtdCoef<T> ec;
 };
 
 template <class T>
@@ -122,7 +124,6 @@ __device__ __forceinline__ void gq_make_lane(int role, const StepCoef<T>& s, con
     K.mAir = gq_mk<T>(pk(one, one, one, z), pk(one, one, one, z));
     K.mTop = gq_mk<T>(pk(z, z, z, one), z);
     K.trK = gq_mk<T>(pk(q.mvCanK, z, z, z), z);
-    K.cP = pk(z, z, z, m.cCovCond);
     K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
     K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
 }
@@ -140,7 +141,9 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T co2Air = y.sh[0], co2Top = y.sh[1], tAir = y.sh[2], tTop = y.sh[3], vpAir = y.sh[4], vpTop = y.sh[5];
     const bool cov = role == 3, scr = role == 2, lane0 = role == 0;
     // physical temperatures of the pair: lanes 2 / 3 carry differences to their air node (rhs_fast<WETDIFF>)
-    const P2<T> Tp = gq_mk<T>(scr ? tAir - y.p.x : cov ? tTop - y.p.x : y.p.x, scr ? tAir - y.p.y : y.p.y);
+    // (lane 3, round 4: y.p.y = w = tCovIn - tCovE, rhs_fast<COVEXP>)
+    const T TpX = scr ? tAir - y.p.x : cov ? tTop - y.p.x : y.p.x;
+    const P2<T> Tp = gq_mk<T>(TpX, scr ? tAir - y.p.y : cov ? TpX - y.p.y : y.p.y);
     // ---- long wave: gather the eight q's, 4 source lanes x 2 packed terms
     const P2<T> kk = Tp + gq_sp<T>(c2k), k2 = kk * kk, qp = k2 * k2;
     P2<T> fir = K.cSky * (gq_sp<T>(s.qSky) - qp);
@@ -175,8 +178,8 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
     const T mvCan = vpd * K.trK.x * M::rcp(m.rB + s.rSK * rfCo2 * rfVp);
     // ---- the pair's balances
-    const T cond = K.cP * (Tp.x - Tp.y), L = m.latent;
-    const P2<T> net = K.src + fir + fluxA + gq_sp<T>(L) * mv - fluxB + gq_mk<T>(-cond - L * mvCan, cond);
+    const T L = m.latent;
+    const P2<T> net = K.src + fir + fluxA + gq_sp<T>(L) * mv - fluxB + gq_mk<T>(-(L * mvCan), T(0));
     const P2<T> dTp = K.iCap * net;
     // ---- sums the air / top balances need
     const P2<T> fa = fluxA * K.mAir, ft = fluxA * K.mTop, ma = mv * K.mAir, mt = mv * K.mTop;
@@ -214,7 +217,8 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     k.sh[4] = m.kCapVpAir * tAirK * (sVapAir - mvAirTop - mvAirOut);
     k.sh[5] = m.kCapVpTop * tTopK * (sVapTop + mvAirTop - mvTopOut);
     // the pair in the integrator's coordinates: d(tAir - T)/dt on the screens, d(tTop - tCovIn)/dt on the cover
-    k.p = gq_mk<T>(scr ? k.sh[2] - dTp.x : cov ? k.sh[3] - dTp.x : dTp.x, scr ? k.sh[2] - dTp.y : dTp.y);
+    // (cover lane: the classical part of slot 5, d(tTop - sigma / 2)/dt, and N_w = nIn - nOut: rhs_fast<COVEXP>)
+    k.p = gq_mk<T>(scr ? k.sh[2] - dTp.x : cov ? k.sh[3] - T(0.5) * (dTp.x + dTp.y) : dTp.x, scr ? k.sh[2] - dTp.y : cov ? dTp.x - dTp.y : dTp.y);
     const T perDay = T(1.0 / 86400.0);
     k.o[0] = lane0 ? perDay * (tCan - y.o[0]) : K.ro[0];             // lane 0: tCan24, tCanSum; lane 3: tIntLamp (off), time
     k.o[1] = lane0 ? perDay * tCan : cov ? perDay : K.ro[1];
@@ -236,7 +240,8 @@ __device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVe
     const T r1 = m.iCapCo2Top * fAir;
     const T r3 = m.iCapTop * (m.rhoCp * (R.fRoofAbs + T(5.0 / 3.0) * R.fScrAbs) + f43 * (hTopCovAbs + hecThTop + hecBlTop));
     const T r16 = m.kCapVpTop * (kMv * fAir + R.tTopK * T(6.4e-9 * 1.1) * hTopCovAbs);
-    const T rOther = M::max(M::max(r1, r3), M::max(r16, s.rateCovE));
+    const T gam = m.iCapCov * m.cCovCond;                   // the conduction is integrated exactly: it leaves both cover rows
+    const T rOther = M::max(M::max(r1, r3), M::max(r16, s.rateCovE - T(2) * gam));
     // the lane's own wet surfaces: x (and y on the screen lane).  Lane 3: cover; lane 2: thermal, blackout screen
     auto wet_smooth = [&](T hec, T sv, T r) { return LK * hec * (kDs * sv * r * r); };
     int sbits = 0;
@@ -258,9 +263,11 @@ __device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVe
     // x component: cover (lane 3) | thermal screen (lane 2)
     {
         const T hecAbs = M::abs(R.hecA.x);
-        const T base = cov ? T(2) * m.cCovCond + wet_smooth(hecAbs, R.sv.x, R.rr.x) + s.firCovIn
+        const T base = cov ? wet_smooth(hecAbs, R.sv.x, R.rr.x) + s.firCovIn
                            : f43 * R.hecB.x + wet_smooth(hecAbs, R.sv.x, R.rr.x) + s.firTh;
-        surface(cov || scr, cov ? 0 : 1, cov ? m.iCapCov : m.iCapThScr, cov ? m.cTopCov : s.hTh, hecAbs, R.g.x, R.Tsurf.x, y.p.x, k.p.x, base);
+        // cover: the true d(tTop - tCovIn)/dt = k.p.x - N_w / 2 + gam w (rk_delta's movement limiter has the same expression)
+        const T ddT = cov ? k.p.x - T(0.5) * k.p.y + gam * y.p.y : k.p.x;
+        surface(cov || scr, cov ? 0 : 1, cov ? m.iCapCov : m.iCapThScr, cov ? m.cTopCov : s.hTh, hecAbs, R.g.x, R.Tsurf.x, y.p.x, ddT, base);
     }
     // y component: blackout screen (lane 2)
     {
@@ -303,46 +310,62 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                                               const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st)
 {
     using M = Math<T>;
-    const int n_win = (n_sub + WIN - 1) / WIN;
-    const T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WIN);
-    const T S = T(SC_SAFETY * 2.785), est_fac = T(1.0 / 6.0), hmin = hnom * T(1.0 / SC_MAX_REFINE);
-    const QTol<T> tol = gq_tol<T>(role);
-    const bool lane0 = role == 0, crop = role == 2;
-    QVec<T> y, xs, k, acc, est, dprev, dwin;
+    // the quad's windows: nominal count now, its own after the pre-pass (it == -1; rk_delta)
+    int n_win = (n_sub + WIN - 1) / WIN;
+    T hw = dt / T(n_win), hnom = hw / T(WIN);
+    int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
+    const T S = T(SC_SAFETY * 2.785), est_fac = T(1.0 / 6.0);
+    const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
+    const T gam = m.iCapCov * m.cCovCond, cw = cov ? T(0.5) : T(0);
+    QVec<T> y, xs, k, acc;
+    // increments over the previous window / at the start of this one of the SEVEN entries tier 2b reads from a lane (pair x, shared
+    // co2Air and tAir, the four "others"): ym of slow_coef
+    T dprev[7], dwin[7];
+    auto slow7 = [](const QVec<T>& v, T* o7) { o7[0] = v.p.x; o7[1] = v.sh[0]; o7[2] = v.sh[2]; for (int j = 0; j < 4; ++j) o7[3 + j] = v.o[j]; };
+    P2<T> estP = gq_sp<T>(T(0));          // comparison stage of the error estimate: the pair and the six shared states
+    T estS[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     auto zero = [](QVec<T>& v) { v.p = gq_sp<T>(T(0)); for (int i = 0; i < 6; ++i) v.sh[i] = T(0); for (int j = 0; j < 4; ++j) v.o[j] = T(0); };
-    zero(del); zero(dprev); zero(est); zero(dwin);
+    zero(del);
+    for (int j = 0; j < 7; ++j) { dprev[j] = T(0); dwin[j] = T(0); }
     int n_steps = 0, flags = 0, side_prev = 0;
     bool capped_prev = false;
-    T t_cap = T(0), h_last = hnom;
+    int n_cap = 0;                // windows taken at the refinement cap
+    T h_last = T(-1);             // length of the last sub-step taken = the one K.ec holds the coefficients of
+    // the pair's y component by the ETD formulas of rk_delta: the cover lane with a = 2 gam, every other lane with a = 0, for which the
+    // coefficients are those of classical RK4 -- one instruction stream for the four lanes
     // harvest: cLeaf = x23, cFruit = x25 live on lane 2 (o[1], o[3])
     auto harvest = [&](T hh) {
         const T a = harvest_flow(z0.o[1] + del.o[1], cr.cLeafMax, hh), b = harvest_flow(z0.o[3] + del.o[3], cr.cFruitMax, hh);
         del.o[1] += crop ? a : T(0); del.o[3] += crop ? b : T(0);
     };
-    harvest(hw2);
-    const int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     auto state_now = [&]() { y.p = z0.p + del.p; for (int i = 0; i < 6; ++i) y.sh[i] = z0.sh[i] + del.sh[i]; for (int j = 0; j < 4; ++j) y.o[j] = z0.o[j] + del.o[j]; };
+    // the cover lane's derivatives of (tTop - tCovIn, tCovE) from the integrator's (classical part of slot 5, N_w): rk_delta's movement limiter
+    auto true_rates = [&](const QVec<T>& kk, const QVec<T>& yy) {
+        QVec<T> r = kk;
+        const T c = T(0.5) * kk.p.y - gam * yy.p.y;
+        r.p = gq_mk<T>(cov ? kk.p.x - c : kk.p.x, cov ? (kk.sh[3] - kk.p.x) - c : kk.p.y);
+        return r;
+    };
     SlowCoef<T> q;
-    for (int it = 0; it <= n_win; ++it) {
-        flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
+    for (int it = -1; it <= n_win; ++it) {
+        flags |= (T(n_cap) * hw > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
         if (flags & SC_FLAG_CAP) break;
         // ---- window start: tier 2b at the predicted window midpoint; every lane evaluates it from the gathered inputs
         state_now();
         {
-            QVec<T> mid;
-            mid.p = y.p + gq_sp<T>(T(0.5)) * dprev.p;
-            for (int i = 0; i < 6; ++i) mid.sh[i] = y.sh[i] + T(0.5) * dprev.sh[i];
-            for (int j = 0; j < 4; ++j) mid.o[j] = y.o[j] + T(0.5) * dprev.o[j];
-            dwin = del;
+            T now7[7], mid[7];
+            slow7(y, now7);
+            for (int j = 0; j < 7; ++j) mid[j] = now7[j] + T(0.5) * dprev[j];
+            slow7(del, dwin);
             T ym[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) ym[i] = T(0);
-            ym[0] = mid.sh[0]; ym[2] = mid.sh[2];
-            ym[4] = gq_bcast<0>(mid.p.x); ym[21] = gq_bcast<0>(mid.o[0]); ym[26] = gq_bcast<0>(mid.o[1]); ym[10] = gq_bcast<0>(mid.o[2]);
-            ym[11] = gq_bcast<0>(mid.o[3]);
-            ym[8] = gq_bcast<1>(mid.p.x); ym[12] = gq_bcast<1>(mid.o[0]); ym[13] = gq_bcast<1>(mid.o[1]); ym[14] = gq_bcast<1>(mid.o[2]);
-            ym[19] = gq_bcast<1>(mid.o[3]);
-            ym[22] = gq_bcast<2>(mid.o[0]); ym[23] = gq_bcast<2>(mid.o[1]); ym[24] = gq_bcast<2>(mid.o[2]); ym[25] = gq_bcast<2>(mid.o[3]);
+            ym[0] = mid[1]; ym[2] = mid[2];
+            ym[4] = gq_bcast<0>(mid[0]); ym[21] = gq_bcast<0>(mid[3]); ym[26] = gq_bcast<0>(mid[4]); ym[10] = gq_bcast<0>(mid[5]);
+            ym[11] = gq_bcast<0>(mid[6]);
+            ym[8] = gq_bcast<1>(mid[0]); ym[12] = gq_bcast<1>(mid[3]); ym[13] = gq_bcast<1>(mid[4]); ym[14] = gq_bcast<1>(mid[5]);
+            ym[19] = gq_bcast<1>(mid[6]);
+            ym[22] = gq_bcast<2>(mid[3]); ym[23] = gq_bcast<2>(mid[4]); ym[24] = gq_bcast<2>(mid[5]); ym[25] = gq_bcast<2>(mid[6]);
             slow_coef<T>(ym, s, m, cr, q);
             gq_make_lane<T>(role, s, m, q, K);
         }
@@ -350,51 +373,72 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         QRates<T> R;
         GQ_FENCE(); gq_stage<T, true>(role, y, K, s, m, q, k, &R);
         int side = capped_prev ? 1 : 0;
-        const T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, hnom, &side);
+        const T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, (it < 0) ? T(0) : hnom, &side);
+        if (it < 0) {
+            // pre-pass (rk_delta): the environment's own number of windows from the rate bound at x0, then the leading harvest half step
+            const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
+            if (sc > T(1)) {
+                n_win = (int)ceil_pos(T(n_win) * sc - T(1e-9));
+                hw = dt / T(n_win); hnom = hw / T(WIN);
+                n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
+            }
+            harvest(T(0.5) * hw);
+            continue;
+        }
         flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
         side_prev = side;
         if (it > 0) {
             QVec<T> dif;
-            dif.p = est.p - k.p;
-            for (int i = 0; i < 6; ++i) dif.sh[i] = est.sh[i] - k.sh[i];
-            const T worst = gq_max(gq_fast_max(dif, tol.est));
+            dif.p = estP - k.p;
+            for (int i = 0; i < 6; ++i) dif.sh[i] = estS[i] - k.sh[i];
+            const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, gq_tol<T>(role).est.y * K.ec.w3)));     // (the ETD component's estimate carries f3)
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
             flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;
         }
         if (it == n_win) break;
         T hs = M::min(S * M::rcp(lam), hnom);
         {
-            const T mv = gq_max(gq_fast_max(k, tol.mov));
+            const T mv = gq_max(gq_fast_max(true_rates(k, y), gq_tol<T>(role).mov));
             hs = (mv * hs > T(SC_MOVE)) ? T(SC_MOVE) * M::rcp(mv) : hs;
         }
+        const T hmin = hnom * T(1.0 / SC_MAX_REFINE);
         const bool capped = !(hs >= hmin);
         hs = capped ? hmin : hs;
-        t_cap += capped ? hw : T(0);
+        n_cap += capped ? 1 : 0;
         capped_prev = capped;
         T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
         const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+        if (h != h_last) etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
         h_last = h;
-        // one classical RK4 sub-step from (y, k = f(y)); full update of the pair, the shared states and lane 0's / lane 3's
-        // first two "others" (tCan24, tCanSum | tIntLamp, time), constant rate for the rest
+        // one sub-step from (y, k = f(y)): classical RK4 on the pair's x component, the shared states and lane 0's / lane 3's first two
+        // "others" (tCan24, tCanSum | tIntLamp, time), ETD on the pair's y component (classical coefficients off the cover lane), the
+        // cover lane's x assembled from tTop, sigma and w (rk_delta), constant rate for the rest
         auto sub_step = [&]() {
-            auto fill = [&](T c) {
-                xs.p = y.p + gq_sp<T>(c) * k.p;
+            const T w0 = y.p.y, n1 = k.p.y;
+            T dWa, accW;
+            auto fill = [&](T c, T dW) {
+                xs.p = gq_mk<T>(y.p.x + c * k.p.x - cw * dW, w0 + dW);
                 for (int i = 0; i < 6; ++i) xs.sh[i] = y.sh[i] + c * k.sh[i];
                 xs.o[0] = y.o[0] + c * k.o[0]; xs.o[1] = y.o[1] + c * k.o[1]; xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
             };
-            acc = k; fill(h2);
+            auto accum = [&]() {
+                acc.p.x += T(2) * k.p.x;
+                for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
+                acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
+                accW += K.ec.f2d * k.p.y;
+            };
+            acc = k;
+            dWa = K.ec.e2m1 * w0 + K.ec.q * n1; accW = K.ec.f1 * n1;
+            fill(h2, dWa);
             GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
-            acc.p = acc.p + gq_sp<T>(T(2)) * k.p;
-            for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
-            acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
-            fill(h2);
+            accum();
+            fill(h2, K.ec.e2m1 * w0 + K.ec.q * k.p.y);
             GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
-            acc.p = acc.p + gq_sp<T>(T(2)) * k.p;
-            for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
-            acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
-            fill(h);
+            accum();
+            fill(h, K.ec.e2m1 * w0 + K.ec.e2 * dWa + K.ec.q * (T(2) * k.p.y - n1));
             GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
-            del.p = del.p + gq_sp<T>(h6) * (acc.p + k.p);
+            const T dW = K.ec.em1 * w0 + accW + K.ec.f3 * k.p.y;
+            del.p = gq_mk<T>(del.p.x + h6 * (acc.p.x + k.p.x) - cw * dW, del.p.y + dW);
             for (int i = 0; i < 6; ++i) del.sh[i] += h6 * (acc.sh[i] + k.sh[i]);
             const bool full01 = lane0 || role == 3;
             del.o[0] += full01 ? h6 * (acc.o[0] + k.o[0]) : h * k.o[0];
@@ -403,18 +447,20 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             ++n_steps;
         };
         sub_step();
-        est = k;
         for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
             state_now();
             GQ_FENCE(); gq_stage<T, false>(role, y, K, s, m, q, k, nullptr);
             sub_step();
-            est = k;
         }
+        estP = k.p;                                        // the last stage of the window's last sub-step
+        for (int i = 0; i < 6; ++i) estS[i] = k.sh[i];
         // ---- window end
-        dprev.p = del.p - dwin.p;
-        for (int i = 0; i < 6; ++i) dprev.sh[i] = del.sh[i] - dwin.sh[i];
-        for (int j = 0; j < 4; ++j) dprev.o[j] = del.o[j] - dwin.o[j];
-        harvest((it == n_win - 1) ? hw2 : hw);
+        {
+            T end7[7];
+            slow7(del, end7);
+            for (int j = 0; j < 7; ++j) dprev[j] = end7[j] - dwin[j];
+        }
+        harvest((it == n_win - 1) ? T(0.5) * hw : hw);
     }
     if (role == 3) del.o[1] = dt * T(1.0 / 86400.0);          // x27 = time [days]
     st.n_steps = n_steps;
@@ -424,7 +470,8 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
 // physical increments of the lane's fast states (for the agreement test of the guard) and finiteness
 template <class T> __device__ __forceinline__ void gq_phys_pair(int role, const QVec<T>& del, P2<T>& out)
 {
-    out = gq_mk<T>(role == 2 ? del.sh[2] - del.p.x : role == 3 ? del.sh[3] - del.p.x : del.p.x, role == 2 ? del.sh[2] - del.p.y : del.p.y);
+    const T dx = role == 2 ? del.sh[2] - del.p.x : role == 3 ? del.sh[3] - del.p.x : del.p.x;     // tThScr | tCovIn from the differences
+    out = gq_mk<T>(dx, role == 2 ? del.sh[2] - del.p.y : role == 3 ? dx - del.p.y : del.p.y);     // tBlScr | tCovE = tCovIn - w
 }
 
 // ---- the guard: rk4_delta_guarded of gl_model.hpp over the quad (same ladder, same acceptance rules) ---------------------------------
@@ -460,7 +507,9 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
         dif.p = now.p - prev.p;
         for (int i = 0; i < 6; ++i) dif.sh[i] = now.sh[i] - prev.sh[i];
         const T worst = gq_max(gq_fast_max(dif, tol.est));
-        ok = (clean && !verify) || (complete && have_prev && worst <= T(SC_AGREE)) || (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
+        const bool by_clean = clean && !verify, by_agree = complete && have_prev && worst <= T(SC_AGREE);
+        ok = by_clean || by_agree || (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
+        if (first_flags && ok && !by_clean) *first_flags |= by_agree ? ((st.flags != 0) ? 32 : 0) : 64;     // rk4_delta_guarded
         done = ok || attempt == SC_ATTEMPTS - 1;
         have_prev = complete;
         prev = now;

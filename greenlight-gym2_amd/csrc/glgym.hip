@@ -103,7 +103,7 @@ template <class T> struct StepArgsT {
     const int* w_off; int* timestep;
     const T* crop_p;
     int N;
-    T* reward; T* info; unsigned char* done; float* metrics;
+    T* reward; T* info; unsigned char* done; float* metrics; int* step_flags;
     T dt; int n_sub;
     T gasR, tCanMin;
     int nd;                     // weather row stride (10, or 14 with the measured-pipe columns of ODE_pipe)
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         a.timestep[b] = ts + 1;
         a.reward[b] = reward;
         a.done[b] = term ? 1 : 0;
+        if (a.step_flags) a.step_flags[b] = first_flags | (retries << 8) | (bad ? GLGYM_SF_FAILED : 0) | (min(extra_steps, 65535) << 16);
         if (a.info) {
             const T inf[GLGYM_NINFO] = {profit, gains, varc, rw.fixedCosts, co2c, heat, elec, viol[1], viol[0], viol[2], T(0)};
 #pragma unroll
@@ -377,7 +378,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
         x0.o[j] = X(ix);
     }
     z0 = x0;
-    z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x, role == 2 ? x0.sh[2] - x0.p.y : x0.p.y);
+    z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x,
+                    role == 2 ? x0.sh[2] - x0.p.y : role == 3 ? x0.p.x - x0.p.y : x0.p.y);      // cover lane: w = tCovIn - tCovE
     if (live && role == 0) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
@@ -386,20 +388,41 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     int extra_steps, first_flags = 0;
     const int retries = rk4_delta_guarded_quad<T, RK4_WINDOW<T>::value, LDSQ>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps,
                                                                              a.verify != 0, &first_flags);
-    // ---- new state: physical increments of what the lane owns
+    // ---- new state: physical increments of what the lane owns.  Nothing but the integrator's own state is kept live across the
+    // integrator (the fp64 build is at its register limit there): the old state and the applied control are read again
     P2<T> dP;
     gq_phys_pair<T>(role, del, dP);
+    asm volatile("" ::: "memory");
+    // (opaque copies of the env indices: the address arithmetic of the epilogue is redone here instead of being carried -- as spilled
+    // 64-bit pointers -- across the integrator)
+    int gl2 = blockIdx.x * WAVE + threadIdx.x;
+    asm volatile("" : "+v"(gl2));
+    const int role2 = gl2 & 3, b2 = gl2 >> 2;
+    const bool live2 = b2 < a.B;
+    const int bb2 = live2 ? b2 : a.B - 1;
+    const int ts2 = a.timestep[bb2];
+    auto X2 = [&](int i) { return a.x[(size_t)i * a.ld + bb2]; };
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x0.sh[i] = X2(gq_sh_ix(i));
+    x0.p = gq_mk<T>(X2(role2 == 0 ? 4 : role2 == 1 ? 8 : role2 == 2 ? 7 : 5), X2(role2 == 0 ? 9 : role2 == 1 ? 17 : role2 == 2 ? 20 : 6));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ix = role2 == 0 ? gq_other_ix(0, j) : role2 == 1 ? gq_other_ix(1, j) : role2 == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1);
+        x0.o[j] = X2(ix);
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) u[j] = a.u[(size_t)j * a.ld + bb2];       // (written above by lane 0 of the quad)
     QVec<T> x1;
     x1.p = gq_mk<T>(bad ? x0.p.x : x0.p.x + dP.x, bad ? x0.p.y : x0.p.y + dP.y);
 #pragma unroll
     for (int i = 0; i < 6; ++i) x1.sh[i] = bad ? x0.sh[i] : x0.sh[i] + del.sh[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) x1.o[j] = bad ? x0.o[j] : x0.o[j] + del.o[j];
-    if (role == 3) {    // x27 = time [days since reset]: exact from the step counter (step_kernel)
+    if (role2 == 3) {    // x27 = time [days since reset]: exact from the step counter (step_kernel)
         const double per_step = (double)a.dt / 86400.0;
-        double t_start = (double)x0.o[1] - (double)ts * per_step;
+        double t_start = (double)x0.o[1] - (double)ts2 * per_step;
         if (fabs(t_start) < 5e-4) t_start = 0.0;
-        if (!bad) x1.o[1] = T(t_start + ((double)ts + 1.0) * per_step);
+        if (!bad) x1.o[1] = T(t_start + ((double)ts2 + 1.0) * per_step);
     }
     const T dFruit = gq_bcast<2>(del.o[3]);                 // cFruit lives on lane 2
     // ---- reward epilogue (step_kernel): every lane has what it needs, lane 0 writes
@@ -417,29 +440,30 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     const T gains = (bad ? T(0) : dFruit) * rw.gainK;
     const T profit = gains - varc;
     const T reward = (profit - rw.minProfit) * rw.invRange - pen;
-    const bool term = bad || (ts >= a.N);
-    if (live) {
-        auto W = [&](int i, T v) { a.x[(size_t)i * a.ld + b] = v; };
-        W(role == 0 ? 4 : role == 1 ? 8 : role == 2 ? 7 : 5, x1.p.x);
-        W(role == 0 ? 9 : role == 1 ? 17 : role == 2 ? 20 : 6, x1.p.y);
+    const bool term = bad || (ts2 >= a.N);
+    if (live2) {
+        auto W = [&](int i, T v) { a.x[(size_t)i * a.ld + b2] = v; };
+        W(role2 == 0 ? 4 : role2 == 1 ? 8 : role2 == 2 ? 7 : 5, x1.p.x);
+        W(role2 == 0 ? 9 : role2 == 1 ? 17 : role2 == 2 ? 20 : 6, x1.p.y);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (role != 3 || j < 2) W(role == 0 ? gq_other_ix(0, j) : role == 1 ? gq_other_ix(1, j) : role == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1), x1.o[j]);
-        if (role == 0) {
+            if (role2 != 3 || j < 2) W(role2 == 0 ? gq_other_ix(0, j) : role2 == 1 ? gq_other_ix(1, j) : role2 == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1), x1.o[j]);
+        if (role2 == 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) W(gq_sh_ix(i), x1.sh[i]);
-            a.timestep[b] = ts + 1;
-            a.reward[b] = reward;
-            a.done[b] = term ? 1 : 0;
+            a.timestep[b2] = ts2 + 1;
+            a.reward[b2] = reward;
+            a.done[b2] = term ? 1 : 0;
+            if (a.step_flags) a.step_flags[b2] = first_flags | (retries << 8) | (bad ? GLGYM_SF_FAILED : 0) | (min(extra_steps, 65535) << 16);
             if (a.info) {
                 const T inf[GLGYM_NINFO] = {profit, gains, varc, rw.fixedCosts, co2c, heat, elec, viol[1], viol[0], viol[2], T(0)};
 #pragma unroll
-                for (int i = 0; i < GLGYM_NINFO; ++i) a.info[(size_t)i * a.ld + b] = inf[i];
+                for (int i = 0; i < GLGYM_NINFO; ++i) a.info[(size_t)i * a.ld + b2] = inf[i];
             }
         }
     }
     if (a.metrics) {
-        const bool cnt = live && role == 0;
+        const bool cnt = live2 && role2 == 0;
         const float w = cnt ? 1.f : 0.f;
         float mv[GLGYM_NMETRIC] = {w * (float)reward, w * (float)profit, (cnt && term) ? 1.f : 0.f,
                                    (cnt && bad) ? 1.f : 0.f, w * (float)viol[0], w * (float)viol[1],
@@ -1382,7 +1406,7 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     k.x = (T*)a->x; k.u = (T*)a->u; k.action = a->action; k.control = (const T*)a->control;
     k.weather = (const T*)a->weather; k.weather_rows = a->weather_rows;
     k.w_off = a->w_off; k.timestep = a->timestep; k.crop_p = (const T*)a->crop_p; k.N = a->N;
-    k.reward = (T*)a->reward; k.info = (T*)a->info; k.done = a->done; k.metrics = a->metrics;
+    k.reward = (T*)a->reward; k.info = (T*)a->info; k.done = a->done; k.metrics = a->metrics; k.step_flags = a->step_flags;
     k.dt = T(h->dt); k.n_sub = h->n_sub; k.gasR = T(h->p[39]); k.tCanMin = T(h->p[162]); k.nd = h->nd;
     k.du = h->du;
     for (int j = 0; j < NU; ++j) { k.u_min[j] = h->u_min[j]; k.u_max[j] = h->u_max[j]; }
@@ -1429,8 +1453,8 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // The two-waves-per-SIMD build (256 registers + scratch) is taken on request only (GLGYM_OCC=2).  Round 2 measured it 4 % ahead
     // at B = 262 144; with round 3's integrator (wet surfaces as differences, closing evaluation, four-attempt ladder) it spills
     // more and runs 0.70x the one-wave build at every batch size (profiles/r03_occupancy2_plain.txt).
-    static const int occ_env = [] { const char* e = std::getenv("GLGYM_OCC"); return e ? std::atoi(e) : 0; }();
-    const bool occ2 = def && !a->crop_p && occ_env == 2;
+    const char* oe_ = std::getenv("GLGYM_OCC");               // read per launch, like GLGYM_LAYOUT (tests switch it between steps)
+    const bool occ2 = def && !a->crop_p && oe_ && std::atoi(oe_) == 2;
     if (h->scheme == GLGYM_SCHEME_RK2) launch_step_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, grid, block, st, def, occ2);
     else if (h->scheme == GLGYM_SCHEME_RK3) launch_step_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, grid, block, st, def, occ2);
     else launch_step_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, grid, block, st, def, occ2);

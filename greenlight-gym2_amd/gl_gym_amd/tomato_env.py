@@ -118,8 +118,9 @@ class LazyInfos:
     """List-like view of the per-env info dicts (SB3: ``infos[i]``).  Dicts are built on first access and cached, so
     wrappers that only touch finished envs (VecMonitor, VecNormalize) cost O(#done), not O(B), per step."""
 
-    def __init__(self, keys, info_rows, controls, dones, term_obs):
+    def __init__(self, keys, info_rows, controls, dones, term_obs, step_flags=None):
         self._keys, self._rows, self._ctrl, self._dones, self._term = keys, info_rows, controls, dones, term_obs
+        self._flags = step_flags
         self._cache = {}
 
     def __len__(self):
@@ -129,6 +130,8 @@ class LazyInfos:
         d = dict(zip(self._keys, self._rows[b].tolist()))
         d["controls"] = self._ctrl[b]
         d["TimeLimit.truncated"] = False
+        if self._flags is not None:
+            d["integration"] = int(self._flags[b])        # GLGYM_SF_* word: 0 = first attempt accepted as it stood
         if self._term is not None and self._dones[b]:
             d["terminal_observation"] = self._term[b]
         return d
@@ -162,7 +165,7 @@ class TomatoVecEnv:
                  u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
-        scheme / n_sub: "rk4" (classical RK4, default n_sub 320), "rk3" (Bogacki-Shampine, 354) or "rk2" (explicit midpoint, 376);
+        scheme / n_sub: "rk4" (RK4 with the cover conduction integrated exactly, default n_sub 240), "rk3" (Bogacki-Shampine, 354) or "rk2" (explicit midpoint, 376);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
@@ -269,6 +272,9 @@ class TomatoVecEnv:
         self.obs_t = z(self.B, self.obs_dim, dtype=torch.float32)
         self.term_obs_t = z(self.B, self.obs_dim, dtype=torch.float32)
         self.metrics_t = z(L.METRIC_REPLICAS, L.METRIC_STRIDE, dtype=torch.float32) if collect_metrics else None
+        # how each env-step's integration went (include/glgym.h GLGYM_SF_*: first-attempt flags, extra attempts, and whether the
+        # result was accepted by agreement on a flagged attempt / as the finest attempt alone / not at all); infos["integration"]
+        self.step_flags_t = z(self.B, dtype=torch.int32)
         self.crop_T = z(L.NCROP, self.ld) if self.uncertainty_scale > 0 else None
         self._start_rows_t = torch.as_tensor(self.start_rows, dtype=torch.int32, device=dev)
         self._start_days_t = torch.as_tensor(self.start_days, dtype=torch.float32, device=dev)
@@ -331,7 +337,7 @@ class TomatoVecEnv:
                        self.w_off_t.data_ptr(), self.timestep_t.data_ptr(),
                        self.crop_T.data_ptr() if self.crop_T is not None else None, self.N,
                        self.reward_t.data_ptr(), self.info_T.data_ptr(), self.done_t.data_ptr(),
-                       self.metrics_t.data_ptr() if self.metrics_t is not None else None)
+                       self.metrics_t.data_ptr() if self.metrics_t is not None else None, self.step_flags_t.data_ptr())
         L.check(self._lib.glgym_step(self._h, C.byref(a), self._stream()), "glgym_step")
 
     # ---- tensor interface (no host synchronisation) ---------------------------------------------
@@ -424,12 +430,14 @@ class TomatoVecEnv:
         term = None
         if self.auto_reset and dones.any():
             term = self.term_obs_t.cpu().numpy() if term_obs is None else term_obs
+        flags = self.step_flags_t.cpu().numpy()
         if self.lazy_infos:
-            infos = LazyInfos(L.INFO_KEYS, rows, ctrl, dones, term)
+            infos = LazyInfos(L.INFO_KEYS, rows, ctrl, dones, term, flags)
         else:
             infos = [dict(zip(L.INFO_KEYS, row), controls=c) for row, c in zip(rows.tolist(), ctrl)]
-            for d in infos:
+            for d, f in zip(infos, flags.tolist()):
                 d["TimeLimit.truncated"] = False
+                d["integration"] = f          # GLGYM_SF_* word: 0 = first attempt accepted as it stood
             if term is not None:
                 for b in np.nonzero(dones)[0]:
                     infos[b]["terminal_observation"] = term[b]

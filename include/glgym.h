@@ -69,7 +69,7 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
 /* Sub-stepping scheme of glgym_step / glgym_evalF (greenlight_model.cpp:46-63 uses CVODES BDF, error-controlled and
  * implicit; any scheme that meets the accuracy bar against it is admissible).  n_sub is the NOMINAL (= minimum) number
  * of sub-steps per env-step.  Both schemes are stability-controlled per environment: a bound on the fastest local
- * relaxation rate (cover pair 0.67-0.72 1/s; top-compartment exchange up to 1.1 1/s in storms; a wet screen pinned to
+ * relaxation rate (cover pair 0.67-0.72 1/s -- RK2 / RK3 only; top-compartment exchange up to 1.1 1/s in storms; a wet screen pinned to
  * the air temperature 3 ... 15 1/s) is evaluated once per window of 1-4 nominal sub-steps and the environment takes as
  * many smaller sub-steps in that window as its scheme's stability interval asks for; an embedded error estimate is the
  * safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 64x the nominal count for more than 120 s,
@@ -77,9 +77,13 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  * the env-step is redone with 2x, 4x, 8x n_sub until an attempt is clean or two consecutive attempts agree on the fast states
  * (step doubling; counted in GLGYM_NMETRIC).  An environment for which no two attempts agree is reported like a failed CVODES
  * call in the reference (tomato_env.py:119-123): done = 1, state unchanged (glgym_step) / GLGYM_EODE (glgym_evalF).
- *   GLGYM_SCHEME_RK4: classical RK4 (stability interval 2.785): n_sub >= 224 at dt = 900; use n_sub 320 (nominal lanes
- *     then cover rates up to 0.91 1/s without refinement).  The slow sub-expressions and the harvest flow are evaluated
- *     once per nominal sub-step in fp64, once per two in fp32 (n_sub is then rounded up to even).
+ *   GLGYM_SCHEME_RK4: RK4 (stability interval 2.785) with the one fast LINEAR mode of the model taken out of it: the conduction
+ *     between the two faces of the cover glass (hCovInCovE, aux_states.hpp:918 / ode.hpp:37-42; 0.65 1/s, state-independent) is
+ *     integrated exactly -- Cox-Matthews' exponential RK4 on w = tCovIn - tCovE, classical RK4 on every other state.  The
+ *     nominal sub-step is then set by the top compartment's air exchange: use n_sub 240 (nominal environments cover rates up to
+ *     0.68 1/s).  An environment whose rate bound at the start of the env-step asks for a shorter sub-step gets proportionally
+ *     more windows (up to 2x); what changes during the env-step is followed window by window.  The slow sub-expressions and the
+ *     harvest flow are evaluated once per window of two nominal sub-steps in both precisions (n_sub is rounded up to even).
  *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 376.  Same stability margin with 30 % fewer
  *     right-hand sides; the slow sub-expressions and the harvest flow are shared by four nominal sub-steps (n_sub is
  *     rounded up to a multiple of 4).  Second order: 1e-4 one-step errors occur after abrupt control changes.
@@ -136,7 +140,19 @@ typedef struct {
     float* metrics;            /* [GLGYM_METRIC_REPLICAS][GLGYM_METRIC_STRIDE] f32 accumulators or NULL: wavefront w adds
                                   its sums (GLGYM_NMETRIC order) to replica w % GLGYM_METRIC_REPLICAS; the reader sums the
                                   replicas */
+    int32_t* step_flags;       /* [B] out or NULL: how this env-step's integration went (the reference has no counterpart:
+                                  CVODES either returns or throws, greenlight_model.cpp:110) -- GLGYM_SF_* bits below */
 } glgym_step_args;
+
+/* step_flags[b]: bits 0..4 = why the FIRST attempt was not accepted as it stood (0 = it was): 1 rate bound beyond 64x the nominal
+ * sub-step count for more than 120 s, 2 non-finite, 4 error estimate above tolerance, 8 a wet surface changed sides inside its
+ * bistable regime in a capped window, 16 it took >= 3x the nominal number of sub-steps.  Bits 8..10 = extra attempts used
+ * (2x, 4x, 8x n_sub).  Bits 16..31 = sub-steps taken beyond the nominal n_sub, all attempts together (saturating).  How the returned
+ * state was accepted: */
+#define GLGYM_SF_ACCEPT_AGREE_FLAGGED 32   /* two consecutive attempts agreed, but the accepted (finer) one carried a flag itself */
+#define GLGYM_SF_ACCEPT_LAST_ALONE 64      /* the finest attempt (8x n_sub), unflagged, taken as it stood although it did not agree
+                                              with the attempt before it -- in verified mode as well */
+#define GLGYM_SF_FAILED 128                /* failed integration: done = 1, state unchanged */
 
 /* Device-pointer arguments of observation assembly (row-major output, what SB3 / Gymnasium consume). */
 typedef struct {

@@ -663,7 +663,11 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
     dx[21] = (1.0 / 86400.0) * (xs[4] - xs[21]);
 }
 
-/* order = 4 classical RK4, 3 Bogacki-Shampine's third-order method, 2 explicit midpoint.  window = number of consecutive sub-steps that
+extern int gl_sc_exp;
+static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
+                            int pipe, double h, int em, double *est, double *est_ar, double *est_w);
+/* order = 4 RK4 (with the cover pair's conduction integrated exactly: gl_sc_exp, rk4_exp_substep below), 3 Bogacki-Shampine's
+ * third-order method, 2 explicit midpoint.  window = number of consecutive sub-steps that
  * share one tier-2b evaluation and one harvest half-step pair (1 = every sub-step). */
 static void rk_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                            double *x1, int pipe, int order, int window)
@@ -682,7 +686,10 @@ static void rk_lagged_impl(const double *x0, const double *u, const double *d, c
             for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];   /* predicted middle of the window */
             memcpy(xw, x, sizeof xw);
         }
-        if (order == 4) {
+        if (order == 4 && gl_sc_exp) {
+            rhs_lagged(x, ym, u, d, p, k1, pipe);
+            rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, gl_sc_exp, NULL, NULL, NULL);
+        } else if (order == 4) {
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
             rhs_lagged(xs, ym, u, d, p, k2, pipe);
@@ -770,7 +777,8 @@ void gl_oracle_rk4_lagged_pipe(const double *x0, const double *u, const double *
  * ---------------------------------------------------------------------------------- */
 #define SC_SAFETY 0.92
 #define SC_MAX_REFINE 64.0
-#define SC_MOVE 32.0
+double gl_sc_move = 8.0;
+#define SC_MOVE gl_sc_move
 #define SC_CAP_S 120.0       /* a rate beyond the cap may last this long within one env-step before the lane is failed */
 #define SC_GRACE_S 60.0      /* after a control jump the fast states legitimately move by K within seconds: */
 #define SC_GRACE_MUL 64.0    /* looser estimate tolerance during the first SC_GRACE_S of the env-step */
@@ -787,6 +795,49 @@ static double kz(const double *k, int i)
 }
 
 static double dsat_vp(double t) { return sat_vp(t) * 17.2694 * 238.3 / ((t + 238.3) * (t + 238.3)); }
+
+/* ------------------------------------------------------------------------------------
+ * Round 4: EXPONENTIAL treatment of the fastest constant-rate mode (gl_model.hpp rk_delta, "COVEXP").
+ * The two faces of the glass exchange heat by conduction, hCovInCovE = cCov (tCovIn - tCovE) (aux_states.hpp:918,
+ * ode.hpp:37-42): in the coordinates  sigma = tCovIn + tCovE,  w = tCovIn - tCovE  that is the linear term
+ * dw/dt = -2 cCov / capCov * w  (0.65 1/s, state-independent) and nothing in d sigma/dt.  It is the one mode that keeps
+ * classical RK4 at >= 224 sub-steps per 900 s on calm weather.  gl_sc_exp bit 1 integrates it exactly (Cox-Matthews
+ * ETDRK4 on the w component, classical RK4 on everything else -- for rate 0 the ETD coefficients ARE the classical ones);
+ * bits 2 / 4 (studies only) do the same for the lamp's convective exchange and for the top compartment's air exchange
+ * rate (state dependent, frozen per sub-step).
+ * ---------------------------------------------------------------------------------- */
+int gl_sc_exp = 1;
+int gl_sc_prescale = 1;
+#define SC_PRE_MARGIN 1.02
+#define SC_PRE_MAX 2.0
+/* E = e^z, E2 = e^(z/2), Q = (h/2) phi1(z/2), f1 = h (phi1 - 3 phi2 + 4 phi3), f2 = h (phi2 - 2 phi3), f3 = h (4 phi3 - phi2)
+ * at z = -a h;  phi3 by its Taylor series (no cancellation), phi2, phi1, e^z by the recurrence phi_{k-1} = z phi_k + 1/(k-1)! */
+static void etd_coefs(double a, double h, double *c)
+{
+    double z = -a * h, ph[2][4];
+    for (int half = 0; half < 2; ++half) {
+        const double zz = half ? 0.5 * z : z;
+        if (zz > -3.0) {
+            double t = 1.0 / 6.0, p3 = t;
+            for (int j = 1; j < 40; ++j) { t *= zz / (double)(j + 3); p3 += t; }
+            ph[half][3] = p3;
+            ph[half][2] = zz * p3 + 0.5;
+            ph[half][1] = zz * ph[half][2] + 1.0;
+            ph[half][0] = zz * ph[half][1] + 1.0;
+        } else {
+            ph[half][0] = exp(zz);
+            ph[half][1] = (ph[half][0] - 1.0) / zz;
+            ph[half][2] = (ph[half][1] - 1.0) / zz;
+            ph[half][3] = (ph[half][2] - 0.5) / zz;
+        }
+    }
+    c[0] = ph[0][0];                                       /* E  */
+    c[1] = ph[1][0];                                       /* E2 */
+    c[2] = 0.5 * h * ph[1][1];                             /* Q  */
+    c[3] = h * (ph[0][1] - 3.0 * ph[0][2] + 4.0 * ph[0][3]);   /* f1 */
+    c[4] = h * (ph[0][2] - 2.0 * ph[0][3]);                /* f2: weight of EACH of N(a), N(b) is 2 f2 */
+    c[5] = h * (4.0 * ph[0][3] - ph[0][2]);                /* f3 */
+}
 
 /* Upper bound on the fastest relaxation rate [1/s] of the ODE at state x (negative real spectrum; validated against the
  * finite-difference Jacobian on tests/golden/step_tight_storm.npz: 1.00 ... 1.25 x lambda_max).  dx = the right-hand side at
@@ -834,7 +885,7 @@ static double sc_pinned(double iCap, double hcoef, double hec, double g, double 
 }
 
 static double rate_bound_impl(const double *x, const double *u, const double *d, const double *p, const double *dx,
-                              double h_nominal, int *sides, double *Gs)
+                              double h_nominal, int *sides, double *Gs, int em)
 {
     double a[GL_NAUX];
     gl_oracle_aux(x, u, d, p, a);
@@ -870,20 +921,25 @@ static double rate_bound_impl(const double *x, const double *u, const double *d,
     const double kCapVpTop = p[39] / (p[38] * (p[49] - p[48])), iCapTh = 1.0 / p[119], iCapBl = 1.0 / p[121];
     const double cCov = fabs(1.0 / (p[73] / p[71]));
     const double covOutK = fabs(p[47] / p[46] * (p[51] + p[52] * pow(d[4], p[53])));
-    const double r1 = iCapCo2Top * (fScr + fRoof);
-    const double r3 = iCapTop * (rhoCp * (fRoof + (5.0 / 3.0) * fScr) + f43 * (hecTopCov + hecThTop + hecBlTop));
-    const double r16 = kCapVpTop * (0.002165 * (fScr + fRoof) + (tTop + C2K) * 6.4e-9 * hecTopCov * 1.1);
-    const double row6 = iCapCov * (2.0 * cCov + covOutK + firCovE);
+    /* gl_sc_exp bit 1: the conduction between the cover's faces is integrated exactly and leaves both of its rows (in the
+     * coordinates (sigma, w) the remaining block is symmetric with the two faces' own exchange rates as eigenvalues) */
+    const double cCovB = (em & 1) ? 0.0 : cCov;
+    const double topx = (em & 4) ? 0.0 : 1.0;       /* study: top-compartment air exchange integrated exponentially */
+    const double r1 = iCapCo2Top * (fScr + fRoof) * topx;
+    const double r3 = iCapTop * (rhoCp * (topx * fRoof + (topx + 2.0 / 3.0) * fScr) + f43 * (hecTopCov + hecThTop + hecBlTop));
+    const double r16 = kCapVpTop * (0.002165 * (fScr + fRoof) * topx + (tTop + C2K) * 6.4e-9 * hecTopCov * 1.1);
+    const double row6 = iCapCov * (2.0 * cCovB + covOutK + firCovE);
     const double dvCov = vpTop - sat_vp(tCovIn), dvTh = vpAir - sat_vp(tTh), dvBl = vpAir - sat_vp(tBl);
     const double gCov = dvCov / (1.0 + exp(-0.1 * dvCov)), gTh = dvTh / (1.0 + exp(-0.1 * dvTh)), gBl = dvBl / (1.0 + exp(-0.1 * dvBl));
-    const double base5 = 2.0 * cCov + LK * hecTopCov * 1.1 * dsat_vp(tCovIn) + firCovIn;
+    const double base5 = 2.0 * cCovB + LK * hecTopCov * 1.1 * dsat_vp(tCovIn) + firCovIn;
     const double base7 = f43 * hecThTop + LK * hecATh * 1.1 * dsat_vp(tTh) + firTh;
     const double base20 = f43 * hecBlTop + LK * hecABl * 1.1 * dsat_vp(tBl) + firBl;
     int s5 = 0, s7 = 0, s20 = 0;
+    const double hn_ = (em & 8) ? 0.0 : h_nominal;      /* em bit 8: smooth slopes only (nominal sub-step 0: nothing is 'harmful') */
     double G5[2] = {0, 0}, G7[2] = {0, 0}, G20[2] = {0, 0};
-    const double row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, h_nominal, &s5, G5);
-    const double r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, h_nominal, &s7, G7);
-    const double r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, h_nominal, &s20, G20);
+    const double row5 = sc_pinned(iCapCov, cTopCov, hecTopCov, gCov, dTopCov, dx[3] - dx[5], base5, LK, tCovIn, hn_, &s5, G5);
+    const double r7 = sc_pinned(iCapTh, 1.7 * uTh, hecATh, gTh, dATh, dx[2] - dx[7], base7, LK, tTh, hn_, &s7, G7);
+    const double r20 = sc_pinned(iCapBl, 1.7 * uBl, hecABl, gBl, dABl, dx[2] - dx[20], base20, LK, tBl, hn_, &s20, G20);
     double r = fmax(fmax(r1, r3), fmax(r16, row6));
     r = fmax(fmax(r, row5), fmax(r7, r20));
     if (sides) { sides[0] = s5; sides[1] = s7; sides[2] = s20; }
@@ -894,7 +950,7 @@ static double rate_bound_impl(const double *x, const double *u, const double *d,
 double gl_rate_bound_dx(const double *x, const double *u, const double *d, const double *p, const double *dx,
                         double h_nominal)
 {
-    return rate_bound_impl(x, u, d, p, dx, h_nominal, NULL, NULL);
+    return rate_bound_impl(x, u, d, p, dx, h_nominal, NULL, NULL, 0);
 }
 
 /* convenience: the bound with the second pass always on (lam_nominal = 0) and dx evaluated here */
@@ -905,6 +961,55 @@ double gl_rate_bound(const double *x, const double *u, const double *d, const do
     return gl_rate_bound_dx(x, u, d, p, dx, 1e6);      /* huge nominal sub-step: every wet surface counts as harmful */
 }
 
+/* native (tCovIn, tCovE) <-> (sigma, w); N(y) = f(y) + a y in those coordinates */
+#define TO_Y(v, o) do { memcpy(o, v, sizeof(double) * GL_NX); if (em & 1) { o[5] = v[5] + v[6]; o[6] = v[5] - v[6]; } } while (0)
+#define TO_X(v, o) do { memcpy(o, v, sizeof(double) * GL_NX); if (em & 1) { o[5] = 0.5 * (v[5] + v[6]); o[6] = 0.5 * (v[5] - v[6]); } } while (0)
+#define NONLIN(kk, yy, NN) do { double f_[GL_NX]; TO_Y(kk, f_); for (int i = 0; i < GL_NX; ++i) NN[i] = f_[i] + ar[i] * yy[i]; } while (0)
+/* One RK4 sub-step with the exponential part (em: gl_sc_exp bits), in place on x; k1 = the right-hand side at x (rhs_lagged).
+ * Cox-Matthews ETDRK4 with a diagonal linear part -a_i y_i in the coordinates y = (..., sigma, w, ...):
+ *   a = E2 y + Q N(y),  b = E2 y + Q N(a),  c = E2 a + Q (2 N(b) - N(y)),
+ *   y+ = E y + f1 N(y) + 2 f2 (N(a) + N(b)) + f3 N(c),      N(y) = f(y) + a y.
+ * For a_i = 0: E = E2 = 1, Q = h/2, f1 = f2 = f3 = h/6 -- classical RK4 (stage c from y + h N(b)).
+ * est / est_ar / est_w (optional): the comparison stage N(c) of the nine fast states in the integrator's coordinates
+ * (slot 5: tTop - sigma / 2, slot 6: w), the rates used, and the weights f3_i / (h / 6) of the embedded error estimate
+ * e_i = f3_i |N(c)_i - N(y+)_i|. */
+static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
+                            int pipe, double h, int em, double *est, double *est_ar, double *est_w)
+{
+    double ar[GL_NX] = {0}, C[GL_NX][6], y0[GL_NX], ya[GL_NX], N1[GL_NX], Na[GL_NX], Nb[GL_NX], Nc[GL_NX];
+    double k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], yy[GL_NX];
+    if (em & 1) ar[6] = 2.0 * fabs(1.0 / (p[73] / p[71])) / (0.1 * cos(p[45] * PI_ / 180.0) * p[73] * p[64] * p[72]);
+    if (em & 2) ar[17] = fabs(p[185]) / p[184];
+    if (em & 4) {
+        double aa[GL_NAUX];
+        gl_oracle_aux(x, u, d, p, aa);
+        const double rt = (fabs(aa[136]) + fabs(aa[144])) / (p[49] - p[48]);
+        ar[1] = ar[3] = ar[16] = rt;
+    }
+    for (int i = 0; i < GL_NX; ++i) etd_coefs(ar[i], h, C[i]);
+    TO_Y(x, y0);
+    NONLIN(k1, y0, N1);
+    for (int i = 0; i < GL_NX; ++i) ya[i] = C[i][1] * y0[i] + C[i][2] * N1[i];
+    TO_X(ya, xs); rhs_lagged(xs, ym, u, d, p, k2, pipe); NONLIN(k2, ya, Na);
+    for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][1] * y0[i] + C[i][2] * Na[i];
+    TO_X(yy, xs); rhs_lagged(xs, ym, u, d, p, k3, pipe); NONLIN(k3, yy, Nb);
+    for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][1] * ya[i] + C[i][2] * (2.0 * Nb[i] - N1[i]);
+    TO_X(yy, xs); rhs_lagged(xs, ym, u, d, p, k4, pipe); NONLIN(k4, yy, Nc);
+    for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][3] * N1[i] + 2.0 * C[i][4] * (Na[i] + Nb[i]) + C[i][5] * Nc[i];
+    TO_X(yy, x);
+    if (est) {
+        double kc[GL_NX];
+        memcpy(kc, Nc, sizeof kc);
+        if (em & 1) kc[5] = 0.5 * Nc[5];         /* slot 5 = tTop - sigma / 2 (its classical part); slot 6 = w */
+        for (int j = 0; j < 9; ++j) {
+            const int i = SC_FAST[j];
+            est[j] = (i == 5) ? kc[3] - kc[5] : (i == 7) ? kc[2] - kc[7] : (i == 20) ? kc[2] - kc[20] : kc[i];
+        }
+        memcpy(est_ar, ar, sizeof ar);
+        for (int j = 0; j < 9; ++j) est_w[j] = C[SC_FAST[j]][5] / (h / 6.0);
+    }
+}
+
 /* stats: [0] sub-steps taken, [1] max error-estimate ratio (after the grace scaling), [2] max rate bound, [3] flags
  * (1 rate beyond the refinement cap for more than SC_CAP_S, 2 non-finite, 4 error estimate above tolerance, 8 a wet surface
  * jumped to the other branch) */
@@ -912,15 +1017,29 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                        double *x1, int pipe, int order, int window, double *stats)
 {
     double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX];
-    double est[9] = {0};
-    const int n_win = (n_sub + window - 1) / window;
-    const double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
+    double est[9] = {0}, est_w[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, est_ar[GL_NX] = {0};
     const double S = SC_SAFETY * (order == 4 ? 2.785 : order == 3 ? 2.5127 : 2.0);
     const double est_fac = order == 3 ? 1.0 / 8.0 : 1.0 / 6.0;
+    const int em = (order == 4) ? gl_sc_exp : 0;      /* what is integrated exponentially (RK4 only) */
+    int n_win = (n_sub + window - 1) / window;
+    memcpy(x, x0, sizeof x);
+    if (gl_sc_prescale) {
+        /* Round 4: the environment's OWN number of windows.  n_sub is the nominal (= minimum) count; an environment whose rate
+         * bound at the start of the env-step asks for a shorter sub-step gets proportionally more windows (at most SC_PRE_MAX x),
+         * so that it runs with `window` equal sub-steps per window like everybody else instead of window + 1 longer ones: a
+         * rate 5 % over the nominal limit costs 5 % more stages, not 50 %.  What changes during the env-step is still followed
+         * window by window below. */
+        const double hn0 = dt / (double)(n_win * window);
+        rhs_lagged(x, x, u, d, p, k1, pipe);
+        double lam0 = rate_bound_impl(x, u, d, p, k1, hn0, NULL, NULL, em | 8);
+        if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam0 = fmax(lam0, 1.0);
+        const double sc = fmin(SC_PRE_MARGIN * lam0 * hn0 / S, SC_PRE_MAX);
+        if (sc > 1.0) n_win = (int)ceil((double)n_win * sc - 1e-9);          /* NaN: unchanged */
+    }
+    const double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
     double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0, h_last = hnom;
     int flags = 0;
     const int n_grace = (int)ceil(SC_GRACE_S / hw);
-    memcpy(x, x0, sizeof x);
     memset(dprev, 0, sizeof dprev);
     x[23] = harvest_flow_ref(x[23], p[144], 0.5 * hw);
     x[25] = harvest_flow_ref(x[25], p[145], 0.5 * hw);
@@ -936,7 +1055,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         rhs_lagged(x, ym, u, d, p, k1, pipe);
         int side[3];
         double Gs[6];
-        double lam = rate_bound_impl(x, u, d, p, k1, hnom, side, Gs);
+        double lam = rate_bound_impl(x, u, d, p, k1, hnom, side, Gs, em);
         if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
         if (lam > lmax) lmax = lam;
         /* branch invariant (sc_pinned): a wet surface that was below its air node at the last look and now sits above it in
@@ -952,6 +1071,19 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         }
         if (it > 0) {
             double worst = 0.0;
+            if (em) {
+                /* N1' = f(y+) + a y+ with the rates of the sub-step just taken, in the coordinates of est[] */
+                double y1[GL_NX], f1y[GL_NX], Nn[GL_NX];
+                TO_Y(x, y1); TO_Y(k1, f1y);
+                for (int i = 0; i < GL_NX; ++i) Nn[i] = f1y[i] + est_ar[i] * y1[i];
+                if (em & 1) Nn[5] = 0.5 * Nn[5];
+                for (int j = 0; j < 9; ++j) {
+                    const int i = SC_FAST[j];
+                    const double v = (i == 5) ? Nn[3] - Nn[5] : (i == 7) ? Nn[2] - Nn[7] : (i == 20) ? Nn[2] - Nn[20] : Nn[i];
+                    if (getenv("SC_TRACE") && est_w[j] * fabs(est[j] - v) / SC_TOL[j] > worst) fprintf(stderr, "   j %d est %.6g v %.6g w %.3f\n", j, est[j], v, est_w[j]);
+                    worst = fmax(worst, est_w[j] * fabs(est[j] - v) / SC_TOL[j]);
+                }
+            } else
             for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - kz(k1, SC_FAST[j])) / SC_TOL[j]);
             worst *= h_last * est_fac;
             if (getenv("SC_TRACE")) fprintf(stderr, "it %d h %.3f ratio %.4f lam %.3f\n", it, h_last, worst, lam);
@@ -962,7 +1094,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         if (it == n_win) break;
         double hs = fmin(S / lam, hnom);
         {   /* accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by more
-             * than SC_MOVE x its tolerance scale -- 4 K, 400 Pa, 400 mg m-3 -- in one sub-step.  Idle on trajectories (10-day
+             * than SC_MOVE x its tolerance scale -- 1 K, 100 Pa, 100 mg m-3 (round 4; 4 x that before) -- in one sub-step.  Idle on trajectories (10-day
              * rollout: never; rule-based 0 -> 1 jumps: 2 extra sub-steps in the worst env-step; bench workload: 1e-5 of the
              * env-steps, 1 extra sub-step); it is what keeps violent
              * transients from far-off-equilibrium states accurate, where the rate bound of the window start goes stale
@@ -979,7 +1111,9 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         h_last = h;
         for (int r = 0; r < n; ++r) {
             if (r > 0) rhs_lagged(x, ym, u, d, p, k1, pipe);
-            if (order == 4) {
+            if (em) {
+                rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, em, est, est_ar, est_w);
+            } else if (order == 4) {
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
                 rhs_lagged(xs, ym, u, d, p, k2, pipe);
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k2[i];
@@ -1031,14 +1165,14 @@ void gl_oracle_rk_sc(const double *x0, const double *u, const double *d, const d
  * mg m-3) -- step doubling.  Otherwise it is a failed integration.  (Round 2 accepted any unflagged attempt and never retried a
  * cap hit: tuples A / B of the round-2 review -- wet cover pinned to the top air, sub-step capped, branch jump, failed = 0.)
  * Returns the retries used; out[0] = 1 if the integration failed (x1 then holds the last attempt), out[1] = sub-steps beyond
- * n_sub over all attempts.  pipe != 0: ODE_pipe (d has 14 entries). */
+ * n_sub over all attempts, out[2] = the kernels' step_flags word (include/glgym.h GLGYM_SF_*).  pipe != 0: ODE_pipe (d has 14 entries). */
 #define SC_HEAVY 3.0
 #define SC_AGREE 1e-2
 #define SC_ATTEMPTS 4            /* n, 2n, 4n, 8n */
 int gl_oracle_rk_sc_guarded2(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                              int order, int window, int pipe, int verify, double *x1, double *out)
 {
-    int n = n_sub, extra = 0, ok = 0, have_prev = 0;
+    int n = n_sub, extra = 0, ok = 0, have_prev = 0, first = 0, how = 0;
     double total = 0.0, prev[9];
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         double st[4];
@@ -1047,6 +1181,7 @@ int gl_oracle_rk_sc_guarded2(const double *x0, const double *u, const double *d,
         const int flags = (int)st[3];
         const int n_nom = ((n + window - 1) / window) * window;
         const int complete = !(flags & 3);                           /* ran to the end, finite */
+        if (attempt == 0) first = flags | ((st[0] >= SC_HEAVY * (double)n_nom) ? 16 : 0);
         if (!verify && flags == 0 && st[0] < SC_HEAVY * (double)n_nom) { ok = 1; break; }
         /* agreement verifies flagged attempts too, the branch flag included: on 6 500 raw-jump tuples with half-hour spin-ups
          * (tools/gpu_stress.py) 81 env-steps carried that flag at every level -- 80 of them agreeing with the fine truth, ONE agreeing
@@ -1055,11 +1190,11 @@ int gl_oracle_rk_sc_guarded2(const double *x0, const double *u, const double *d,
         if (complete && have_prev) {
             double worst = 0.0;
             for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(x1[SC_FAST[j]] - prev[j]) / SC_TOL[j]);
-            if (worst <= SC_AGREE) { ok = 1; break; }
+            if (worst <= SC_AGREE) { ok = 1; how = flags ? 32 : 0; break; }
         }
         /* the finest attempt is taken as it stands when nothing flagged it (steps that start on a kink or pass a bifurcation are
          * sensitive at the 1e-4 level for any solver: the best available answer beats a failed episode) */
-        if (attempt == SC_ATTEMPTS - 1 && complete && flags == 0) { ok = 1; break; }
+        if (attempt == SC_ATTEMPTS - 1 && complete && flags == 0) { ok = 1; how = 64; break; }
         have_prev = complete;
         if (complete) for (int j = 0; j < 9; ++j) prev[j] = x1[SC_FAST[j]];
         if (attempt == SC_ATTEMPTS - 1) break;
@@ -1069,6 +1204,8 @@ int gl_oracle_rk_sc_guarded2(const double *x0, const double *u, const double *d,
     if (out) {
         out[0] = ok ? 0.0 : 1.0;
         out[1] = total - (double)(((n_sub + window - 1) / window) * window);
+        if (out[1] < 0.0) out[1] = 0.0;
+        out[2] = (double)(first | how | (ok ? 0 : 128) | (extra << 8)) + 65536.0 * fmin(out[1], 65535.0);        /* include/glgym.h step_flags */
     }
     return extra;
 }
@@ -1076,7 +1213,10 @@ int gl_oracle_rk_sc_guarded2(const double *x0, const double *u, const double *d,
 int gl_oracle_rk_sc_guarded(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                             int order, int window, int pipe, double *x1, double *out)
 {
-    return gl_oracle_rk_sc_guarded2(x0, u, d, p, dt, n_sub, order, window, pipe, 0, x1, out);
+    double o3[3];
+    const int r = gl_oracle_rk_sc_guarded2(x0, u, d, p, dt, n_sub, order, window, pipe, 0, x1, o3);
+    if (out) { out[0] = o3[0]; out[1] = o3[1]; }
+    return r;
 }
 
 /* ROUND-1 guard (kept for regression comparisons; the kernels now run rk_sc_impl + gl_oracle_rk_sc_guarded above): redo the

@@ -246,7 +246,7 @@ def test_c_abi_rejects_bad_arguments_and_handles_ragged_batches(golden):
         kw = dict(B=env.B, ld=env.ld, x=env.x_T.data_ptr(), u=env.u_T.data_ptr(), action=env.action_t.data_ptr(), control=None,
                   weather=env.weather_t.data_ptr(), weather_rows=env.weather_rows, w_off=env.w_off_t.data_ptr(),
                   timestep=env.timestep_t.data_ptr(), crop_p=None, N=env.N, reward=env.reward_t.data_ptr(),
-                  info=env.info_T.data_ptr(), done=env.done_t.data_ptr(), metrics=None)
+                  info=env.info_T.data_ptr(), done=env.done_t.data_ptr(), metrics=None, step_flags=None)
         kw.update(over)
         return L.StepArgs(*[kw[f[0]] for f in L.StepArgs._fields_])
 

@@ -13,7 +13,7 @@ from test_jump_fixture import judge, sce
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("rk4", 320), ("rk3", 354), ("rk2", 376)]
+SCHEMES = [("rk4", 240), ("rk3", 354), ("rk2", 376)]
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -71,7 +71,7 @@ def test_unverified_mode_flags_what_round_2_missed(golden):
     from gl_gym_amd._lib import GlgymOdeError
     g = golden("step_tight_jump")
     for dtype in ("float64", "float32"):
-        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=320)
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=240)
         m.set_verify("never")
         for i in (0, 1):
             try:

@@ -22,7 +22,9 @@ def test_step_map_against_oracle_and_tight(hostmath, oracle, golden):
     g = golden("step_tight")
     X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
     ok = np.ones(len(X), dtype=bool)          # all tuples, incl. the harvest-switch zone (exact sub-flow)
-    ref = np.array([oracle.rk4_lagged(X[i], U[i], D[i], P[i], 900.0, 256) for i in range(len(X))])
+    # the oracle's restatement of the controlled scheme (round 4: its own window count per environment and a movement limiter
+    # that resolves the initial layer make the product differ from the fixed-step rk4_lagged on some of these tuples)
+    ref = np.array([oracle.rk_sc(X[i], U[i], D[i], P[i], 900.0, 256, 4, 1)[0] for i in range(len(X))])
     g64 = np.array([hostmath.step(X[i], U[i], D[i], P[i], False) for i in range(len(X))])
     g32 = np.array([hostmath.step(X[i], U[i], D[i], P[i], True) for i in range(len(X))])
     assert scaled_err(g64[ok], ref[ok]) < 1e-9
@@ -129,17 +131,22 @@ def test_ode_pipe_variant_host(hostmath, oracle, golden):
 
 
 def test_integrator_variants_host(hostmath, oracle, golden):
-    """rk_delta<T, PIPE, ORDER, WIN>: the shipped settings (RK4 / window 1, explicit midpoint / window 4) and two others,
-    product arithmetic vs the oracle's independent restatement (gl_oracle_rk_lagged) and vs the tight one-step maps."""
+    """rk_delta<T, PIPE, ORDER, WIN>: the shipped settings and a few others, product arithmetic vs the oracle's independent
+    restatement of the controlled scheme (gl_oracle_rk_sc; the fixed-step gl_oracle_rk_lagged where the control is idle) and vs the
+    tight one-step maps."""
     g = golden("step_tight")
     X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
     idx = range(0, len(X), 2)
-    for order, win, n, tol_t in ((4, 1, 256, 1.3e-5), (4, 2, 256, 2e-5), (2, 2, 358, 3e-5), (2, 4, 360, 4e-5), (3, 1, 284, 1.5e-5),
+    for order, win, n, tol_t in ((4, 1, 256, 2e-5), (4, 2, 240, 2.5e-5), (2, 2, 358, 3e-5), (2, 4, 360, 4e-5), (3, 1, 284, 1.5e-5),
                                  (3, 3, 354, 2e-5)):
         got = np.array([hostmath.step_scheme(X[i], U[i], D[i], P[i], False, 900.0, n, order, win) for i in idx])
-        ref = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, n, order, win) for i in idx])
+        ref = np.array([oracle.rk_sc(X[i], U[i], D[i], P[i], 900.0, n, order, win)[0] for i in idx])
         g32 = np.array([hostmath.step_scheme(X[i], U[i], D[i], P[i], True, 900.0, n, order, win) for i in idx])
         assert scaled_err(got, ref) < 1e-9, (order, win)
+        # ... and where the control stays idle the controlled scheme IS the fixed-step one
+        fixed = np.array([oracle.rk_lagged(X[i], U[i], D[i], P[i], 900.0, n, order, win) for i in idx])
+        idle = [j for j, i in enumerate(idx) if oracle.rk_sc(X[i], U[i], D[i], P[i], 900.0, n, order, win)[1][0] == -(-n // win) * win]
+        assert len(idle) >= 8 and scaled_err(ref[idle], fixed[idle]) < 1e-9, (order, win, len(idle))
         assert scaled_err(got, XT[list(idx)]) < tol_t, (order, win)
         assert scaled_err(g32, XT[list(idx)]) < tol_t + 1e-5, (order, win)
 
