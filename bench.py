@@ -161,6 +161,40 @@ def cpu_baseline(n_sub: int, budget_s: float = 8.0):
             "cpu_baseline_same_scheme_all_cores": rk_all}
 
 
+def parity_leg(args, dev, layout):
+    """-> (max scaled state error over the 10-day fixture rollout, failed integrations, note).  64 identical environments (one
+    wavefront of the one-lane kernel / 4 of the quad kernel); the fixture travels with the repository."""
+    import numpy as np
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = np.load(ROOT / "tests" / "golden" / "rollout_10day.npz")
+    acts, w, XR = g["actions"], g["weather"], g["X"]
+    old = os.environ.get("GLGYM_LAYOUT")
+    if layout:
+        os.environ["GLGYM_LAYOUT"] = layout
+    try:
+        env = TomatoVecEnv(64, weather=w, dtype="float64" if args.dtype == "f64" else "float32", n_sub=args.n_sub, scheme=args.scheme,
+                           season_length=(len(acts) - 1) // 96, pred_horizon=0.5, device=str(dev), auto_reset=False)
+        env.reset_tensor()
+        a_all = torch.as_tensor(acts, device=dev)
+        X = [env.x[0].double().cpu().numpy()]
+        for k in range(len(acts)):
+            env.step_tensor(a_all[k][None].expand(64, 6).contiguous(), want_obs=False)
+            X.append(env.x[0].double().cpu().numpy())
+        failed = env.metrics().get("n_ode_fail", 0.0)
+        env.close()
+    finally:
+        if layout:
+            if old is None:
+                os.environ.pop("GLGYM_LAYOUT", None)
+            else:
+                os.environ["GLGYM_LAYOUT"] = old
+    X = np.array(X)
+    scale = np.maximum(np.abs(XR), 1e-3 * np.abs(XR).max(axis=0, keepdims=True))
+    scale[scale == 0] = 1.0
+    return float(np.max(np.abs(X - XR) / scale)), float(failed), "rollout_10day.npz, %d steps" % len(acts)
+
+
 def main():
     ap = argparse.ArgumentParser()
     # Defaults measure SUSTAINED throughput: under continuous load the MI355X settles at a lower clock within ~0.1 s, so a
@@ -175,6 +209,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the accuracy leg (10-day fixture rollout after the timed region)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step sequence from a captured HIP graph (one launch per step instead of five); the "
                          "step_kernel time for the roofline leg is then taken from W eager warm-up steps")
@@ -322,13 +357,21 @@ def main():
             dist.barrier()
         alt = (other, env.n_sub, time.perf_counter() - ta)
         env.set_scheme(args.scheme, args.n_sub)
-    # final metric gather: the only collective on this path (RCCL all_gather of 6 doubles per rank)
+    # ---- the metric's second half (BASELINE.json: "max |delta state| vs CasADi ref"; SURVEY 8d / 8e: max_scaled_err in the gathered
+    # vector): after timing, the same library, dtype, scheme and n_sub run the 961 steps of the 10-day fixture
+    # (tests/golden/rollout_10day.npz: Bleiswijk weather, delta-u-bounded random actions, truth = Radau rtol = atol = 1e-11 of the
+    # reference-text right-hand side -- the reference's CVODES itself is not available) through the SAME kernel
+    # layout as the timed batch, on every rank; the state error is max |x - x_truth| / max(|x_truth|, 1e-3 max_t |x_truth|).
+    parity = (-1.0, 0.0, None)
+    if not args.no_parity:
+        parity = parity_leg(args, dev, "one" if B > 16384 else None)
+    # final metric gather: the only collective on this path (RCCL all_gather of 16 doubles per rank)
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
                            m.get("n_done", 0.0), kern_ms, m.get("n_guard_retries", 0.0), m.get("n_refined_substeps", 0.0),
                            float(rank), float(666 + rank), m.get("n_flag_err", 0.0), m.get("n_flag_branch", 0.0),
-                           m.get("n_flag_cap", 0.0), m.get("n_flag_heavy", 0.0)], device=None if share_gpu else dev,
-                          force_collective=use_dist)
+                           m.get("n_flag_cap", 0.0), m.get("n_flag_heavy", 0.0), parity[0], parity[1]],
+                          device=None if share_gpu else dev, force_collective=use_dist)
     if rank == 0:
         agg = aggregate(rows)
         t_max, value, kern_ms_max = agg["t_max"], agg["value"], agg["kernel_ms_max"]
@@ -409,7 +452,7 @@ def main():
                     "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "obs_bytes_per_env_step": obs_bytes}})
         out = {
             "collective": None if not use_dist else {"backend": dist.get_backend(), "world": world,
-                                                     "note": "one all_gather of 14 doubles per rank at the end of the run"},
+                                                     "ranks_gathered": len(rows), "note": "one all_gather of 16 doubles per rank at the end of the run"},
             "metric": "TomatoEnv env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -428,6 +471,14 @@ def main():
                                  "more, smaller sub-steps per window where needed; embedded error estimate as safety net), "
                                  "Strang-split exact harvest flow, slow sub-expressions once per window at the predicted midpoint "
                                  "(DESIGN.md 2)"},
+            "parity": None if agg["max_scaled_err"] is None else {
+                "max_scaled_err_10day": agg["max_scaled_err"], "bar": 1e-4, "failed": agg["parity_failed"],
+                "fixture": "tests/golden/rollout_10day.npz: 961 env-steps (10 days, Bleiswijk weather, delta-u-bounded random "
+                           "actions), truth = Radau rtol = atol = 1e-11 of the reference-text right-hand side",
+                "note": "the metric's second half (max |delta state| vs the reference solution), run after the timed region with the "
+                        "same dtype / scheme / n_sub / kernel layout on every rank; worst rank reported.  CVODES itself is not "
+                        "available here or on the GPU box: the truth is a tight stiff solve, the reference-tolerance band "
+                        "(BDF 1e-6) sits 4e-6 ... 1.3e-5 from it (DESIGN.md section 3)"},
             "roofline": roof,
             "integrator_events": {"failed_integrations": agg["ode_failures"], "guard_retries": agg["guard_retries"],
                                   "refined_substeps": agg["refined_substeps"], "first_attempt_flags": agg["first_attempt_flags"],

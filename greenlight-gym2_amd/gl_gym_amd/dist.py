@@ -31,16 +31,20 @@ def gather_metrics(local: Sequence[float], device=None, force_collective: bool =
 def aggregate(rows: List[List[float]]) -> Dict[str, float]:
     """rows[r] = [elapsed_s, env_steps, sum_reward, failed integrations, episodes_done, kernel_ms,
     (optional:) guard retries, refined sub-steps, rank, seed, first-attempt flags: error estimate, branch invariant, cap /
-    non-finite, heavy].
-    Whole-job throughput = all env-steps / the slowest rank's wall time."""
+    non-finite, heavy, (round 4:) max scaled state error of the rank's parity leg (10-day fixture; < 0 = not run), failed
+    integrations in that leg].
+    Whole-job throughput = all env-steps / the slowest rank's wall time; the job's parity figure = the worst rank's."""
     t_max = max(r[0] for r in rows)
     steps = sum(r[1] for r in rows)
     col = lambda i: [r[i] if len(r) > i else 0.0 for r in rows]  # noqa: E731
+    perr = [r[14] for r in rows if len(r) > 14 and r[14] >= 0.0]
     return {"value": steps / t_max, "t_max": t_max, "env_steps": steps, "sum_reward": sum(r[2] for r in rows),
             "ode_failures": sum(r[3] for r in rows), "episodes_finished": sum(r[4] for r in rows),
             "kernel_ms_max": max(r[5] for r in rows), "guard_retries": sum(col(6)), "refined_substeps": sum(col(7)),
             "first_attempt_flags": {"error_estimate": sum(col(10)), "branch_invariant": sum(col(11)),
                                     "cap_or_nonfinite": sum(col(12)), "heavy": sum(col(13))},
+            "max_scaled_err": max(perr) if perr else None, "parity_failed": sum(col(15)),
             "ranks": [{"rank": int(r[8]) if len(r) > 8 else i, "seed": int(r[9]) if len(r) > 9 else None,
-                       "elapsed_s": r[0], "env_steps": r[1], "sum_reward": r[2], "kernel_ms": r[5]}
+                       "elapsed_s": r[0], "env_steps": r[1], "sum_reward": r[2], "kernel_ms": r[5],
+                       "max_scaled_err": (r[14] if r[14] >= 0.0 else None) if len(r) > 14 else None}
                       for i, r in enumerate(rows)]}

@@ -693,3 +693,53 @@ def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
     assert abs(ml["sum_reward"] - rep * ms["sum_reward"]) < 1e-4 * abs(rep * ms["sum_reward"]) + 1.0
     print(f"occupancy-2 build vs occupancy-1 build ({scheme}): worst relative difference {worst:.1e}")
     small.close(); large.close()
+
+
+def test_bench_workload_at_full_batch_against_oracle_and_fine_truth(oracle):
+    """The workload bench.py TIMES (BASELINE configs[2]: B = 65 536, fp32, synthetic weather year, per-env episode starts, jittered
+    states, fresh U(-1, 1) actions every step, the default dispatch = the one-lane kernel), checked instead of timed: 64 environments
+    sampled across the wavefronts (one per 16 waves, rotating lane) are compared EVERY step with the CPU checker's restatement of the
+    controlled scheme started from the kernel's own previous state (one-step maps: fp32 rounding), and 16 of them free-running over
+    all 48 steps with plain classical RK4 at 8 192 sub-steps (the fine truth: the accuracy bar)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.utils import synthetic_weather
+    B, n_steps = 65536, 48
+    w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
+    starts = np.arange(0, 35040 - 5760 - 60, 96)
+    env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=60, pred_horizon=0.5, seed=666, start_rows=starts, auto_reset=True)
+    assert env.n_sub == 240 and env.scheme == "rk4"
+    env.reset_tensor()
+    dev = env.device
+    env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)).to(env.tdtype))
+    gen = torch.Generator(device=dev).manual_seed(666)
+    pick = np.array([16 * 64 * i + (7 * i) % 64 for i in range(64)])                 # 64 envs, one per 16 waves, every lane residue
+    p = env.p.astype(np.float64)
+    w_off = env.w_off_t.cpu().numpy()[pick]
+    x_true = env.x[pick].double().cpu().numpy().copy()                                # fine truth, free-running (first 16)
+    pool = ThreadPoolExecutor(8)
+    worst_one, worst_flags = 0.0, 0
+    for k in range(n_steps):
+        x_prev = env.x[pick].double().cpu().numpy().copy()
+        torch.rand(B, 6, generator=gen, device=dev, out=env.action_t)
+        env.action_t.mul_(2.0).sub_(1.0)
+        env._launch_step(raw_control=False)
+        u = env.u[pick].double().cpu().numpy()                                         # the control the kernel applied
+        x_gpu = env.x[pick].double().cpu().numpy()
+        flags = env.step_flags_t.cpu().numpy()[pick]
+        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 240, 4, 2, want_flags=True), range(64)))
+        for j in range(64):
+            assert not ref[j][3] and not (flags[j] & 128)
+            worst_one = max(worst_one, scaled_err(x_gpu[j][None], ref[j][0][None]))
+            worst_flags += int((flags[j] & 0xffff) != (ref[j][4] & 0xffff))          # same guard decisions (fp32 may flip one rarely)
+        x_true[:16] = np.array(list(pool.map(lambda j: oracle.rk4(x_true[j], u[j], w[w_off[j] + k], p, 900.0, 8192), range(16))))
+        env._launch_reset(env.done_t)
+    e_true = scaled_err(env.x[pick[:16]].double().cpu().numpy(), x_true[:16])
+    m = env.metrics()
+    print(f"bench workload, B = 65 536 x {n_steps} steps: 64 sampled envs vs the oracle's scheme per step {worst_one:.1e} (guard words differing: "
+          f"{worst_flags}); 16 envs free-running vs RK4-8192 truth {e_true:.1e}; failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}")
+    assert worst_one < 5e-5 and worst_flags <= 2            # one-step maps in fp32 vs the fp64 restatement: 2.3e-5 measured
+    assert e_true < 1e-4
+    assert m["n_ode_fail"] == 0 and m["n_env_steps"] == B * n_steps
+    env.close()

@@ -1,0 +1,66 @@
+"""The saddle-node corner, frozen behind thresholds.  tools/gpu_stress.py's one-step stress of the PRODUCT kernels
+through glgym_evalF (step-doubling verified): 16 384 random spun-up tuples of five kinds; truth = the fp64 kernel at 2 560 ^ 5 120
+sub-steps agreeing to 2e-7.  Kinds 0-3 (plain, extreme weather, corner controls, random control jumps) must be clean.  Kind 4 is
+the round-2 review's recipe after a half-hour spin-up (vents slammed open, screens pulled, cold, 8-40 m/s wind, super-saturated
+outside air): a wet cover pinned to the top air at up to 750 1/s while its drive sits at +-1e-4 K/s -- the one place where the step
+map can be silently wrong or report a failed integration, at rates that were MEASURED in round 3 (three seeds, 19 500 such tuples:
+fp64 2 gross + 10 failed, fp32 5 + 5; scipy's BDF at the reference's tolerances lands on the same wrong branch on the gross ones,
+DESIGN.md 2.5).  The thresholds are those rates with head-room for one seed: they catch a regression, they do not claim the corner
+is solved."""
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_one_step_stress_rates_stay_at_the_measured_level():
+    sys.path.insert(0, str(ROOT / "tools"))
+    import gpu_stress
+    res = gpu_stress.run_stress(16384, 11, schemes=("rk4",), dtypes=("float64", "float32"))
+    for dtype in ("float64", "float32"):
+        r = res[("rk4", dtype)]
+        n4 = r["n_kind"][4]
+        assert r["n"] > 15000 and n4 > 2500
+        # kinds 0-3: nothing beyond the metric floor, no failed integration
+        assert sum(r["real"][:4]) == 0 and sum(r["gross"][:4]) == 0 and sum(r["failed"][:4]) == 0, (dtype, r)
+        # the review's recipe: gross <= 3e-4, failed <= 1e-3, above-the-bar <= 2.5e-3 per tuple (+1: one seed's granularity)
+        assert r["gross"][4] <= 3e-4 * n4 + 1, (dtype, r)
+        assert r["failed"][4] <= 1e-3 * n4 + 1, (dtype, r)
+        assert r["real"][4] <= 2.5e-3 * n4 + 1, (dtype, r)
+        assert r["q999"] < 1e-4, (dtype, r)
+
+
+def test_step_flags_say_how_an_env_step_was_accepted():
+    """include/glgym.h GLGYM_SF_*: per-env word of glgym_step -- first-attempt flags, extra attempts, sub-steps beyond the nominal
+    count, and whether the result was accepted by agreement on a flagged attempt / as the finest attempt alone / not at all.  On the
+    jump fixture through step_raw_control (verified): every env-step used at least one extra attempt, none failed, and the word
+    equals the CPU checker's restatement of the guard in fp64."""
+    import numpy as np
+    import torch
+    from gl_gym_amd import _lib as L
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    sys.path.insert(0, str(ROOT))
+    from oracle import gl_oracle as O
+    g = np.load(ROOT / "tests" / "golden" / "step_tight_jump.npz")
+    X, U, D = g["X"][:128], g["U"][:128], g["D"][:128]
+    B = len(X)
+    w = np.repeat(D, 4, axis=0)
+    env = TomatoVecEnv(B, weather=w, dtype="float64", season_length=0.02, pred_horizon=0, auto_reset=False)
+    env.reset()
+    env.w_off_t.copy_(torch.arange(B, dtype=torch.int32, device=env.device) * 4)
+    env.x.copy_(torch.as_tensor(X, dtype=env.tdtype, device=env.device))
+    obs, r, done, infos = env.step_raw_control(U)
+    fl = env.step_flags_t.cpu().numpy()
+    assert not (fl & L.SF_FAILED).any() and not done.any()
+    assert (((fl >> 8) & 7) >= 1).all()                                    # verified: at least n_sub and 2 n_sub
+    ref = np.array([O.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, env.n_sub, 4, 2, verify=True, want_flags=True)[4]
+                    for i in range(B)])
+    assert np.array_equal(fl & 0xffff, ref & 0xffff), np.nonzero((fl & 0xffff) != (ref & 0xffff))
+    assert np.abs((fl >> 16) - (ref >> 16)).max() <= 2                     # sub-step counts (a ceil() may flip on a last bit)
+    n_flagged_accept = int(((fl & L.SF_ACCEPT_AGREE_FLAGGED) != 0).sum())
+    print(f"jump fixture, 128 tuples, verified: extra attempts {np.bincount((fl >> 8) & 7)}, accepted by agreement on a flagged attempt: "
+          f"{n_flagged_accept}, finest attempt alone: {int(((fl & L.SF_ACCEPT_LAST_ALONE) != 0).sum())}")
+    env.close()
