@@ -88,7 +88,7 @@ def workload_label(args, B, world):
 
 DEFAULT_SCHEME = "rk4"
 STAGES = {"rk4": 4, "rk2": 2, "rk3": 3}
-N_SUB = {"rk4": 240, "rk2": 376, "rk3": 354}
+N_SUB = {"rk4": 240, "rk2": 376, "rk3": 270}
 
 
 def cpu_baseline(n_sub: int, budget_s: float = 8.0):
@@ -204,8 +204,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
     ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2", "rk3"],
-                    help="sub-stepper: RK4 (n_sub 240), Bogacki-Shampine (354) or explicit midpoint (376); include/glgym.h")
-    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 240 rk4 / 354 rk3 / 376 rk2)")
+                    help="sub-stepper: RK4 (n_sub 240), the three-stage third-order scheme (270) or explicit midpoint (376); include/glgym.h")
+    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 240 rk4 / 270 rk3 / 376 rk2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,7 +494,7 @@ def main():
                 "integrator": alt[0], "n_sub": alt[1], "value": B * world * K / alt[2], "unit": "env-steps/s",
                 "ms_per_step": 1e3 * alt[2] / K,
                 "note": "informational: same workload and timing protocol with the library's third-order sub-stepper "
-                        "(Bogacki-Shampine 3(2), rank-0 clock); accuracy of all schemes vs the tight fixtures in DESIGN.md section 2"},
+                        "(three stages, cover conduction exact like RK4's; rank-0 clock); accuracy of all schemes vs the tight fixtures in DESIGN.md section 2"},
             "sum_reward": agg["sum_reward"], "ode_failures": agg["ode_failures"],
             "episodes_finished": agg["episodes_finished"],
         }

@@ -1487,8 +1487,8 @@ GL_HD void rhs_stage(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, con
 // i.e. w = exp(-z) solves w + ln w = D (Wright omega).  harvest_flow returns the INCREMENT of c over time t.
 //   * z0 < -40: the rate is below 2e-13 mg/s -> 0.
 //   * z0 - k M t > 40: the rate stays saturated at M (to 4e-18) over the whole interval -> -M t (and w would underflow).
-//   * first Newton step |dz| < 0.03 (always on nominal trajectories): increment form (Newton on dz with expm1), so
-//     that the tiny change is not lost in fp32;
+//   * first Newton step |dz| < 4e-3 (always on nominal trajectories): closed-form series inversion; |dz| < 0.03: increment
+//     form (Newton on dz with expm1), so that the tiny change is not lost in fp32;
 //   * else: Newton on w + ln w = D from the asymptotic initial guess (monotone, no overflow).
 // ---------------------------------------------------------------------------------------------------
 template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
@@ -1500,8 +1500,17 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
     if (z0 < T(-40)) return T(0);
     if (z0 - a > T(40)) return T(-5e4) * t;
     const T E0 = M::exp(-z0);
-    T dz = -a * M::rcp(one + E0);                                     // first Newton step from dz = 0
-    if (dz > T(-0.03)) {
+    const T inv = M::rcp(one + E0);
+    T dz = -a * inv;                                                  // first Newton step from dz = 0
+    if (dz > T(-4e-3)) {
+        // nominal trajectories (c a few thousand mg below cMax: E0 ~ 1e5, dz ~ -1e-3 per window): the series inversion of
+        //   x (1 + E0) + E0 (x^2 / 2 + x^3 / 6 + x^4 / 24 + ...) = a,  x = -dz,  x1 = a / (1 + E0),  r = E0 / (1 + E0):
+        //   x = x1 (1 + c2 x1 + c3 x1^2 + c4 x1^3),  c2 = -r/2,  c3 = r^2/2 - r/6,  c4 = -r (5 r^2/8 - 5 r/12 + 1/24);
+        // truncation x1^4 < 3e-10 relative.  (Round 4: two Newton steps with expm1 here were 7 % of a window.)
+        const T r = E0 * inv, x1 = -dz;
+        const T c2 = T(-0.5) * r, c3 = r * (T(0.5) * r - T(1.0 / 6.0)), c4 = -r * (r * (T(0.625) * r - T(5.0 / 12.0)) + T(1.0 / 24.0));
+        dz = -x1 * (one + x1 * (c2 + x1 * (c3 + x1 * c4)));
+    } else if (dz > T(-0.03)) {
         // small change (always the case on nominal trajectories): two more Newton steps converge to < 1e-12 relative
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -1568,9 +1577,9 @@ template <> struct RkVec<float> {
 // ---------------------------------------------------------------------------------------------------
 // The sub-stepper, round 2: STABILITY-CONTROLLED.
 //
-// ORDER: 4 = classical RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 3 = Bogacki-Shampine
-// (2.513: 0.84 per stage, third order, a true embedded second-order solution), 2 = explicit midpoint (2.0, i.e. 1.0 per
-// stage: the same stability margin with 30 % fewer right-hand sides than RK4; second order).  WIN: nominal
+// ORDER: 4 = RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 3 = the three-stage third-order scheme
+// (2.513: 0.84 per stage) -- both with the cover pair's conduction taken out of the explicit part and integrated exactly (round 4,
+// below) -- 2 = explicit midpoint (2.0, i.e. 1.0 per stage, conduction in its right-hand side; second order).  WIN: nominal
 // number of sub-steps per WINDOW; a window shares one tier-2b evaluation and one pair of harvest half steps.
 //
 // The env-step is n_win = ceil(n_sub / WIN) windows of length hw.  Inside a window every lane takes
@@ -1586,7 +1595,7 @@ template <> struct RkVec<float> {
 // Safety net: an embedded error estimate on the nine fast states.  With k1' = f(y_{n+1}) (= the next sub-step's first
 // stage, free), y* = y_n + h/6 (k1 + 2 k2 + 2 k3 + k1') is a third-order solution, so  e = h/6 |k4 - k1'|  estimates the
 // local error of RK4 (for a mode at the stability limit e ~ 2x the mode's amplitude); midpoint: e = h/6 |k1 - 2 k2 + k1'|;
-// Bogacki-Shampine: its own embedded pair, e = h/8 |(-5/9 k1 + 2/3 k2 + 8/9 k3) - k1'|.
+// three-stage scheme: e = h/6 |k3 - k1'| (comparison solution y + h/6 (k1 + 4 k2 + k1'), second order).
 // It is checked at every window boundary (every sub-step once refined); SC_FLAG_ERR makes the guard redo the env-step
 // with 2x, then 4x windows.  oracle/gl_oracle.c (rk_sc_impl) restates all of it.
 // ---------------------------------------------------------------------------------------------------
@@ -1624,14 +1633,18 @@ template <class T> struct ScStat {
 //     w_a = E2 w + Q N1,   w_b = E2 w + Q Na,   w_c = E2 w_a + Q (2 Nb - N1),   w+ = E w + f1 N1 + 2 f2 (Na + Nb) + f3 Nc,
 //     E = e^z, E2 = e^(z/2), Q = h/2 phi1(z/2), f1 = h (phi1 - 3 phi2 + 4 phi3), f2 = h (phi2 - 2 phi3), f3 = h (4 phi3 - phi2) at z = -a h
 // -- exact for a constant N_w, and for a = 0 the coefficients ARE those of classical RK4 (E = E2 = 1, Q = h/2, f1 = f2 = f3 = h/6), which is what
-// every other state gets.  The integrator keeps slot 5 = tTop - tCovIn (the wet inner face as a difference to its air node, full
+// every other state gets.  ORDER = 3 is the three-stage member of the same family (Cox-Matthews' ETD3RK):
+//     w_a = E2 w + Q N1,   w_b = E w + h phi1 (2 Na - N1),   w+ = E w + f1 N1 + 4 f2 Na + f3 Nb
+// -- for a = 0 Kutta's third-order method (stages at 0, h/2, h; weights 1/6, 4/6, 1/6), whose last stage against the next sub-step's
+// first one gives the same kind of embedded estimate as RK4's: e = h/6 |k3 - k1'| (the second-order comparison solution
+// y + h (k1/6 + 4 k2/6 + k1'/6)).  The integrator keeps slot 5 = tTop - tCovIn (the wet inner face as a difference to its air node, full
 // relative precision in fp32): its increments are assembled from the increments of tTop, sigma (classical part, returned by
 // rhs_fast<COVEXP> in dx[5]) and w:  d z5 = d tTop - (d sigma + d w) / 2.
 // phi3 by its Taylor series (no cancellation; terms for 1 ulp of T at |z| <= 3), phi2, phi1, e^z by the stable downward recurrence
 // phi_{k-1} = z phi_k + 1/(k-1)!; beyond |z| = 3 (n_sub < 200 at dt = 900 s: not a production setting) the closed forms.
 // oracle/gl_oracle.c (etd_coefs) restates it.
 // ---------------------------------------------------------------------------------------------------
-template <class T> struct EtdCoef { T e2m1, e2, q, em1, f1, f2d, f3, w3; };     // E2 - 1, E2, Q, E - 1, f1, 2 f2, f3, f3 / (h/6)
+template <class T> struct EtdCoef { T e2m1, e2, q, em1, f1, f2d, f3, w3, hp1; };     // E2 - 1, E2, Q, E - 1, f1, 2 f2, f3, f3 / (h/6), h phi1(z)
 template <class T> GL_HD void etd_phis(T z, T& e, T& p1, T& p2, T& p3)
 {
     using M = Math<T>;
@@ -1665,6 +1678,7 @@ template <class T> GL_HD void etd_coefs(T a, T h, EtdCoef<T>& c)
     c.f2d = T(2) * h * (p2 - T(2) * p3);
     c.f3 = h * (T(4) * p3 - p2);
     c.w3 = T(6) * (T(4) * p3 - p2);
+    c.hp1 = h * p1;
 }
 
 // A lane whose rate bound at the START of the env-step asks for a shorter sub-step than the nominal one gets proportionally more
@@ -1681,12 +1695,12 @@ template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool LDSCOEF =
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                     int n_sub, T* del, ScStat<T>& st)
 {
-    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (RK4, cover conduction exponential), 3 (Bogacki-Shampine) or 2 (explicit midpoint)");
+    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (RK4) or 3 (three-stage third-order scheme), both with the cover conduction exponential, or 2 (explicit midpoint)");
     using M = Math<T>;
-    constexpr bool COVEXP = ORDER == 4;
+    constexpr bool COVEXP = ORDER == 4 || ORDER == 3;
     constexpr bool UNIFORM = RhsStage<T, PIPE>::UNIFORM_CALLS;
     const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
-    const T est_fac = T(ORDER == 3 ? 1.0 / 8.0 : 1.0 / 6.0);
+    const T est_fac = T(1.0 / 6.0);
     // the environment's windows: nominal count now, its own after the pre-pass (it == -1) below
     int n_win = (n_sub + WIN - 1) / WIN;
     T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WIN), hmin = hnom * T(1.0 / SC_MAX_REFINE);
@@ -1858,28 +1872,44 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     del[5] += h6 * (acc[5] + k[5]) - T(0.5) * dW;
                 }
             } else if (ORDER == 3) {
-                // Bogacki-Shampine: k2 = f(y + h/2 k1), k3 = f(y + 3h/4 k2), y+ = y + h (2/9 k1 + 1/3 k2 + 4/9 k3);
-                // est accumulates  -5/9 k1 + 2/3 k2 + 8/9 k3  (the embedded second-order solution, see rk_delta's header)
-                const T h34 = T(0.75) * h;
-#pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] = T(-5.0 / 9.0) * k[sc_fast(j)];
-#pragma unroll
-                for (int p = 0; p < GL_NPAIR_FAST; ++p)
-                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
-                        r.st(acc, r.sp(T(2.0 / 9.0)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
-#pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] += T(2.0 / 3.0) * k[sc_fast(j)];
+                // the three-stage scheme: Kutta's RK3 (k2 = f(y + h/2 k1), k3 = f(y + h (2 k2 - k1)), y+ = y + h/6 (k1 + 4 k2 + k3)) on
+                // every fast pair but (5, 6); slot 6 (w) by the ETD3RK formulas above, slot 5 assembled from tTop, sigma and w
+                const T h6 = h * T(1.0 / 6.0);
+                const T w0 = y[6], n1 = k[6];
+                T accW = T(0);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
-                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
-                        r.st(acc, r.ld(acc) + r.sp(T(1.0 / 3.0)) * r.ld(k)); r.st(xs, r.ld(y) + r.sp(h34) * r.ld(k)); });
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                    if (p != 3)
+                        RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(acc, r.ld(k)); r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
+                {
+                    const T dWa = ec.e2m1 * w0 + ec.q * n1;
+                    accW = ec.f1 * n1;
+                    acc[5] = k[5]; xs[5] = y[5] + h2 * k[5] - T(0.5) * dWa; xs[6] = w0 + dWa;
+                }
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+#pragma unroll
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)                   // stage input y + h (2 k2 - k1) = y + 2h k2 - h k1 (acc holds k1)
+                    if (p != 3)
+                        RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                            r.st(xs, r.ld(y) + r.sp(h) * (r.sp(T(2)) * r.ld(k) - r.ld(acc))); r.st(acc, r.ld(acc) + r.sp(T(4)) * r.ld(k)); });
+                {
+                    const T dWb = ec.em1 * w0 + ec.hp1 * (T(2) * k[6] - n1);
+                    accW += T(2) * ec.f2d * k[6];
+                    xs[5] = y[5] + h * (T(2) * k[5] - acc[5]) - T(0.5) * dWb; xs[6] = w0 + dWb;
+                    acc[5] += T(4) * k[5];
+                }
+                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 for the constant-rate states
-                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
-                        if (p < GL_NPAIR_FAST) r.st(del, r.ld(del) + r.sp(h) * (r.ld(acc) + r.sp(T(4.0 / 9.0)) * r.ld(k)));
-                        else r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
+                    if (p != 3)
+                        RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                            if (p < GL_NPAIR_FAST) r.st(del, r.ld(del) + r.sp(h6) * (r.ld(acc) + r.ld(k)));
+                            else r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
+                {
+                    const T dW = ec.em1 * w0 + accW + ec.f3 * k[6];
+                    del[6] += dW;
+                    del[5] += h6 * (acc[5] + k[5]) - T(0.5) * dW;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] = -k[sc_fast(j)];
@@ -1896,9 +1926,9 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // the first sub-step uses the stage evaluated above; every further one starts with its own first stage (written
         // as two loops so that the compiler cannot hoist that evaluation above the exit test of the previous sub-step)
         sub_step();
-        // the last stage (RK4: k4; midpoint: 2 k2 - k1) of the window's last sub-step, for the estimate at the next start
+        // the last stage (RK4: k4; three-stage scheme: k3; midpoint: 2 k2 - k1) of the window's last sub-step, for the estimate at the next start
 #pragma unroll
-        for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
+        for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
         if (UNIFORM) {
             // fp64 on the device: the stage is an out-of-line call, and calls are kept wave-uniform -- every lane runs the
             // wave's longest window, lanes that are done take sub-steps of length 0 (same time at wave level: they would
@@ -1916,7 +1946,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 n_steps -= (act || fin || (flags & SC_FLAG_CAP)) ? 0 : 1;
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j)
-                    est[j] = !act ? keep[j] : (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
+                    est[j] = !act ? keep[j] : (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
             }
             if (COVEXP && h_ec != h_last) { etd_coefs<T>(T(2) * gamCov, h_last, ec); h_ec = h_last; }   // the estimate's weight is that of the last real sub-step
         } else {
@@ -1925,7 +1955,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);                // same tier 2b
                 sub_step();
 #pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER == 4) ? k[sc_fast(j)] : est[j] + T(ORDER == 3 ? 8.0 / 9.0 : 2.0) * k[sc_fast(j)];
+                for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
             }
         }
         // ---- window end: increment of the window's RK part (harvest excluded), harvest flow

@@ -87,9 +87,11 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 376.  Same stability margin with 30 % fewer
  *     right-hand sides; the slow sub-expressions and the harvest flow are shared by four nominal sub-steps (n_sub is
  *     rounded up to a multiple of 4).  Second order: 1e-4 one-step errors occur after abrupt control changes.
- *   GLGYM_SCHEME_RK3: Bogacki-Shampine 3(2) (stability interval 2.513): use n_sub 354.  Third order with its own embedded
- *     second-order solution as the error estimate; 17 % fewer right-hand sides than RK4 at RK4-like accuracy; the slow
- *     sub-expressions and the harvest flow are shared by three nominal sub-steps (n_sub is rounded up to a multiple of 3). */
+ *   GLGYM_SCHEME_RK3: the three-stage, third-order member of the same exponential family (Cox-Matthews ETD3RK on the cover
+ *     conduction, Kutta's RK3 -- stages at 0, h/2, h -- on every other state; stability interval 2.513): use n_sub 270.  19 % fewer
+ *     right-hand sides than RK4 at RK4-like accuracy (the error of both is set by the slow tier's window, not by the order); the
+ *     slow sub-expressions and the harvest flow are shared by three nominal sub-steps (n_sub is rounded up to a multiple of 3).
+ *     (Rounds 2-3 shipped Bogacki-Shampine 3(2) with the conduction in its right-hand side at n_sub 354 under this name.) */
 typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1, GLGYM_SCHEME_RK3 = 2 } glgym_scheme;
 
 /* Step-doubling VERIFIED integration: no attempt is accepted on its own, the result is the finer of two agreeing attempts (at

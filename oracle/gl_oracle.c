@@ -666,8 +666,8 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
 extern int gl_sc_exp;
 static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
                             int pipe, double h, int em, double *est, double *est_ar, double *est_w);
-/* order = 4 RK4 (with the cover pair's conduction integrated exactly: gl_sc_exp, rk4_exp_substep below), 3 Bogacki-Shampine's
- * third-order method, 2 explicit midpoint.  window = number of consecutive sub-steps that
+/* order = 4 RK4 / 3 the three-stage third-order scheme (both with the cover pair's conduction integrated exactly: gl_sc_exp,
+ * rk4_exp_substep below), 2 explicit midpoint.  window = number of consecutive sub-steps that
  * share one tier-2b evaluation and one harvest half-step pair (1 = every sub-step). */
 static void rk_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                            double *x1, int pipe, int order, int window)
@@ -698,13 +698,9 @@ static void rk_lagged_impl(const double *x0, const double *u, const double *d, c
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + h * k3[i];
             rhs_lagged(xs, ym, u, d, p, k4, pipe);
             for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-        } else if (order == 3) {   /* Bogacki-Shampine (GLGYM_SCHEME_RK3) */
+        } else if (order == 3) {   /* GLGYM_SCHEME_RK3: the exponential three-stage scheme (rk4_exp_substep, bit 16) */
             rhs_lagged(x, ym, u, d, p, k1, pipe);
-            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
-            rhs_lagged(xs, ym, u, d, p, k2, pipe);
-            for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.75 * h * k2[i];
-            rhs_lagged(xs, ym, u, d, p, k3, pipe);
-            for (int i = 0; i < GL_NX; ++i) x[i] += h * ((2.0 / 9.0) * k1[i] + (1.0 / 3.0) * k2[i] + (4.0 / 9.0) * k3[i]);
+            rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, gl_sc_exp | 16, NULL, NULL, NULL);
         } else {
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
@@ -837,6 +833,7 @@ static void etd_coefs(double a, double h, double *c)
     c[3] = h * (ph[0][1] - 3.0 * ph[0][2] + 4.0 * ph[0][3]);   /* f1 */
     c[4] = h * (ph[0][2] - 2.0 * ph[0][3]);                /* f2: weight of EACH of N(a), N(b) is 2 f2 */
     c[5] = h * (4.0 * ph[0][3] - ph[0][2]);                /* f3 */
+    c[6] = h * ph[0][1];                                   /* h phi1(z): the full-step stage of the three-stage scheme */
 }
 
 /* Upper bound on the fastest relaxation rate [1/s] of the ODE at state x (negative real spectrum; validated against the
@@ -976,7 +973,9 @@ double gl_rate_bound(const double *x, const double *u, const double *d, const do
 static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
                             int pipe, double h, int em, double *est, double *est_ar, double *est_w)
 {
-    double ar[GL_NX] = {0}, C[GL_NX][6], y0[GL_NX], ya[GL_NX], N1[GL_NX], Na[GL_NX], Nb[GL_NX], Nc[GL_NX];
+    const int three = (em & 16) != 0;      /* Cox-Matthews ETD3RK (for a = 0: Kutta's third-order method): a = E2 y + Q N(y),
+                                            * b = E y + h phi1 (2 N(a) - N(y)),  y+ = E y + f1 N(y) + 4 f2 N(a) + f3 N(b) */
+    double ar[GL_NX] = {0}, C[GL_NX][7], y0[GL_NX], ya[GL_NX], N1[GL_NX], Na[GL_NX], Nb[GL_NX], Nc[GL_NX];
     double k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], yy[GL_NX];
     if (em & 1) ar[6] = 2.0 * fabs(1.0 / (p[73] / p[71])) / (0.1 * cos(p[45] * PI_ / 180.0) * p[73] * p[64] * p[72]);
     if (em & 2) ar[17] = fabs(p[185]) / p[184];
@@ -991,11 +990,17 @@ static void rk4_exp_substep(double *x, const double *k1, const double *ym, const
     NONLIN(k1, y0, N1);
     for (int i = 0; i < GL_NX; ++i) ya[i] = C[i][1] * y0[i] + C[i][2] * N1[i];
     TO_X(ya, xs); rhs_lagged(xs, ym, u, d, p, k2, pipe); NONLIN(k2, ya, Na);
+    if (three) {
+        for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][6] * (2.0 * Na[i] - N1[i]);
+        TO_X(yy, xs); rhs_lagged(xs, ym, u, d, p, k3, pipe); NONLIN(k3, yy, Nc);         /* Nc = the last stage N(b) */
+        for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][3] * N1[i] + 4.0 * C[i][4] * Na[i] + C[i][5] * Nc[i];
+    } else {
     for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][1] * y0[i] + C[i][2] * Na[i];
     TO_X(yy, xs); rhs_lagged(xs, ym, u, d, p, k3, pipe); NONLIN(k3, yy, Nb);
     for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][1] * ya[i] + C[i][2] * (2.0 * Nb[i] - N1[i]);
     TO_X(yy, xs); rhs_lagged(xs, ym, u, d, p, k4, pipe); NONLIN(k4, yy, Nc);
     for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][3] * N1[i] + 2.0 * C[i][4] * (Na[i] + Nb[i]) + C[i][5] * Nc[i];
+    }
     TO_X(yy, x);
     if (est) {
         double kc[GL_NX];
@@ -1019,8 +1024,10 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
     double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX];
     double est[9] = {0}, est_w[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, est_ar[GL_NX] = {0};
     const double S = SC_SAFETY * (order == 4 ? 2.785 : order == 3 ? 2.5127 : 2.0);
-    const double est_fac = order == 3 ? 1.0 / 8.0 : 1.0 / 6.0;
-    const int em = (order == 4) ? gl_sc_exp : 0;      /* what is integrated exponentially (RK4 only) */
+    const double est_fac = 1.0 / 6.0;
+    /* what is integrated exponentially: the cover conduction in RK4 (order 4) and in the three-stage scheme (order 3; bit 16 selects
+     * its formulas in rk4_exp_substep); gl_sc_exp = 0 (studies): classical RK4 / Kutta's RK3 */
+    const int em = (order == 4) ? gl_sc_exp : (order == 3) ? (gl_sc_exp | 16) : 0;
     int n_win = (n_sub + window - 1) / window;
     memcpy(x, x0, sizeof x);
     if (gl_sc_prescale) {
@@ -1122,17 +1129,6 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                 rhs_lagged(xs, ym, u, d, p, k4, pipe);
                 for (int i = 0; i < GL_NX; ++i) x[i] += (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
                 for (int j = 0; j < 9; ++j) est[j] = kz(k4, SC_FAST[j]);
-            } else if (order == 3) {
-                /* Bogacki-Shampine 3(2): with k1' = f(y_{n+1}) (the next sub-step's first stage) the embedded second-order
-                 * solution differs from the third-order one by  h (-5/72 k1 + 1/12 k2 + 1/9 k3 - 1/8 k1')  =
-                 * h/8 ((-5/9 k1 + 2/3 k2 + 8/9 k3) - k1') */
-                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
-                rhs_lagged(xs, ym, u, d, p, k2, pipe);
-                for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.75 * h * k2[i];
-                rhs_lagged(xs, ym, u, d, p, k3, pipe);
-                for (int i = 0; i < GL_NX; ++i) x[i] += h * ((2.0 / 9.0) * k1[i] + (1.0 / 3.0) * k2[i] + (4.0 / 9.0) * k3[i]);
-                for (int j = 0; j < 9; ++j)
-                    est[j] = (-5.0 / 9.0) * kz(k1, SC_FAST[j]) + (2.0 / 3.0) * kz(k2, SC_FAST[j]) + (8.0 / 9.0) * kz(k3, SC_FAST[j]);
             } else {
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
                 rhs_lagged(xs, ym, u, d, p, k2, pipe);

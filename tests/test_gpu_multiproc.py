@@ -32,6 +32,11 @@ def test_two_rank_bench_on_one_gpu():
     t_max = max(r["elapsed_s"] for r in ranks)
     assert abs(d["value"] - 8192 * 6 / t_max) < 1e-6 * d["value"]
     assert d["ode_failures"] == 0
+    # the N > 1 line carries the collective's world size, per-rank kernel times and the metric's accuracy half (every rank runs the
+    # 10-day fixture after its timed region; the job's figure is the worst rank's)
+    assert d["collective"]["world"] == 2 and d["collective"]["ranks_gathered"] == 2
+    assert all(r["kernel_ms"] > 0 and 0 < r["max_scaled_err"] < 1e-4 for r in ranks)
+    assert d["parity"]["max_scaled_err_10day"] == max(r["max_scaled_err"] for r in ranks) and d["parity"]["failed"] == 0
 
 
 def test_rccl_at_world_size_one():
@@ -47,7 +52,7 @@ def test_rccl_at_world_size_one():
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, text[-3000:]
     d = json.loads(lines[0])
-    assert d["collective"] == {"backend": "nccl", "world": 1, "note": d["collective"]["note"]}
+    assert d["collective"] == {"backend": "nccl", "world": 1, "ranks_gathered": 1, "note": d["collective"]["note"]}
     assert d["n_gpus"] == 1 and d["ranks"][0]["env_steps"] == 4096 * 6 and d["ode_failures"] == 0
 
 

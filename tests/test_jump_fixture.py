@@ -68,7 +68,7 @@ def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
     p = golden("params_default")["p"].astype(np.float64)
     X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
     for i in list(range(0, 15)) + [40, 100, 300]:
-        for (n, o, w) in ((240, 4, 2), (354, 3, 3)):
+        for (n, o, w) in ((240, 4, 2), (270, 3, 3)):
             a = hostmath.step_guarded(X[i], U[i], D[i], p, False, 900.0, n, o, w, verify=True)
             b = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n, o, w, verify=True)
             assert a[1] == b[1] and a[3] == b[3] and not a[3], (i, n, a[1:], b[1:])
