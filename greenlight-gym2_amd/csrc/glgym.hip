@@ -131,14 +131,16 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #ifndef GL_STEP_WAVES_PER_SIMD
 #define GL_STEP_WAVES_PER_SIMD 1
 #endif
-// Tier-2b / harvest window of the RK4 scheme: two sub-steps (5.6 s at the default n_sub) in both precisions.  It costs 2e-6
-// against the tight fixtures -- below fp32 rounding (1e-5), and in fp64 the default stays inside the 1.3e-5 of the reference
-// solver's tolerance (8.7e-6) -- and a third of the fp64 env-step.  (Midpoint scheme: 4 sub-steps, Bogacki-Shampine: 3.)
+// Tier-2b / harvest window of the RK4 scheme: THREE sub-steps (11.25 s at the default n_sub 240) in both precisions (round 4; two
+// before).  Measured on the GPU against the two-sub-step window at the same n_sub: 7.64e7 against 6.82e7 env-steps/s; 10-day fixture
+// 2.43e-5 against 2.41e-5 (fp32), one-step stress identical (kinds 0-3 clean, 99.9 % quantile 4.4e-5 against 5.2e-5); the tight
+// one-step tuples 3.5e-5 against 2.4e-5 in fp64 -- all of it one artificial tuple that starts with an EMPTY carbohydrate buffer
+// (the CPU study rk3e_study).  (Midpoint scheme: 4 sub-steps, three-stage scheme: 3.)
 #ifndef GL_RK4_WIN_F32
-#define GL_RK4_WIN_F32 2
+#define GL_RK4_WIN_F32 3
 #endif
 #ifndef GL_RK4_WIN_F64
-#define GL_RK4_WIN_F64 2
+#define GL_RK4_WIN_F64 3
 #endif
  // kernels that integrate in fp64 take the LDS mailbox of gl_model.hpp (rhs_stage_f64) as dynamic LDS
 #define GL_LAUNCH_T(kern, crop, grid, block, st, ...)                                                                       \

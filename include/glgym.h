@@ -83,7 +83,7 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     nominal sub-step is then set by the top compartment's air exchange: use n_sub 240 (nominal environments cover rates up to
  *     0.68 1/s).  An environment whose rate bound at the start of the env-step asks for a shorter sub-step gets proportionally
  *     more windows (up to 2x); what changes during the env-step is followed window by window.  The slow sub-expressions and the
- *     harvest flow are evaluated once per window of two nominal sub-steps in both precisions (n_sub is rounded up to even).
+ *     harvest flow are evaluated once per window of three nominal sub-steps in both precisions (n_sub is rounded up to a multiple of 3).
  *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 376.  Same stability margin with 30 % fewer
  *     right-hand sides; the slow sub-expressions and the harvest flow are shared by four nominal sub-steps (n_sub is
  *     rounded up to a multiple of 4).  Second order: 1e-4 one-step errors occur after abrupt control changes.

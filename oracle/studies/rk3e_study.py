@@ -1,6 +1,7 @@
 """Round 4 study (CPU, fp64, oracle restatement): the exponential THREE-stage scheme (Cox-Matthews ETD3RK on the cover pair's
-conduction mode, Kutta's third-order method on everything else; order code 5 of gl_oracle_rk_sc) against Bogacki-Shampine with the
-conduction in its right-hand side (order 3, n_sub 354) and the exponential RK4 (order 4, n_sub 240), on the tight fixtures.
+conduction mode, Kutta's third-order method on everything else; order 3 of gl_oracle_rk_sc since it became scheme "rk3") against the
+exponential RK4 (order 4, n_sub 240) and both with other tier-2b windows, on the tight fixtures.  First run (with Bogacki-Shampine
+3(2), conduction in its right-hand side, as order 3 at n_sub 354): rk3e_study_result.txt.
     python oracle/studies/rk3e_study.py"""
 import sys, time
 from concurrent.futures import ThreadPoolExecutor
@@ -26,7 +27,7 @@ def rollout(R, n, order, win):
         x, r, ex, f = O.rk_sc_guarded(x, u, w[k], p, 900.0, n, order, win)
         Xs.append(x); ref += ex; fail += f
     return O.scaled_rel_err(np.array(Xs), XR), ref, fail
-for order, win, n in ((4, 2, 240), (3, 3, 354), (5, 3, 270), (5, 3, 255), (5, 2, 270), (5, 3, 240)):
+for order, win, n in ((4, 2, 240), (4, 3, 240), (3, 3, 270), (3, 2, 270), (3, 4, 272), (3, 3, 240)):
     t0 = time.time()
     run = lambda X, U, D, P, v: list(pool.map(lambda i: O.rk_sc_guarded(X[i], U[i], D[i], P[i] if P is not None else p, 900.0, n, order, win, verify=v), range(len(X))))
     r = run(t['X'], t['U'], t['D'], t['P'], False); e_t = sce(np.array([a[0] for a in r]), t['X_tight']).max()
@@ -36,6 +37,6 @@ for order, win, n in ((4, 2, 240), (3, 3, 354), (5, 3, 270), (5, 3, 255), (5, 2,
     ej = np.quantile(sce(gj, jp['X_tight']).max(axis=1), 0.99)
     r = run(jp['X'], jp['U'], jp['D'], None, False); gj = np.array([a[0] for a in r]); wju, fju = judge(gj, jp['X_tight'])
     e3, ref3, f3 = rollout(R3, n, order, win); e10, ref10, f10 = rollout(R10, n, order, win)
-    stages = (3 if order in (3, 5) else 4) * n
+    stages = (3 if order == 3 else 4) * n
     print(f"order {order} window {win} n_sub {n} ({stages} stages): tight {e_t:.1e} | storm max {e_s:.1e} >1e-4 {ws} mean sub-steps {sub_s:.0f} | jump verified >1e-4 {wj} floor {fj} "
           f"failed {fail_j} q99 {ej:.1e}; unverified >1e-4 {wju} | 3-day {e3:.1e} (refined {ref3}, failed {f3}) | 10-day {e10:.1e} (refined {ref10}, failed {f10}) | {time.time()-t0:.0f}s", flush=True)

