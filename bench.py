@@ -56,7 +56,7 @@ CYC_PLAIN, CYC_TRANS = 2.3, 7.7
 # Recorded rocprofv3 PMC measurements of step_kernel per launch at B = 65 536, one entry per shipped variant (bench.py cannot
 # collect counters itself).  Written by tools/pmc_summary.py from the separate --pmc passes of tools/profile_round.sh /
 # tools/profile_variants.sh; the summaries they come from are committed next to it.
-PMC_FILES = [ROOT / "profiles" / "r03_pmc_constants.json", ROOT / "profiles" / "r02_pmc_constants.json"]
+PMC_FILES = [ROOT / "profiles" / "r04_pmc_constants.json", ROOT / "profiles" / "r03_pmc_constants.json"]
 
 
 def load_pmc(variant: str):
@@ -389,12 +389,15 @@ def main():
         # batches up to 16 384 -- and fp64 batches beyond 28 672 -- run the four-lanes-per-environment kernel (glgym.hip launch_step;
         # GLGYM_LAYOUT overrides): another kernel, other counters
         layout = os.environ.get("GLGYM_LAYOUT", "")
-        if args.scheme == "rk4" and not args.uncertainty and (
-                layout == "quad" or (layout == "" and (B <= 16384 or (args.dtype == "f64" and B > 28672)))):
+        quad = args.scheme == "rk4" and not args.uncertainty and (
+            layout == "quad" or (layout == "" and (B <= 16384 or (args.dtype == "f64" and B > 28672))))
+        if quad:
             variant += "_quad"
-        pmc = load_pmc(variant)
-        roof = {"bound": "valu", "kernel": "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["fma"],
-                "unit": "TFLOP/s", "frac": None, "traffic": None}
+        pmc = load_pmc(variant + "_b65536") if (quad and B > 16384) else None      # recorded at this size (four rounds of waves)
+        pmc = pmc or load_pmc(variant)
+        waves = (4 if quad else 1) * ((B + 63) // 64)
+        roof = {"bound": "valu", "kernel": "step_kernel_quad" if quad else "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["fma"],
+                "unit": "TFLOP/s", "frac": None, "traffic": None, "waves_per_launch": waves, "waves_per_simd": waves / N_SIMD}
         if pmc is not None:
             pmc_batch = float(pmc.get("batch", 65536))
             scale = (B / pmc_batch) * (args.n_sub / float(pmc.get("n_sub", N_SUB[args.scheme])))
@@ -428,11 +431,11 @@ def main():
                 "frac_measured_ruler": need_meas / (N_SIMD * t_s * clk * 1e9),
                 "frac_measured_ruler_note": "same with the issue costs measured on this chip with >= 2 co-resident waves (2.3 / 7.7 "
                                             "cycles, profiles/r02_microbench_issue_rates.txt) and " + clk_note,
-                "valu_busy_one_wave_per_simd": pmc.get("valu_busy"),
-                "valu_busy_note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the recorded profile: B = 65 536 is exactly one "
-                                  "wave per SIMD and a lone wave is issued a vector instruction only every ~5 cycles "
-                                  "(transcendental 8.4), so this -- not `frac` -- is how close the kernel is to the ceiling "
-                                  "its launch geometry allows",
+                "valu_busy_per_wave": pmc.get("valu_busy"),
+                "valu_busy_note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the recorded profile of this variant (waves per SIMD "
+                                  "above).  With ONE wave per SIMD -- all a one-lane-per-environment kernel can have at B = 65 536 -- "
+                                  "a lone wave is issued a vector instruction only every ~5 cycles (transcendental 8.4), so this -- "
+                                  "not `frac` -- is how close the kernel is to the ceiling its launch geometry allows",
                 "traffic": pmc["traffic_bytes"] * (B / pmc_batch),
                 "valu_insts_per_launch": valu, "trans_insts_per_launch": trans,
                 "pmc_source": pmc.get("source"), "pmc_variant": variant,

@@ -22,8 +22,8 @@ def pytest_configure(config):
 # `python -m torch.distributed.run ... bench.py` has to be a fresh child process; the jobs are started once the collection
 # shows that their tests will run, and only collected by the tests.  Job "two_rank": bench.py --gpus 2 with both ranks on the
 # one GPU of the box (gloo gather).  Job "rccl_ws1": ONE rank with backend "nccl" (= RCCL): init, barrier and the all_gather
-# of a device tensor on hardware.  (torch.cuda.device_count() initialises the HIP runtime in this process on ROCm; harmless:
-# the launchers are children, nothing here is exec'ed.)
+# of a device tensor on hardware.  (torch.cuda.device_count() counts devices without initialising the HIP runtime on this image --
+# the task environment's statement, also relied on in bench.py -- and either way the launchers are children: nothing here is exec'ed.)
 TWO_RANK = {"proc": None, "log": None}
 RCCL_WS1 = {"proc": None, "log": None}
 

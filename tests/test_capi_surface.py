@@ -120,6 +120,45 @@ def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
             assert body.count("v_readlane_b32") < 32, (variant, body.count("v_readlane_b32"))
 
 
+def test_quad_kernel_isa_keeps_its_spill_free_inner_loops(tmp_path):
+    """ISA regression for the four-lanes-per-environment kernels: the fp64 build sits at the 512-register limit and
+    hipcc 7.2's spill code has produced wrong fp64 results on this kernel before.  fp32: no scratch at all.
+    fp64 (coefficient blocks in LDS): at most 96 bytes of scratch, none of it touched inside the sub-step loops (window-level
+    bookkeeping only), and the quad_perm DPP moves stay 32-bit -- gfx950 implements 64-bit DPP for row_newbcast only."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("hipcc not available")
+    csrc = ROOT / "greenlight-gym2_amd" / "csrc"
+    out = tmp_path / "glgym.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                           "--offload-arch=gfx950", "-std=c++17",
+                           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(csrc / "glgym.hip")])
+    s = out.read_text()
+    for variant, max_scratch in (("step_kernel_quadIfLb1E", 0), ("step_kernel_quadIfLb0E", 0), ("step_kernel_quadIdLb1E", 96),
+                                 ("step_kernel_quadIdLb0E", 96)):
+        m = re.search(r"^(_ZN\S*" + variant + r"\S*):", s, flags=re.M)
+        body = s[m.start():]
+        body = body[:body.index(".Lfunc_end")]
+        desc = s[s.index(".amdhsa_kernel " + m.group(1)):]
+        desc = desc[:desc.index(".end_amdhsa_kernel")]
+        assert "v_mfma" not in body
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1)) <= max_scratch, variant
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1)) <= 512, variant
+        assert not re.search(r"v_mov_b64_dpp|v_mov_b64.*quad_perm", body), variant
+        # no scratch access inside the innermost (sub-step) loops: walk the blocks, track the loop depth the compiler annotates
+        depth = 0
+        for line in body.split("\n"):
+            d = re.search(r"Depth=(\d)", line)
+            if d and ("in Loop" in line or "Loop Header" in line):
+                depth = int(d.group(1))
+            elif re.match(r"^\.LBB\d+_\d+:\s*$", line):
+                depth = 0
+            if "scratch_" in line:
+                assert depth < 3, (variant, line.strip())
+
+
 def test_scheme_table_and_default_sub_step_counts():
     """Host-side scheme constants agree with include/glgym.h, and the nominal sub-step keeps its length when dt changes
     (multiples of the scheme's tier-2b window: RK4 -> 4, Bogacki-Shampine -> 3, midpoint -> 4)."""

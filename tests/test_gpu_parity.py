@@ -75,6 +75,12 @@ def test_evalF_signature_and_value(models, golden, oracle):
     m_def.close()
     print(f"fp64 RK4 vs tight one-step solutions: n_sub 256 {scaled_err(got64[ok], XT[ok]):.2e}, default 240 {e_def:.2e}")
     assert e_def < 3.6e-5
+    # the PARITY configuration (include/glgym.h): n_sub 480 sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances
+    m_par = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=480)
+    e_par = scaled_err(m_par.evalF_batch(X, U, D, P), XT)
+    m_par.close()
+    print(f"fp64 RK4 parity configuration n_sub 480: {e_par:.2e} (BDF rtol = atol = 1e-6 on the same tuples: {scaled_err(g['X_bdf1e6'], XT):.2e})")
+    assert e_par < 1.3e-5
     # batched call with per-row crop parameters == row-by-row calls
     got_b = m64.evalF_batch(X[:16], U[:16], D[:16], P[:16])
     assert scaled_err(got_b, got64[:16]) < 1e-12
