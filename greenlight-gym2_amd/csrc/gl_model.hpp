@@ -1434,7 +1434,7 @@ template <class T, bool PIPE> struct RhsStage {
         slow_coef<T>(ym, s, m, cr, q);
     }
 };
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_F64_INLINE)
+#if defined(__HIP_DEVICE_COMPILE__)
 template <bool PIPE> struct RhsStage<double, PIPE> {
     static constexpr bool UNIFORM_CALLS = true;
     // once per integration: the per-env-step coefficients, the crop constants and (uniform) the model constants
@@ -1602,11 +1602,6 @@ template <> struct RkVec<float> {
 #ifndef SC_MAX_REFINE
 #define SC_MAX_REFINE 64
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GL_COEF_FENCE(on) do { if (on) asm volatile("" : : "v"(&s) : "memory"); } while (0)     /* the address escapes: no forwarding */
-#else
-#define GL_COEF_FENCE(on) do { } while (0)
-#endif
 // After a control jump the fast states legitimately move by kelvins within seconds (the estimate decays 5x per window,
 // e.g. 0.16 K -> 0.034 -> 0.006 after a 0 -> 1 actuator jump at n_sub = 320): the estimate tolerance is SC_GRACE_MUL x
 // looser during the first SC_GRACE_S seconds of an env-step.  An instability keeps growing and is caught after that.
@@ -1688,10 +1683,7 @@ template <class T> GL_HD void etd_coefs(T a, T h, EtdCoef<T>& c)
 #define SC_PRE_MARGIN 1.02
 #define SC_PRE_MAX 2.0
 
-// LDSCOEF = true: the per-env-step coefficient block `s` lives in LDS (the two-waves-per-SIMD build of step_kernel: 69 registers
-// less per lane).  A compiler-level memory fence in front of every stage makes hipcc RE-READ the coefficients there (merged into
-// ds_read_b64 / b128 where adjacent) instead of hoisting 69 loads out of the loops and spilling them to scratch again.
-template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool LDSCOEF = false>
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                     int n_sub, T* del, ScStat<T>& st)
 {
@@ -1756,7 +1748,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
         T lam = (it < 0) ? T(0) : hnom;                           // in: nominal sub-step (0: smooth slopes only); out: the rate bound
         int side = capped_prev ? 1 : 0;                           // in: was the window just taken capped?  out: the side bits
-        GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, true, COVEXP>(y, q, s, m, cr, k, &lam, &side);
+        rhs_stage<T, PIPE, true, COVEXP>(y, q, s, m, cr, k, &lam, &side);
         if (it < 0) {
             const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
             if (sc > T(1)) {                                      // (a NaN rate leaves the nominal count)
@@ -1845,21 +1837,21 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     accW = ec.f1 * n1;
                     acc[5] = k[5]; xs[5] = y[5] + h2 * k[5] - T(0.5) * dWa; xs[6] = w0 + dWa;
                 }
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
                 stage_in(false, h2);
                 if (COVEXP) {
                     const T dWb = ec.e2m1 * w0 + ec.q * k[6];
                     accW += ec.f2d * k[6];
                     acc[5] += T(2) * k[5]; xs[5] = y[5] + h2 * k[5] - T(0.5) * dWb; xs[6] = w0 + dWb;
                 }
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
                 stage_in(false, h);
                 if (COVEXP) {
                     const T dWc = ec.e2m1 * w0 + ec.e2 * dWa + ec.q * (T(2) * k[6] - n1);
                     accW += ec.f2d * k[6];
                     acc[5] += T(2) * k[5]; xs[5] = y[5] + h * k[5] - T(0.5) * dWc; xs[6] = w0 + dWc;
                 }
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 = k4 for the constant-rate states
                     if (!(COVEXP && p == 3))
@@ -1886,7 +1878,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     accW = ec.f1 * n1;
                     acc[5] = k[5]; xs[5] = y[5] + h2 * k[5] - T(0.5) * dWa; xs[6] = w0 + dWa;
                 }
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)                   // stage input y + h (2 k2 - k1) = y + 2h k2 - h k1 (acc holds k1)
                     if (p != 3)
@@ -1898,7 +1890,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     xs[5] = y[5] + h * (T(2) * k[5] - acc[5]) - T(0.5) * dWb; xs[6] = w0 + dWb;
                     acc[5] += T(4) * k[5];
                 }
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)                   // k1 = k2 = k3 for the constant-rate states
                     if (p != 3)
@@ -1916,7 +1908,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)
                     RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
@@ -1941,7 +1933,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) keep[j] = est[j];
                 state_now();
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);
+                rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);
                 sub_step();
                 n_steps -= (act || fin || (flags & SC_FLAG_CAP)) ? 0 : 1;
 #pragma unroll
@@ -1952,7 +1944,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         } else {
             for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
                 state_now();
-                GL_COEF_FENCE(LDSCOEF); rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);                // same tier 2b
+                rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);                // same tier 2b
                 sub_step();
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
@@ -2003,7 +1995,7 @@ template <class T> GL_HD bool all_finite(const T* v)
     return chk == T(0);
 }
 
-template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool LDSCOEF = false>
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                             int n_sub, T* del, bool* failed, int* extra_steps = nullptr, bool verify = false,
                             int* first_flags = nullptr)
@@ -2022,7 +2014,7 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
         ScStat<T> st;
         T tmp[NX];
         T* dst = UNIFORM ? tmp : del;
-        rk_delta<T, PIPE, ORDER, WIN, LDSCOEF>(x0, s, m, cr, dt, n, dst, st);
+        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, dst, st);
         if (!done) {
             if (UNIFORM) {
 #pragma unroll

@@ -229,23 +229,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         s_reg.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
         s_reg.tPipeSet = tPipe;
     }
-    // -DGL_OCC2_LDS_COEF (experiment, round 3; measured and NOT adopted): in the OCC = 2 build the coefficient block goes to LDS,
-    // one padded record per lane (17 KB per wave, 8 waves per CU = 139 KB), and the integrator re-reads it stage by stage
-    // (rk_delta<LDSCOEF>; 68-word records: the 16-byte reads of eight consecutive lanes fall into eight different bank groups).
-    // An FMA with an LDS-sourced coefficient costs 4.2 cycles against 2.7 at two waves per SIMD when read 16 bytes at a time one
-    // block ahead (profiles/r03_microbench_lds_b128.txt) -- but the block is not where the registers go: with all 69
-    // coefficients in LDS the kernel still needs 256 registers + 272 B of scratch (the integrator's six 28-entry state arrays
-    // and the 45 tier-2b values are ~255 on their own), and it runs 0.61x / 0.80x / 0.89x the one-wave build at B = 131 072 /
-    // 262 144 / 524 288 (profiles/r03_occupancy2_lds_coef.txt).
-#ifdef GL_OCC2_LDS_COEF
-    constexpr bool LDSCOEF = OCC == 2 && sizeof(T) == 4;
-#else
-    constexpr bool LDSCOEF = false;
-#endif
-    struct alignas(16) CoefRec { StepCoef<T> s; char pad[(272 > sizeof(StepCoef<T>)) ? 272 - sizeof(StepCoef<T>) : 16]; };
-    __shared__ CoefRec sh_coef[LDSCOEF ? WAVE : 1];
-    if (LDSCOEF) sh_coef[lane].s = s_reg;
-    const StepCoef<T>& s = LDSCOEF ? sh_coef[lane].s : s_reg;
+    const StepCoef<T>& s = s_reg;
     // the applied control is final here (self.u is set before evalF and survives a failed integration, tomato_env.py:117-123):
     // store it now and re-read the three entries the reward needs afterwards, so that no u[] stays live across the integrator
     if (live) {
@@ -255,7 +239,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
     T del[NX];
     bool bad;
     int extra_steps, first_flags = 0;
-    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value, LDSCOEF>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags);
+    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags);
     const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)

@@ -804,8 +804,9 @@ static double dsat_vp(double t) { return sat_vp(t) * 17.2694 * 238.3 / ((t + 238
  * ---------------------------------------------------------------------------------- */
 int gl_sc_exp = 1;
 int gl_sc_prescale = 1;
-int gl_sc_emc = 0;
-int gl_sc_pred0 = 0;
+/* (Tried for the window-length error and removed, round 4: an Euler-Maclaurin end correction of cBuf's midpoint quadrature and a
+ * forward-Euler predictor for the first window's tier-2b midpoint -- neither touches the one tuple that carries that error, the second
+ * costs 1e-5 on the soil chain: DESIGN.md 2.6.) */
 #define SC_PRE_MARGIN 1.02
 #define SC_PRE_MAX 2.0
 /* E = e^z, E2 = e^(z/2), Q = (h/2) phi1(z/2), f1 = h (phi1 - 3 phi2 + 4 phi3), f2 = h (phi2 - 2 phi3), f3 = h (4 phi3 - phi2)
@@ -1050,15 +1051,9 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
     int flags = 0;
     const int n_grace = (int)ceil(SC_GRACE_S / hw);
     memset(dprev, 0, sizeof dprev);
-    /* Round 4: the first window's tier-2b midpoint is predicted too -- with the derivative of the pre-pass (a forward-Euler step over
-     * the window) where later windows use the previous window's increment.  After a control jump the first window is where the slow
-     * sub-expressions' inputs (tCan, tAir, co2Air) move fastest; evaluating it at the window START was the largest single term of the
-     * window-length error (cBuf on the tight fixture: 3.5e-5 at 11 s windows). */
-    if (gl_sc_prescale && gl_sc_pred0) for (int i = 0; i < GL_NX; ++i) dprev[i] = hw * k1[i];
     x[23] = harvest_flow_ref(x[23], p[144], 0.5 * hw);
     x[25] = harvest_flow_ref(x[25], p[145], 0.5 * hw);
     int side_prev[3] = {0, 0, 0}, capped_prev = 0;
-    double em_s = 0.0, em_f0 = 0.0, em_f1 = 0.0, em_f2 = 0.0;
     /* n_win windows + one closing evaluation at the final state (it == n_win): the error estimate of the last sub-step and
      * the branch invariant of the last window (round 2 left that tail unchecked) */
     for (int it = 0; it <= n_win; ++it) {
@@ -1146,17 +1141,6 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
             n_steps += 1.0;
         }
         for (int i = 0; i < GL_NX; ++i) dprev[i] = x[i] - xw[i];
-        if (gl_sc_emc) {
-            /* Euler-Maclaurin end correction (round 4).  The carbohydrate buffer is a pure quadrature of the tier-2b rate dBuf held
-             * at the window midpoints: the composite midpoint rule is off by  hw^2/24 (f'(T) - f'(0)) + O(hw^4)  -- the one
-             * place where the window length showed (cBuf is small against its flows: 3.5e-5 at 11 s windows on the tight fixture,
-             * every other state < 8e-6).  f'(0), f'(T) by the one-sided three-point formulas on the first / last three midpoint
-             * values:  f'(0) = (-2 f1 + 3 f2 - f3) / hw,  f'(T) = (2 fN - 3 fN-1 + fN-2) / hw. */
-            const double f = k1[22];                  /* the window's dBuf (constant over the window) */
-            if (it == 0) em_s = -2.0 * f; else if (it == 1) em_s += 3.0 * f; else if (it == 2) em_s -= f;
-            em_f2 = em_f1; em_f1 = em_f0; em_f0 = f;
-            if (it == n_win - 1 && n_win >= 3) x[22] += (hw / 24.0) * ((2.0 * em_f0 - 3.0 * em_f1 + em_f2) - em_s);
-        }
         const double hh = (it == n_win - 1) ? 0.5 * hw : hw;
         x[23] = harvest_flow_ref(x[23], p[144], hh);
         x[25] = harvest_flow_ref(x[25], p[145], hh);
