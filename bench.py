@@ -386,11 +386,11 @@ def main():
         # executed work: the recorded PMC instruction counts of the default workload, scaled to this run's batch / n_sub,
         # over the kernel time measured live with HIP events on the launch stream
         variant = f"{args.dtype}_{args.scheme}" + ("_config5" if args.uncertainty else "")
-        # batches up to 16 384 -- and fp64 batches beyond 28 672 -- run the four-lanes-per-environment kernel (glgym.hip launch_step;
+        # batches up to 16 384 -- and every fp64 batch -- run the four-lanes-per-environment kernel (glgym.hip launch_step;
         # GLGYM_LAYOUT overrides): another kernel, other counters
         layout = os.environ.get("GLGYM_LAYOUT", "")
         quad = args.scheme == "rk4" and not args.uncertainty and (
-            layout == "quad" or (layout == "" and (B <= 16384 or (args.dtype == "f64" and B > 28672))))
+            layout == "quad" or (layout == "" and (B <= 16384 or args.dtype == "f64")))
         if quad:
             variant += "_quad"
         pmc = load_pmc(variant + "_b65536") if (quad and B > 16384) else None      # recorded at this size (four rounds of waves)

@@ -1410,20 +1410,17 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
         return GLGYM_OK;
     }
     // Layout by batch size: four lanes per environment while the batch leaves SIMDs idle (GLGYM_LAYOUT = one | quad overrides).
-    // The quad kernels integrate classical RK4 of the default ODE with shared crop parameters and the interlights off.  fp64: the
-    // coefficient blocks live in LDS (rk_delta_quad<LDSQ>) -- with them in registers the kernel needed 512 registers + 336 B of
-    // scratch and hipcc 7.2's spill code failed on it (failed integrations from the reset state; correct with a printf in the
-    // loop); in LDS: 479 registers, no scratch, every fp64 parity test green, 5.8 ms per env-step against the mailbox kernel's 8.8 (4.7
-    // against 7.3 with the two-sub-step window, 3.9 with the default parameter block compiled in).  fp64 takes the quad kernel at
-    // LARGE batches too: it has no scratch / mailbox traffic and scales with the batch (16 384 environments per 4.07 ms round: 16.2 ms
-    // at 65 536), where the one-lane kernel goes memory-bound (7.3 ms up to 16 384, 8.9 at 32 768, 17.7 at 65 536); only between
-    // 16 384 and 28 672 is one lane per environment ahead (7.9 against 8.4 ms).  profiles/r03_small_batch_rate_fp64.txt
+    // The quad kernels integrate RK4 of the default ODE with shared crop parameters and the interlights off.  fp64: the coefficient
+    // blocks live in LDS (rk_delta_quad<LDSQ>; with them in registers hipcc 7.2's spill code failed on this kernel), and fp64 takes
+    // the quad kernel at EVERY batch size: it has no mailbox traffic and scales with the batch in rounds of 16 384 environments
+    // (2.86 ms per round; B = 65 536: 11.7 ms, 5.6e6 env-steps/s), where the one-lane fp64 kernel goes memory-bound (7.8 ms at
+    // 24 576 with 6.4 GB of traffic).  profiles/r04_f64_rk4*_pmc_summary.csv, r04_variant_f64_b65536_bench_line.json
     {
         const char* le_ = std::getenv("GLGYM_LAYOUT");          // read per launch: tests and tools switch it between steps
         const int layout_env = !le_ ? 0 : (le_[0] == 'q' ? 2 : 1);
         const bool quad_ok = h->scheme == GLGYM_SCHEME_RK4 && !a->crop_p && !m.intLampActive;
         const int b_small = 4 * h->n_simd * 4;                   // 16 384 on MI355X: one quad-kernel round
-        const bool by_size = a->B <= b_small || (sizeof(T) == 8 && 4 * a->B > 7 * b_small);
+        const bool by_size = a->B <= b_small || sizeof(T) == 8;    // fp64: always (round 4: 5.7 ms against the mailbox kernel's 7.8 at B = 24 576)
         if (quad_ok && (layout_env == 2 || (layout_env == 0 && by_size))) {
             const dim3 qgrid((4 * a->B + WAVE - 1) / WAVE);
             const bool qdef = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;

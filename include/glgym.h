@@ -239,8 +239,8 @@ int glgym_set_obs_modules(glgym_handle h, const int32_t* modules, int n);
 int glgym_obs_dim(glgym_handle h, int Np);
 
 /* Device pointers; asynchronous on `stream` (a hipStream_t, NULL = default stream).
- * glgym_step picks its kernel layout per launch: one lane per environment, or -- classical RK4, shared crop parameters,
- * interlights off; B <= 16 384, and in fp64 also B > 28 672 -- four lanes per environment (csrc/gl_model_quad.hpp).  Same scheme
+ * glgym_step picks its kernel layout per launch: one lane per environment, or -- RK4, shared crop parameters,
+ * interlights off; B <= 16 384, and in fp64 at every batch size -- four lanes per environment (csrc/gl_model_quad.hpp).  Same scheme
  * decision for decision, results equal to rounding.  Environment variable GLGYM_LAYOUT = one | quad overrides (read per launch). */
 int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream);
 int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream);

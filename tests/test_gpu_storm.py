@@ -188,7 +188,7 @@ def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
 
 
 def test_fp64_large_batches_take_the_quad_kernel_and_equal_one_lane_per_environment(golden):
-    """fp64 batches beyond 28 672 are dispatched to the four-lanes-per-environment kernel as well (it has no scratch / mailbox
+    """fp64 batches of every size are dispatched to the four-lanes-per-environment kernel (it has no scratch / mailbox
     traffic and scales with the batch; glgym.hip launch_step).  40 000 environments -- 2.4 rounds of the quad kernel, a ragged last
     wave -- three env-steps from different start days with random actions: the default dispatch against GLGYM_LAYOUT=one, states
     to fp64 rounding, rewards, terminal flags and integrator events equal."""

@@ -46,10 +46,10 @@ variant f32_rk4 "step_kernel<float, false, true, false, 0, 1>" 240 F32
 variant f32_rk3 "step_kernel<float, false, true, false, 2, 1>" 270 F32 --scheme rk3
 variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 376 F32 --scheme rk2
 variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 240 F32 --uncertainty 0.2
-# fp64 at B = 65 536 takes the four-lanes-per-environment kernel by default (glgym.hip launch_step); the one-lane fp64 kernel is
-# recorded where it is the default: 16 384 < B <= 28 672
+# fp64 RK4 takes the four-lanes-per-environment kernel at every batch size (glgym.hip launch_step); the one-lane fp64 (mailbox) kernel
+# -- what the other fp64 schemes / ODE_pipe / per-env crop blocks still run -- is recorded with GLGYM_LAYOUT=one
 PBATCH=24576
-variant f64_rk4 "step_kernel<double, false, false, false, 0, 1>" 240 F64 --dtype f64 --batch 24576
+GLGYM_LAYOUT=one variant f64_rk4 "step_kernel<double, false, false, false, 0, 1>" 240 F64 --dtype f64 --batch 24576
 PBATCH=65536
 variant f64_rk4_quad_b65536 "step_kernel_quad<double, true>" 240 F64 --dtype f64
 # the four-lanes-per-environment kernels (what batches up to 16 384 run), recorded at B = 4 096 (config 2 in fp64)
