@@ -88,7 +88,7 @@ def workload_label(args, B, world):
 
 DEFAULT_SCHEME = "rk4"
 STAGES = {"rk4": 4, "rk2": 2, "rk3": 3}
-N_SUB = {"rk4": 240, "rk2": 376, "rk3": 270}
+N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270}
 
 
 def cpu_baseline(n_sub: int, budget_s: float = 8.0):
@@ -204,8 +204,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
     ap.add_argument("--scheme", default=DEFAULT_SCHEME, choices=["rk4", "rk2", "rk3"],
-                    help="sub-stepper: RK4 (n_sub 240), the three-stage third-order scheme (270) or explicit midpoint (376); include/glgym.h")
-    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 240 rk4 / 270 rk3 / 376 rk2)")
+                    help="sub-stepper: RK4 (n_sub 240), the three-stage third-order scheme (270) or the midpoint rule (336); include/glgym.h")
+    ap.add_argument("--n-sub", type=int, default=None, help="sub-steps per 900 s env-step (default: 240 rk4 / 270 rk3 / 336 rk2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-obs", action="store_true", help="skip the observation-assembly kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1632,7 +1632,7 @@ template <class T> struct ScStat {
 //     w_a = E2 w + Q N1,   w_b = E w + h phi1 (2 Na - N1),   w+ = E w + f1 N1 + 4 f2 Na + f3 Nb
 // -- for a = 0 Kutta's third-order method (stages at 0, h/2, h; weights 1/6, 4/6, 1/6), whose last stage against the next sub-step's
 // first one gives the same kind of embedded estimate as RK4's: e = h/6 |k3 - k1'| (the second-order comparison solution
-// y + h (k1/6 + 4 k2/6 + k1'/6)).  The integrator keeps slot 5 = tTop - tCovIn (the wet inner face as a difference to its air node, full
+// y + h (k1/6 + 4 k2/6 + k1'/6)).  ORDER = 2 is the exponential midpoint rule (ETD2RK):  w_a = E2 w + Q N1,  w+ = E w + h phi1 Na.  The integrator keeps slot 5 = tTop - tCovIn (the wet inner face as a difference to its air node, full
 // relative precision in fp32): its increments are assembled from the increments of tTop, sigma (classical part, returned by
 // rhs_fast<COVEXP> in dx[5]) and w:  d z5 = d tTop - (d sigma + d w) / 2.
 // phi3 by its Taylor series (no cancellation; terms for 1 ulp of T at |z| <= 3), phi2, phi1, e^z by the stable downward recurrence
@@ -1687,9 +1687,9 @@ template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                     int n_sub, T* del, ScStat<T>& st)
 {
-    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (RK4) or 3 (three-stage third-order scheme), both with the cover conduction exponential, or 2 (explicit midpoint)");
+    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (RK4), 3 (three-stage third-order scheme) or 2 (midpoint rule), all with the cover conduction exponential");
     using M = Math<T>;
-    constexpr bool COVEXP = ORDER == 4 || ORDER == 3;
+    constexpr bool COVEXP = true;                  // every scheme of the family integrates the cover conduction exactly (round 4)
     constexpr bool UNIFORM = RhsStage<T, PIPE>::UNIFORM_CALLS;
     const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
     const T est_fac = T(1.0 / 6.0);
@@ -1778,7 +1778,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
             for (int j = 0; j < SC_NFAST; ++j) {
                 // (the ETD component's estimate carries f3 instead of h/6)
-                const T wj = (COVEXP && sc_fast(j) == 6) ? T(sc_itol(j)) * ec.w3 : T(sc_itol(j));
+                const T wj = (ORDER != 2 && sc_fast(j) == 6) ? T(sc_itol(j)) * ec.w3 : T(sc_itol(j));
                 worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * wj);
             }
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
@@ -1903,15 +1903,28 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     del[5] += h6 * (acc[5] + k[5]) - T(0.5) * dW;
                 }
             } else {
+                // the midpoint rule of the family (ETD2RK): k2 = f(y + h/2 k1), y+ = y + h k2;  w_a = E2 w + Q N1,  w+ = E w + h phi1 Na
 #pragma unroll
                 for (int j = 0; j < SC_NFAST; ++j) est[j] = -k[sc_fast(j)];
+                const T w0 = y[6];
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR_FAST; ++p)
-                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
-                rhs_stage<T, PIPE>(xs, q, s, m, cr, k);
+                    if (p != 3)
+                        RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.sp(h2) * r.ld(k)); });
+                {
+                    const T dWa = ec.e2m1 * w0 + ec.q * k[6];
+                    xs[5] = y[5] + h2 * k[5] - T(0.5) * dWa; xs[6] = w0 + dWa;
+                }
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
 #pragma unroll
                 for (int p = 0; p < GL_NPAIR; ++p)
-                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
+                    if (p != 3)
+                        RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
+                {
+                    const T dW = ec.em1 * w0 + ec.hp1 * k[6];
+                    del[6] += dW;
+                    del[5] += h * k[5] - T(0.5) * dW;
+                }
             }
             n_steps += ((flags & SC_FLAG_CAP) || fin) ? 0 : 1;
         };

@@ -21,7 +21,7 @@ class GreenLight:
     def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=None, device=0, variant="ode", scheme="rk4"):
         """nd = 10, or 14 as in experiments/gl_predefined_controls.py:95 (rows carry the measured pipe columns).
         variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14).
-        scheme = "rk4" (RK4 with the cover conduction integrated exactly, n_sub 240), "rk3" (three-stage third-order scheme, same exact conduction, 270) or "rk2" (explicit midpoint, 376): include/glgym.h."""
+        scheme = "rk4" (RK4 with the cover conduction integrated exactly, n_sub 240), "rk3" (three-stage third-order scheme, same exact conduction, 270) or "rk2" (midpoint rule, same exact conduction, 336): include/glgym.h."""
         self._lib = L.load()
         if scheme not in L.SCHEMES:
             raise ValueError("scheme must be 'rk4', 'rk3' or 'rk2'")

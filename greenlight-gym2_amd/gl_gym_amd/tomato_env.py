@@ -165,7 +165,7 @@ class TomatoVecEnv:
                  u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
-        scheme / n_sub: "rk4" (RK4 with the cover conduction integrated exactly, default n_sub 240), "rk3" (three-stage third-order scheme, same exact conduction, 270) or "rk2" (explicit midpoint, 376);
+        scheme / n_sub: "rk4" (RK4 with the cover conduction integrated exactly, default n_sub 240), "rk3" (three-stage third-order scheme, same exact conduction, 270) or "rk2" (midpoint rule, same exact conduction, 336);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()

@@ -69,7 +69,7 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
 /* Sub-stepping scheme of glgym_step / glgym_evalF (greenlight_model.cpp:46-63 uses CVODES BDF, error-controlled and
  * implicit; any scheme that meets the accuracy bar against it is admissible).  n_sub is the NOMINAL (= minimum) number
  * of sub-steps per env-step.  Both schemes are stability-controlled per environment: a bound on the fastest local
- * relaxation rate (cover pair 0.67-0.72 1/s -- RK2 / RK3 only; top-compartment exchange up to 1.1 1/s in storms; a wet screen pinned to
+ * relaxation rate (top-compartment exchange 0.2-0.7 1/s, up to 1.1 1/s in storms; a wet screen pinned to
  * the air temperature 3 ... 15 1/s) is evaluated once per window of 1-4 nominal sub-steps and the environment takes as
  * many smaller sub-steps in that window as its scheme's stability interval asks for; an embedded error estimate is the
  * safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 64x the nominal count for more than 120 s,
@@ -87,9 +87,10 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     That window is what sets the accuracy at a given n_sub (max scaled error on the tight one-step tuples, fp64: 3.5e-5 at 240,
  *     8.7e-6 at 480, 3.9e-6 at 720; 10-day rollout 8.5e-6 at 240): for PARITY runs against the reference's solver set n_sub 480,
  *     which sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances (tests/test_gpu_parity.py).
- *   GLGYM_SCHEME_RK2: explicit midpoint (stability interval 2.0): use n_sub 376.  Same stability margin with 30 % fewer
- *     right-hand sides; the slow sub-expressions and the harvest flow are shared by four nominal sub-steps (n_sub is
- *     rounded up to a multiple of 4).  Second order: 1e-4 one-step errors occur after abrupt control changes.
+ *   GLGYM_SCHEME_RK2: the midpoint rule of the same family (ETD2RK on the cover conduction, explicit midpoint elsewhere; stability
+ *     interval 2.0): use n_sub 336.  30 % fewer right-hand sides than RK4; the slow sub-expressions and the harvest flow are shared
+ *     by four nominal sub-steps (n_sub is rounded up to a multiple of 4).  Second order: the least accurate of the three (tight
+ *     one-step tuples 3.2e-5, storm fixture 2.9e-5 in fp64).
  *   GLGYM_SCHEME_RK3: the three-stage, third-order member of the same exponential family (Cox-Matthews ETD3RK on the cover
  *     conduction, Kutta's RK3 -- stages at 0, h/2, h -- on every other state; stability interval 2.513): use n_sub 270.  19 % fewer
  *     right-hand sides than RK4 at RK4-like accuracy (the error of both is set by the slow tier's window, not by the order); the

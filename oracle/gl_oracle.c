@@ -667,7 +667,7 @@ extern int gl_sc_exp;
 static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
                             int pipe, double h, int em, double *est, double *est_ar, double *est_w);
 /* order = 4 RK4 / 3 the three-stage third-order scheme (both with the cover pair's conduction integrated exactly: gl_sc_exp,
- * rk4_exp_substep below), 2 explicit midpoint.  window = number of consecutive sub-steps that
+ * rk4_exp_substep below), 2 the midpoint rule of the same family.  window = number of consecutive sub-steps that
  * share one tier-2b evaluation and one harvest half-step pair (1 = every sub-step). */
 static void rk_lagged_impl(const double *x0, const double *u, const double *d, const double *p, double dt, int n_sub,
                            double *x1, int pipe, int order, int window)
@@ -701,6 +701,9 @@ static void rk_lagged_impl(const double *x0, const double *u, const double *d, c
         } else if (order == 3) {   /* GLGYM_SCHEME_RK3: the exponential three-stage scheme (rk4_exp_substep, bit 16) */
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, gl_sc_exp | 16, NULL, NULL, NULL);
+        } else if (gl_sc_exp) {   /* GLGYM_SCHEME_RK2: the exponential midpoint rule (rk4_exp_substep, bit 32) */
+            rhs_lagged(x, ym, u, d, p, k1, pipe);
+            rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, gl_sc_exp | 32, NULL, NULL, NULL);
         } else {
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
@@ -976,6 +979,7 @@ double gl_rate_bound(const double *x, const double *u, const double *d, const do
 static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
                             int pipe, double h, int em, double *est, double *est_ar, double *est_w)
 {
+    const int two = (em & 32) != 0;        /* exponential midpoint rule (ETD2RK): a = E2 y + Q N(y),  y+ = E y + h phi1 N(a) */
     const int three = (em & 16) != 0;      /* Cox-Matthews ETD3RK (for a = 0: Kutta's third-order method): a = E2 y + Q N(y),
                                             * b = E y + h phi1 (2 N(a) - N(y)),  y+ = E y + f1 N(y) + 4 f2 N(a) + f3 N(b) */
     double ar[GL_NX] = {0}, C[GL_NX][7], y0[GL_NX], ya[GL_NX], N1[GL_NX], Na[GL_NX], Nb[GL_NX], Nc[GL_NX];
@@ -993,7 +997,10 @@ static void rk4_exp_substep(double *x, const double *k1, const double *ym, const
     NONLIN(k1, y0, N1);
     for (int i = 0; i < GL_NX; ++i) ya[i] = C[i][1] * y0[i] + C[i][2] * N1[i];
     TO_X(ya, xs); rhs_lagged(xs, ym, u, d, p, k2, pipe); NONLIN(k2, ya, Na);
-    if (three) {
+    if (two) {
+        for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][6] * Na[i];
+        for (int i = 0; i < GL_NX; ++i) Nc[i] = 2.0 * Na[i] - N1[i];                  /* the comparison stage of the estimate */
+    } else if (three) {
         for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][6] * (2.0 * Na[i] - N1[i]);
         TO_X(yy, xs); rhs_lagged(xs, ym, u, d, p, k3, pipe); NONLIN(k3, yy, Nc);         /* Nc = the last stage N(b) */
         for (int i = 0; i < GL_NX; ++i) yy[i] = C[i][0] * y0[i] + C[i][3] * N1[i] + 4.0 * C[i][4] * Na[i] + C[i][5] * Nc[i];
@@ -1014,7 +1021,7 @@ static void rk4_exp_substep(double *x, const double *k1, const double *ym, const
             est[j] = (i == 5) ? kc[3] - kc[5] : (i == 7) ? kc[2] - kc[7] : (i == 20) ? kc[2] - kc[20] : kc[i];
         }
         memcpy(est_ar, ar, sizeof ar);
-        for (int j = 0; j < 9; ++j) est_w[j] = C[SC_FAST[j]][5] / (h / 6.0);
+        for (int j = 0; j < 9; ++j) est_w[j] = two ? 1.0 : C[SC_FAST[j]][5] / (h / 6.0);
     }
 }
 
@@ -1028,9 +1035,9 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
     double est[9] = {0}, est_w[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, est_ar[GL_NX] = {0};
     const double S = SC_SAFETY * (order == 4 ? 2.785 : order == 3 ? 2.5127 : 2.0);
     const double est_fac = 1.0 / 6.0;
-    /* what is integrated exponentially: the cover conduction in RK4 (order 4) and in the three-stage scheme (order 3; bit 16 selects
-     * its formulas in rk4_exp_substep); gl_sc_exp = 0 (studies): classical RK4 / Kutta's RK3 */
-    const int em = (order == 4) ? gl_sc_exp : (order == 3) ? (gl_sc_exp | 16) : 0;
+    /* what is integrated exponentially: the cover conduction, in every scheme -- RK4 (order 4), the three-stage scheme (order 3; bit 16
+     * selects its formulas in rk4_exp_substep) and the midpoint rule (order 2; bit 32); gl_sc_exp = 0 (studies): the classical schemes */
+    const int em = (order == 4) ? gl_sc_exp : (order == 3) ? (gl_sc_exp | 16) : (order == 2) ? (gl_sc_exp | 32) : 0;
     int n_win = (n_sub + window - 1) / window;
     memcpy(x, x0, sizeof x);
     if (gl_sc_prescale) {

@@ -13,7 +13,7 @@ from test_jump_fixture import judge, sce
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("rk4", 240), ("rk3", 270), ("rk2", 376)]
+SCHEMES = [("rk4", 240), ("rk3", 270), ("rk2", 336)]
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

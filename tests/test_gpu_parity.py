@@ -129,7 +129,7 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme):
     B = 64                                    # 64 identical envs: also checks lane-independence
     n_steps = len(acts)
     if dtype == "float64":
-        # explicit midpoint at n_sub = 376: second order, 6.5e-6 / 7.7e-6 in fp64; RK4 at its round-4 nominal count of 240
+        # the midpoint rule at n_sub = 336: second order, 7.6e-6 / 9.6e-6 in fp64; RK4 at its round-4 nominal count of 240
         # (3.75 s sub-steps, 7.5 s tier-2b windows): 3.8e-6 / 6.0e-6; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6
         tol = 1e-5
     env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
@@ -569,7 +569,7 @@ def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
     X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
     for dtype, tol_o, tol_t in (("float64", 1e-9, 3e-5), ("float32", 3e-5, 4e-5)):
         m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk2")
-        assert m.n_sub == 376                  # the scheme's default nominal count
+        assert m.n_sub == 336                  # the scheme's default nominal count
         m.set_n_sub(360)
         got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
         ref = np.array([oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, 360, 2, 4)[0] for i in range(len(X))])
@@ -598,7 +598,7 @@ def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
         m.set_n_sub(268)                       # n_sub is rounded up to a multiple of the 3-sub-step window
         np.testing.assert_array_equal(np.array(m.evalF(X[0], U[0], D[0], P[0])), got[0])
         m.close()
-    assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3").n_sub == 90 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2").n_sub == 376
+    assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3").n_sub == 90 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2").n_sub == 336
 
 
 @pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 3), ("rk2", 2, 4), ("rk3", 3, 3)])

@@ -12,7 +12,7 @@ from conftest import scaled_err
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("rk4", 240), ("rk2", 376), ("rk3", 270)]            # the schemes' default nominal sub-step counts
+SCHEMES = [("rk4", 240), ("rk2", 336), ("rk3", 270)]            # the schemes' default nominal sub-step counts
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

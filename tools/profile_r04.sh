@@ -44,7 +44,7 @@ grep "^{" $OUT/bench_stats.log > $OUT/r04_rk4_bench_line.json
 f=$(ls $OUT/stats/*/*kernel_stats.csv | head -1); python tools/condense_stats.py $f $OUT/r04_rk4_bench_kernel_stats.csv; rm -rf $OUT/stats
 variant f32_rk4 "step_kernel<float, false, true, false, 0, 1>" 240 F32
 variant f32_rk3 "step_kernel<float, false, true, false, 2, 1>" 270 F32 --scheme rk3
-variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 376 F32 --scheme rk2
+variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 336 F32 --scheme rk2
 variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 240 F32 --uncertainty 0.2
 # fp64 RK4 takes the four-lanes-per-environment kernel at every batch size (glgym.hip launch_step); the one-lane fp64 (mailbox) kernel
 # -- what the other fp64 schemes / ODE_pipe / per-env crop blocks still run -- is recorded with GLGYM_LAYOUT=one
