@@ -364,7 +364,7 @@ def main():
     # layout as the timed batch, on every rank; the state error is max |x - x_truth| / max(|x_truth|, 1e-3 max_t |x_truth|).
     parity = (-1.0, 0.0, None)
     if not args.no_parity:
-        parity = parity_leg(args, dev, "one" if B > 16384 else None)
+        parity = parity_leg(args, dev, "one" if (B > 16384 and args.dtype != "f64") else None)   # (fp64 has one layout)
     # final metric gather: the only collective on this path (RCCL all_gather of 16 doubles per rank)
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
@@ -389,8 +389,7 @@ def main():
         # batches up to 16 384 -- and every fp64 batch -- run the four-lanes-per-environment kernel (glgym.hip launch_step;
         # GLGYM_LAYOUT overrides): another kernel, other counters
         layout = os.environ.get("GLGYM_LAYOUT", "")
-        quad = args.scheme == "rk4" and not args.uncertainty and (
-            layout == "quad" or (layout == "" and (B <= 16384 or args.dtype == "f64")))
+        quad = args.dtype == "f64" or (not args.uncertainty and (layout == "quad" or (layout == "" and B <= 16384)))
         if quad:
             variant += "_quad"
         pmc = load_pmc(variant + "_b65536") if (quad and B > 16384) else None      # recorded at this size (four rounds of waves)

@@ -467,6 +467,7 @@ template <class T> struct StepCoef {
     // ODE_pipe variant only (ode.hpp:184-189): track the measured pipe temperature d10 unless d10 < 1 or d12 > 0.
     // Set by the caller after precompute(); dead (and removed by the compiler) in the default ODE instantiations.
     T pipeTrack, tPipeSet;
+    T pipeOde;        // 1: the ODE_pipe variant (only read by kernels that select the variant at run time: gl_model_quad.hpp)
     // stability control (rate_bound in rhs_fast): long-wave part of the diagonal relaxation rate of the two screens and
     // the inner cover face [W m-2 K-1] (4 sigma T^3 x the surface's exchange coefficients, T = 313 K, canopy view
     // factors <= 1), and the complete Gershgorin row of the outer cover face [1/s], which depends on (u, d) only
@@ -586,6 +587,7 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
     s.mcExtAir = uCo2 * m.co2PerFlr;
     s.pipeTrack = T(0);
     s.tPipeSet = T(0);
+    s.pipeOde = T(0);
     {
         const T k4T3 = T(4.0 * 313.15 * 313.15 * 313.15);      // d(T^4)/dT at 40 C (sigma is in the coefficients)
         s.firTh = k4T3 * ((m.bCanThScr + m.bPipeThScr + m.bFlrThScr + m.bLampThScr) * uThBl +
@@ -1023,12 +1025,7 @@ template <class T> struct AirBlock {
 //   harm: the surface's harm gate;  G = L 6.4e-9 gate(dv) [K];  dT = tAir - tSurface;  ddT = d(dT)/dt;
 //   smooth = the surface's rate without the singular slope;  look = how far ahead [s] the reach of dT is extrapolated.
 template <class T>
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __noinline__
-#else
-inline
-#endif
-T sc_pinned_rate(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth, T look)
+GL_HD T sc_pinned_rate_inl(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth, T look)
 {
     using M = Math<T>;
     const T one = T(1), f43 = T(4.0 / 3.0);
@@ -1048,6 +1045,17 @@ T sc_pinned_rate(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth,
     const T sr = (reach > T(1e-12)) ? M::powa(M::max(reach, T(1e-12)), T(1.0 / 3.0)) : T(0);
     sq = M::max(M::max(sq, sr), T(1e-4));
     return pin ? smooth + kq * (G * M::rcp(T(3) * sq * sq) + f43 * sq) - iCap * f43 * hec : smooth;
+}
+// out of line in the one-lane kernels (taken by a handful of lanes per launch; inlined three times it costs registers on the hot path)
+template <class T>
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+inline
+#endif
+T sc_pinned_rate(bool harm, T iCap, T hcoef, T hec, T Gs, T dT, T ddT, T smooth, T look)
+{
+    return sc_pinned_rate_inl<T>(harm, iCap, hcoef, hec, Gs, dT, ddT, smooth, look);
 }
 
 // RATES = true additionally returns in *lam an upper bound on the fastest relaxation rate [1/s] at this state, from
@@ -1337,146 +1345,15 @@ GL_HD constexpr bool gl_const_rate(int i) { return (i >= 10 && i <= 14) || i == 
 constexpr int GL_N_SLOW = 16;
 
 // ---------------------------------------------------------------------------------------------------
-// rhs_stage: how the integrator calls rhs().  fp32: inlined (4 copies per sub-step, everything in registers).
-// fp64 on the device: ONE out-of-line copy.  The fully inlined fp64 step kernel needs > 512 registers per lane and
-// spills VGPR -> AGPR -> scratch plus SGPRs; hipcc 7.2 -O3 then produced wrong results that changed with the
-// optimisation level (fp32 and the host build were unaffected).  Out of line, each function fits its register budget.
+// rhs_stage: how the one-lane integrator calls rhs(): inlined, everything in registers.  (fp64 on the device integrates four
+// lanes per environment -- gl_model_quad.hpp -- since round 4: the fully inlined one-lane fp64 kernel needs > 512 registers per
+// lane, and the out-of-line variant with its LDS mailbox that rounds 2-3 shipped ran at a third of the quad kernel's rate.)
 // ---------------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-// What crosses the call lives in LDS, not on the stack: a per-wave "mailbox" of 8-byte slots, slot j of lane l at
-// gl_lds64[j * 64 + l] (conflict-free ds_read_b64 / ds_write_b64), plus one uniform copy of ModelConst behind it.  With
-// pointer arguments to the caller's locals every stage made ~90 flat loads from scratch and ~40 dependent waits on them:
-// 26 000 cycles per stage for 1 800 instructions.  The kernels that integrate in fp64 are launched with
-// gl_f64_lds_bytes() of dynamic LDS: 73 KB (two waves per CU), 91 KB with per-env crop parameters.
-extern __shared__ double gl_lds64[];
-#endif
-// per-lane slots: stage state in / derivative out (shared), rate bound, StepCoef, SlowCoef; then three uniform slots (ModelConst
-// + the per-env-crop flag); then, only for kernels with per-env crop parameters, the per-lane CropConst
-constexpr int GL_F64_X = 0, GL_F64_K = 0, GL_F64_LAM = NX, GL_F64_SIDE = NX + 1, GL_F64_S = NX + 2;
-constexpr int GL_F64_NS = (int)(sizeof(StepCoef<double>) / 8), GL_F64_NQ = (int)(sizeof(SlowCoef<double>) / 8),
-              GL_F64_NCR = (int)(sizeof(CropConst<double>) / 8), GL_F64_NM = (int)(sizeof(ModelConst<double>) / 8);
-constexpr int GL_F64_Q = GL_F64_S + GL_F64_NS, GL_F64_MSLOT = GL_F64_Q + GL_F64_NQ;
-constexpr int GL_F64_M = GL_F64_MSLOT * 64;                       // uniform block: element f at gl_lds64[GL_F64_M + f]
-constexpr int GL_F64_MSLOTS = (GL_F64_NM + 1 + 63) / 64, GL_F64_CR = GL_F64_MSLOT + GL_F64_MSLOTS;
-constexpr size_t gl_f64_lds_bytes(bool per_env_crop) { return (size_t)(GL_F64_CR + (per_env_crop ? GL_F64_NCR : 0)) * 64 * 8; }
-static_assert(sizeof(StepCoef<double>) % 8 == 0 && sizeof(SlowCoef<double>) % 8 == 0 && sizeof(CropConst<double>) % 8 == 0 &&
-              sizeof(ModelConst<double>) % 8 == 0, "mailbox slots are 8 bytes");
-#if defined(__HIP_DEVICE_COMPILE__)
-
-template <class S> __device__ __forceinline__ void f64_put(const S& v, int slot0)
-{
-    constexpr int N = (int)(sizeof(S) / 8);
-    double t[N];
-    __builtin_memcpy(t, &v, sizeof(S));
-#pragma unroll
-    for (int f = 0; f < N; ++f) gl_lds64[(slot0 + f) * 64 + threadIdx.x] = t[f];
-}
-template <class S> __device__ __forceinline__ void f64_get(S& v, int slot0)
-{
-    constexpr int N = (int)(sizeof(S) / 8);
-    double t[N];
-#pragma unroll
-    for (int f = 0; f < N; ++f) t[f] = gl_lds64[(slot0 + f) * 64 + threadIdx.x];
-    __builtin_memcpy(&v, t, sizeof(S));
-}
-__device__ __forceinline__ void f64_get_model(ModelConst<double>& m)
-{
-    double t[GL_F64_NM];
-#pragma unroll
-    for (int f = 0; f < GL_F64_NM; ++f) t[f] = gl_lds64[GL_F64_M + f];       // same address in every lane: broadcast read
-    __builtin_memcpy(&m, t, sizeof m);
-}
-
-__device__ __forceinline__ void f64_get_crop(CropConst<double>& cr, const ModelConst<double>& m)
-{
-    if (gl_lds64[GL_F64_M + GL_F64_NM] != 0.0) f64_get(cr, GL_F64_CR);        // wave-uniform flag
-    else cr = m.crop;
-}
-
-template <bool PIPE, bool RATES, bool COVEXP>
-__device__ __noinline__ inline void rhs_stage_f64()
-{
-    double x[NX], dx[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x];
-    StepCoef<double> s; SlowCoef<double> q; CropConst<double> cr; ModelConst<double> m;
-    f64_get(s, GL_F64_S); f64_get(q, GL_F64_Q); f64_get_model(m); f64_get_crop(cr, m);
-    double lam = RATES ? gl_lds64[GL_F64_LAM * 64 + threadIdx.x] : 0.0;
-    int side = RATES ? (int)gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] : 0;
-    rhs_fast<double, false, PIPE, RATES, true, COVEXP>(x, q, s, m, cr, dx, RATES ? &lam : nullptr, RATES ? &side : nullptr);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x] = dx[i];
-    if (RATES) { gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = lam; gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] = (double)side; }
-}
-__device__ __noinline__ inline void slow_coef_f64()
-{
-    double ym[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) ym[i] = gl_slow_slot(i) >= 0 ? gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] : 0.0;
-    StepCoef<double> s; CropConst<double> cr; ModelConst<double> m; SlowCoef<double> q;
-    f64_get(s, GL_F64_S); f64_get_model(m); f64_get_crop(cr, m);
-    slow_coef<double>(ym, s, m, cr, q);
-    f64_put(q, GL_F64_Q);
-}
-#endif
-template <class T, bool PIPE> struct RhsStage {
-    static constexpr bool UNIFORM_CALLS = false;
-    static GL_HD void begin(const StepCoef<T>&, const ModelConst<T>&, const CropConst<T>&) {}
-    template <bool RATES, bool COVEXP>
-    static GL_HD void run(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
-                          const CropConst<T>& cr, T* dx, T* lam, int* side)
-    {
-        rhs_fast<T, false, PIPE, RATES, true, COVEXP>(x, q, s, m, cr, dx, lam, side);
-    }
-    static GL_HD void slow(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr,
-                           SlowCoef<T>& q)
-    {
-        slow_coef<T>(ym, s, m, cr, q);
-    }
-};
-#if defined(__HIP_DEVICE_COMPILE__)
-template <bool PIPE> struct RhsStage<double, PIPE> {
-    static constexpr bool UNIFORM_CALLS = true;
-    // once per integration: the per-env-step coefficients, the crop constants and (uniform) the model constants
-    static __device__ void begin(const StepCoef<double>& s, const ModelConst<double>& m, const CropConst<double>& cr)
-    {
-        f64_put(s, GL_F64_S);
-        const bool per_env_crop = &cr != &m.crop;                     // folds after inlining
-        if (per_env_crop) f64_put(cr, GL_F64_CR);
-        gl_lds64[GL_F64_M + GL_F64_NM] = per_env_crop ? 1.0 : 0.0;
-        double t[GL_F64_NM];
-        __builtin_memcpy(t, &m, sizeof m);
-#pragma unroll
-        for (int f = 0; f < GL_F64_NM; ++f) gl_lds64[GL_F64_M + f] = t[f];     // every lane writes the same values
-    }
-    template <bool RATES, bool COVEXP>
-    static __device__ void run(const double* x, const SlowCoef<double>&, const StepCoef<double>&,
-                               const ModelConst<double>&, const CropConst<double>&, double* dx, double* lam, int* side)
-    {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] = x[i];
-        if (RATES) { gl_lds64[GL_F64_LAM * 64 + threadIdx.x] = *lam; gl_lds64[GL_F64_SIDE * 64 + threadIdx.x] = (double)*side; }
-        rhs_stage_f64<PIPE, RATES, COVEXP>();
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = gl_lds64[(GL_F64_K + i) * 64 + threadIdx.x];
-        if (RATES) { *lam = gl_lds64[GL_F64_LAM * 64 + threadIdx.x]; *side = (int)gl_lds64[GL_F64_SIDE * 64 + threadIdx.x]; }
-    }
-    // q stays in the mailbox (run() reads it there); only the slow-slot entries of ym are defined, the rest is not read
-    static __device__ void slow(const double* ym, const StepCoef<double>&, const ModelConst<double>&,
-                                const CropConst<double>&, SlowCoef<double>&)
-    {
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (gl_slow_slot(i) >= 0) gl_lds64[(GL_F64_X + i) * 64 + threadIdx.x] = ym[i];
-        slow_coef_f64();
-    }
-};
-#endif
 template <class T, bool PIPE = false, bool RATES = false, bool COVEXP = false>
 GL_HD void rhs_stage(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, const ModelConst<T>& m,
                      const CropConst<T>& cr, T* dx, T* lam = nullptr, int* side = nullptr)
 {
-    RhsStage<T, PIPE>::template run<RATES, COVEXP>(x, q, s, m, cr, dx, lam, side);
+    rhs_fast<T, false, PIPE, RATES, true, COVEXP>(x, q, s, m, cr, dx, lam, side);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1690,7 +1567,6 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (RK4), 3 (three-stage third-order scheme) or 2 (midpoint rule), all with the cover conduction exponential");
     using M = Math<T>;
     constexpr bool COVEXP = true;                  // every scheme of the family integrates the cover conduction exactly (round 4)
-    constexpr bool UNIFORM = RhsStage<T, PIPE>::UNIFORM_CALLS;
     const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
     const T est_fac = T(1.0 / 6.0);
     // the environment's windows: nominal count now, its own after the pre-pass (it == -1) below
@@ -1711,7 +1587,6 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
     for (int j = 0; j < GL_N_SLOW; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
-    RhsStage<T, PIPE>::begin(s, m, cr);
 #pragma unroll
     for (int i = 0; i < NX; ++i) del[i] = T(0);
 #pragma unroll
@@ -1728,24 +1603,21 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     };
     int side_prev = 0;
     bool capped_prev = false;
-    bool fin = false;               // this lane is through (fp64 on the device keeps its out-of-line calls wave-uniform: it runs on idle)
     // it == -1: the pre-pass (rate bound at x0 -> this environment's number of windows);  0 .. n_win - 1: the windows;
     // it == n_win: one closing evaluation at the final state (the error estimate of the last sub-step and the branch invariant
     // of the last window)
-    for (int it = -1; UNIFORM ? GL_WAVE_ANY(!fin) : !fin; ++it) {
+    for (int it = -1;; ++it) {
         // A rate beyond SC_MAX_REFINE x the nominal one is followed at the finest sub-step (the seconds before a cold, wet
         // surface crosses the air temperature); one that PERSISTS is unresolvable at this n_sub: the guard retries finer
-        flags |= (!fin && t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
-        // (fp64 on the device keeps its out-of-line calls wave-uniform: a capped lane runs on, its result is discarded anyway
-        // and its sub-steps are no longer counted)
-        if ((flags & SC_FLAG_CAP) && !UNIFORM) break;
+        flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
+        if (flags & SC_FLAG_CAP) break;
         // ---- window start: tier 2b at the predicted window midpoint  y + (previous window's increment) / 2, then the
         // first stage of the window's first sub-step together with the rate bound (the only place it is evaluated)
         state_now();
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) { xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)]; dwin[gl_slow_slot(i)] = del[i]; }
-        RhsStage<T, PIPE>::slow(xs, s, m, cr, q);
+        slow_coef<T>(xs, s, m, cr, q);
         T lam = (it < 0) ? T(0) : hnom;                           // in: nominal sub-step (0: smooth slopes only); out: the rate bound
         int side = capped_prev ? 1 : 0;                           // in: was the window just taken capped?  out: the side bits
         rhs_stage<T, PIPE, true, COVEXP>(y, q, s, m, cr, k, &lam, &side);
@@ -1771,7 +1643,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // in a saddle-node when the drive passes through zero, and feedback through the other exchange paths can turn the
         // drive positive again right after): 2 % of the raw-jump tuples, 7e-7 of the bench workload's env-steps, every
         // ladder level agreeing with the truth.
-        flags |= (!fin && (((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
+        flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
         side_prev = side;
         if (it > 0) {                                             // embedded error estimate of the previous sub-step
             T worst = T(0);
@@ -1782,10 +1654,9 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * wj);
             }
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
-            flags |= (fin || worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
+            flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
         }
-        fin = fin || it >= n_win;
-        if (fin && !UNIFORM) break;               // (fp64 on the device: a finished lane idles through the wave's remaining windows with h = 0)
+        if (it >= n_win) break;
         // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
         T hs = M::min(S * M::rcp(lam), hnom);
         {   // accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by
@@ -1807,13 +1678,13 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 }
             hs = (mv * hs > T(SC_MOVE)) ? T(SC_MOVE) * M::rcp(mv) : hs;
         }
-        const bool capped = !fin && !(hs >= hmin);                // also true for a NaN rate
+        const bool capped = !(hs >= hmin);                        // also true for a NaN rate
         hs = capped ? hmin : hs;
         t_cap += capped ? hw : T(0);
         capped_prev = capped;
-        T n_rem = fin ? T(1) : M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
-        T h = fin ? T(0) : hw * M::rcp(n_rem), h2 = T(0.5) * h;
-        h_last = fin ? h_last : h;
+        T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
+        const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h;
+        h_last = h;
         if (COVEXP && h != h_ec) { etd_coefs<T>(T(2) * gamCov, h, ec); h_ec = h; }
         // one sub-step from (y, k = f(y)): leaves the increment in del and the scheme's last stage in k
         auto sub_step = [&]() {
@@ -1926,7 +1797,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                     del[5] += h * k[5] - T(0.5) * dW;
                 }
             }
-            n_steps += ((flags & SC_FLAG_CAP) || fin) ? 0 : 1;
+            ++n_steps;
         };
         // the first sub-step uses the stage evaluated above; every further one starts with its own first stage (written
         // as two loops so that the compiler cannot hoist that evaluation above the exit test of the previous sub-step)
@@ -1934,40 +1805,18 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // the last stage (RK4: k4; three-stage scheme: k3; midpoint: 2 k2 - k1) of the window's last sub-step, for the estimate at the next start
 #pragma unroll
         for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
-        if (UNIFORM) {
-            // fp64 on the device: the stage is an out-of-line call, and calls are kept wave-uniform -- every lane runs the
-            // wave's longest window, lanes that are done take sub-steps of length 0 (same time at wave level: they would
-            // idle), and keep the estimate stage of their own last real sub-step
-            for (n_rem -= T(1); GL_WAVE_ANY(n_rem >= T(0.5)); n_rem -= T(1)) {
-                const bool act = n_rem >= T(0.5);
-                h = act ? h_last : T(0); h2 = T(0.5) * h;
-                if (COVEXP && h != h_ec) { etd_coefs<T>(T(2) * gamCov, h, ec); h_ec = h; }
-                T keep[SC_NFAST];
+        for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
+            state_now();
+            rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);                // same tier 2b
+            sub_step();
 #pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) keep[j] = est[j];
-                state_now();
-                rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);
-                sub_step();
-                n_steps -= (act || fin || (flags & SC_FLAG_CAP)) ? 0 : 1;
-#pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j)
-                    est[j] = !act ? keep[j] : (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
-            }
-            if (COVEXP && h_ec != h_last) { etd_coefs<T>(T(2) * gamCov, h_last, ec); h_ec = h_last; }   // the estimate's weight is that of the last real sub-step
-        } else {
-            for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
-                state_now();
-                rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);                // same tier 2b
-                sub_step();
-#pragma unroll
-                for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
-            }
+            for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
         }
         // ---- window end: increment of the window's RK part (harvest excluded), harvest flow
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dwin[gl_slow_slot(i)];
-        const T hh = fin ? T(0) : (it == n_win - 1) ? hw2 : hw;
+        const T hh = (it == n_win - 1) ? hw2 : hw;
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
     }
@@ -2014,25 +1863,16 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
                             int* first_flags = nullptr)
 {
     using M = Math<T>;
-    constexpr bool UNIFORM = RhsStage<T, PIPE>::UNIFORM_CALLS;
     int n = n_sub, extra = 0, total = 0;
     bool done = false, ok = false, have_prev = false;
     T prev[SC_NFAST];
 #pragma unroll
     for (int j = 0; j < SC_NFAST; ++j) prev[j] = T(0);
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
-        // fp64 on the device: every lane of the wave runs the attempt while any lane needs it (wave-uniform out-of-line calls);
-        // lanes that are done keep their accepted result
-        if (UNIFORM ? !GL_WAVE_ANY(!done) : done) break;
+        if (done) break;
         ScStat<T> st;
-        T tmp[NX];
-        T* dst = UNIFORM ? tmp : del;
-        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, dst, st);
-        if (!done) {
-            if (UNIFORM) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) del[i] = tmp[i];
-            }
+        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del, st);
+        {
             total += st.n_steps;
             const int n_nom = ((n + WIN - 1) / WIN) * WIN;
             // diagnostics: why the FIRST attempt was not accepted as it stood (SC_FLAG_* | 16 = SC_HEAVY sub-steps)

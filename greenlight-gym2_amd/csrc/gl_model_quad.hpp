@@ -20,8 +20,9 @@
 // Same scheme as rk_delta / rk4_delta_guarded of gl_model.hpp, decision for decision (windows, tier 2b at the predicted
 // midpoint, exact harvest sub-flow, wet surfaces as differences to their air node, rate bound -> sub-steps per window, movement
 // limiter, embedded error estimate, branch invariant, closing evaluation, step-doubling ladder): the CPU checker's restatement of
-// that scheme is the reference for both layouts (tests/).  Classical RK4, default ODE variant, shared crop parameters,
-// interlights off (what the reference configures); everything else stays on the one-lane kernels.
+// that scheme is the reference for both layouts (tests/).  Every member of the scheme family (RK4 / three-stage / midpoint, all
+// with the exponential cover conduction), both ODE variants, shared or per-environment crop constants, interlights on or off: in
+// fp64 this layout is the only integrator on the device (round 4); in fp32 it serves the small batches.
 // Measured (tools/lanes_stage_proto.hip, profiles/r03_lanes_stage_proto.txt): the bare RK4 chain runs 1.48x (fp32) / 1.43x (fp64)
 // the env-steps per second of the one-lane layout for B <= 16 384 and 0.73x at B = 65 536 -- hence the dispatch by batch size.
 #pragma once
@@ -90,6 +91,7 @@ template <class T> struct LaneK {
     P2<T> src, iCap, wetC, mAir, mTop, trK;
     P2<T> firX[4], firY[4];        // C[own x|y][lane s .x] and C[own x|y][lane s .y]
     P2<T> cSky;
+    P2<T> iC;                      // interlight long-wave coefficients of the pair (zero power in the reference; geometry may be present)
     T ro[4];                       // rates of the lane's constant-rate states (tier 2b)
     // ETD coefficients of the pair's y component for the sub-step in use (rk_delta_quad; part of this record so that the fp64
     // build keeps them in LDS with the rest of it): cover lane a = 2 cCovCond / capCov, every other lane a = 0 = classical RK4
@@ -124,6 +126,7 @@ __device__ __forceinline__ void gq_make_lane(int role, const StepCoef<T>& s, con
     K.mAir = gq_mk<T>(pk(one, one, one, z), pk(one, one, one, z));
     K.mTop = gq_mk<T>(pk(z, z, z, one), z);
     K.trK = gq_mk<T>(pk(q.mvCanK, z, z, z), z);
+    K.iC = gq_mk<T>(pk(q.iCan, q.iFlr, q.iThScr, q.iCovIn), pk(q.iPipe, q.iLamp, q.iBlScr, z));
     K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
     K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
 }
@@ -132,7 +135,12 @@ __device__ __forceinline__ void gq_make_lane(int role, const StepCoef<T>& s, con
 template <class T> struct QRates { P2<T> hecA, hecB, sv, rr, g, Tsurf; T fScrAbs, fRoofAbs, tTopK; };
 
 // ---- one stage.  y: the lane's states in the integrator's coordinates; k: derivatives in the same coordinates ------------------
-template <class T, bool RATES>
+// PIPE: the reference's ODE_pipe (ode.hpp:126-263) is compiled in and selected at RUN TIME by s.pipeOde -- lane 0's pipe follows the
+// measured temperature while tracking (s.pipeTrack), the grow pipe (lane 1, fourth "other") stands still (rhs_fast<PIPE>).  Run time,
+// not another instantiation: the fp64 builds of this layout sit at the register limit, and every additional variant is one more
+// binary hipcc 7.2 can get wrong (a separate ODE_pipe build computed a wrong second soil layer); this way ODE_pipe runs the very
+// kernel the default variant's rounding-level parity tests cover.
+template <class T, bool RATES, bool PIPE = false>
 __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK<T>& K, const StepCoef<T>& s, const ModelConst<T>& m,
                                          const SlowCoef<T>& q, QVec<T>& k, QRates<T>* R)
 {
@@ -154,6 +162,16 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
         fir = fir + K.firX[1] * (gq_sp<T>(q1x) - qp) + K.firY[1] * (gq_sp<T>(q1y) - qp);
         fir = fir + K.firX[2] * (gq_sp<T>(q2x) - qp) + K.firY[2] * (gq_sp<T>(q2y) - qp);
         fir = fir + K.firX[3] * (gq_sp<T>(q3x) - qp);
+    }
+    // ---- interlights: geometry only (aux_states.hpp:261 hard-wires their power to zero); every term is exactly 0 with the default block
+    T dInt = T(0), hIntAir = T(0);
+    if (m.intLampActive) {
+        const T tInt = gq_bcast<3>(y.o[0]);                          // x18 lives on lane 3
+        const T ki = tInt + c2k, ki2 = ki * ki, qInt = ki2 * ki2;
+        const P2<T> iTo = K.iC * (gq_sp<T>(qInt) - qp);              // into the pair's surfaces
+        fir = fir + iTo;
+        hIntAir = m.cIntLampAir * (tInt - tAir);
+        dInt = m.iCapIntLamp * (-hIntAir - q.iSky * (qInt - s.qSky) - gq_sum(iTo.x + iTo.y));
     }
     // ---- exchange with node A (dA = T_A - T_i: exactly the carried difference on the wet lanes)
     const P2<T> dA = gq_mk<T>(scr || cov ? y.p.x : tAir - Tp.x, scr ? y.p.y : (cov ? s.tOut : tAir) - Tp.y);
@@ -212,7 +230,7 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T hAirOut = s.hAirOutK * dTOut;
     k.sh[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
     k.sh[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
-    k.sh[2] = m.iCapAir * (sHeatAir + q.swAir - hAirOut - hAirTop + q.hGroPipeAir);
+    k.sh[2] = m.iCapAir * (sHeatAir + q.swAir - hAirOut - hAirTop + q.hGroPipeAir + hIntAir);
     k.sh[3] = m.iCapTop * (sHeatTop + hAirTop - hTopOut);
     k.sh[4] = m.kCapVpAir * tAirK * (sVapAir - mvAirTop - mvAirOut);
     k.sh[5] = m.kCapVpTop * tTopK * (sVapTop + mvAirTop - mvTopOut);
@@ -220,9 +238,13 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     // (cover lane: the classical part of slot 5, d(tTop - sigma / 2)/dt, and N_w = nIn - nOut: rhs_fast<COVEXP>)
     k.p = gq_mk<T>(scr ? k.sh[2] - dTp.x : cov ? k.sh[3] - T(0.5) * (dTp.x + dTp.y) : dTp.x, scr ? k.sh[2] - dTp.y : cov ? dTp.x - dTp.y : dTp.y);
     const T perDay = T(1.0 / 86400.0);
-    k.o[0] = lane0 ? perDay * (tCan - y.o[0]) : K.ro[0];             // lane 0: tCan24, tCanSum; lane 3: tIntLamp (off), time
+    k.o[0] = lane0 ? perDay * (tCan - y.o[0]) : cov ? dInt : K.ro[0];  // lane 0: tCan24, tCanSum; lane 3: tIntLamp, time
     k.o[1] = lane0 ? perDay * tCan : cov ? perDay : K.ro[1];
     k.o[2] = K.ro[2]; k.o[3] = K.ro[3];
+    if (PIPE) {
+        k.p = gq_mk<T>(k.p.x, (lane0 && s.pipeTrack != T(0)) ? s.tPipeSet - Tp.y : k.p.y);      // ode.hpp:184-189 (pipeTrack is 0 outside ODE_pipe)
+        k.o[3] = (role == 1 && s.pipeOde != T(0)) ? T(0) : k.o[3];                               // ode.hpp:240
+    }
     if (RATES) { R->hecA = hecA; R->hecB = hecB; R->sv = sv; R->rr = rr; R->g = g; R->Tsurf = Tp; R->fScrAbs = fScrAbs; R->fRoofAbs = fRoofAbs; R->tTopK = tTopK; }
 }
 
@@ -257,7 +279,7 @@ __device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVe
         const bool harm = on && (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
                           (kG3 > T(0.3) * rfree * rfree);
         T row = iCap * (base + f43 * hecAbs);
-        if (GL_WAVE_ANY(harm)) row = sc_pinned_rate<T>(harm, iCap, hcoef, hecAbs, LK * g, dT, ddT, row, T(4) * h_nominal);
+        if (GL_WAVE_ANY(harm)) row = sc_pinned_rate_inl<T>(harm, iCap, hcoef, hecAbs, LK * g, dT, ddT, row, T(4) * h_nominal);
         rows = M::max(rows, on ? row : T(0));
     };
     // x component: cover (lane 3) | thermal screen (lane 2)
@@ -304,17 +326,22 @@ template <class T> __device__ __forceinline__ T gq_fast_max(const QVec<T>& a, P2
 // a compiler fence in front of every stage, whose operands are their addresses, makes hipcc re-read them there instead of
 // hoisting ~115 doubles into registers -- in fp64 that is the difference between 512 registers + scratch (whose spill code hipcc
 // 7.2 gets wrong on this kernel too) and a kernel that fits.
-#define GQ_FENCE() do { if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K) : "memory"); } while (0)
-template <class T, int WIN, bool LDSQ>
+// ORDER: 4 (RK4), 3 (three-stage scheme), 2 (midpoint rule) -- rk_delta's three members of the exponential family.
+// LDSC: the crop constants `cr` are a per-quad LDS record as well (per-env crop blocks); otherwise they are part of `m` and their
+// address must NOT reach the fence (it would force a private copy of the whole kernel argument).
+#define GQ_FENCE() do { if (LDSQ && LDSC) asm volatile("" : : "v"(&s), "v"(&K), "v"(&cr) : "memory"); \
+                        else if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K) : "memory"); } while (0)
+template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
 __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
                                               const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st)
 {
+    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER");
     using M = Math<T>;
     // the quad's windows: nominal count now, its own after the pre-pass (it == -1; rk_delta)
     int n_win = (n_sub + WIN - 1) / WIN;
     T hw = dt / T(n_win), hnom = hw / T(WIN);
     int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
-    const T S = T(SC_SAFETY * 2.785), est_fac = T(1.0 / 6.0);
+    const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(1.0 / 6.0);
     const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
     const T gam = m.iCapCov * m.cCovCond, cw = cov ? T(0.5) : T(0);
     QVec<T> y, xs, k, acc;
@@ -371,9 +398,10 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         }
         // ---- first stage of the window's first sub-step with the rate bound; branch invariant; error estimate of the last sub-step
         QRates<T> R;
-        GQ_FENCE(); gq_stage<T, true>(role, y, K, s, m, q, k, &R);
+        GQ_FENCE(); gq_stage<T, true, PIPE>(role, y, K, s, m, q, k, &R);
         int side = capped_prev ? 1 : 0;
-        const T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, (it < 0) ? T(0) : hnom, &side);
+        T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, (it < 0) ? T(0) : hnom, &side);
+        if (PIPE) lam = (s.pipeTrack != T(0)) ? M::max(lam, T(1)) : lam;      // dxdt(9) = tPipeSet - x9: rate 1 1/s (rhs_fast<RATES, PIPE>)
         if (it < 0) {
             // pre-pass (rk_delta): the environment's own number of windows from the rate bound at x0, then the leading harvest half step
             const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
@@ -391,7 +419,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             QVec<T> dif;
             dif.p = estP - k.p;
             for (int i = 0; i < 6; ++i) dif.sh[i] = estS[i] - k.sh[i];
-            const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, gq_tol<T>(role).est.y * K.ec.w3)));     // (the ETD component's estimate carries f3)
+            const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, ORDER != 2 ? gq_tol<T>(role).est.y * K.ec.w3 : gq_tol<T>(role).est.y)));     // (the ETD component's estimate carries f3)
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
             flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;
         }
@@ -410,50 +438,89 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
         if (h != h_last) etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
         h_last = h;
-        // one sub-step from (y, k = f(y)): classical RK4 on the pair's x component, the shared states and lane 0's / lane 3's first two
-        // "others" (tCan24, tCanSum | tIntLamp, time), ETD on the pair's y component (classical coefficients off the cover lane), the
-        // cover lane's x assembled from tTop, sigma and w (rk_delta), constant rate for the rest
+        // one sub-step from (y, k = f(y)): the classical scheme on the pair's x component, the shared states and lane 0's / lane 3's first
+        // two "others" (tCan24, tCanSum | tIntLamp, time), its ETD sibling on the pair's y component (classical coefficients off the
+        // cover lane), the cover lane's x assembled from tTop, sigma and w (rk_delta), constant rate for the rest
         auto sub_step = [&]() {
             const T w0 = y.p.y, n1 = k.p.y;
-            T dWa, accW;
+            const bool full01 = lane0 || role == 3;
             auto fill = [&](T c, T dW) {
                 xs.p = gq_mk<T>(y.p.x + c * k.p.x - cw * dW, w0 + dW);
                 for (int i = 0; i < 6; ++i) xs.sh[i] = y.sh[i] + c * k.sh[i];
                 xs.o[0] = y.o[0] + c * k.o[0]; xs.o[1] = y.o[1] + c * k.o[1]; xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
             };
-            auto accum = [&]() {
-                acc.p.x += T(2) * k.p.x;
-                for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
-                acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
-                accW += K.ec.f2d * k.p.y;
-            };
-            acc = k;
-            dWa = K.ec.e2m1 * w0 + K.ec.q * n1; accW = K.ec.f1 * n1;
-            fill(h2, dWa);
-            GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
-            accum();
-            fill(h2, K.ec.e2m1 * w0 + K.ec.q * k.p.y);
-            GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
-            accum();
-            fill(h, K.ec.e2m1 * w0 + K.ec.e2 * dWa + K.ec.q * (T(2) * k.p.y - n1));
-            GQ_FENCE(); gq_stage<T, false>(role, xs, K, s, m, q, k, nullptr);
-            const T dW = K.ec.em1 * w0 + accW + K.ec.f3 * k.p.y;
-            del.p = gq_mk<T>(del.p.x + h6 * (acc.p.x + k.p.x) - cw * dW, del.p.y + dW);
-            for (int i = 0; i < 6; ++i) del.sh[i] += h6 * (acc.sh[i] + k.sh[i]);
-            const bool full01 = lane0 || role == 3;
-            del.o[0] += full01 ? h6 * (acc.o[0] + k.o[0]) : h * k.o[0];
-            del.o[1] += full01 ? h6 * (acc.o[1] + k.o[1]) : h * k.o[1];
+            if (ORDER == 4) {
+                T dWa, accW;
+                auto accum = [&]() {
+                    acc.p.x += T(2) * k.p.x;
+                    for (int i = 0; i < 6; ++i) acc.sh[i] += T(2) * k.sh[i];
+                    acc.o[0] += T(2) * k.o[0]; acc.o[1] += T(2) * k.o[1];
+                    accW += K.ec.f2d * k.p.y;
+                };
+                acc = k;
+                dWa = K.ec.e2m1 * w0 + K.ec.q * n1; accW = K.ec.f1 * n1;
+                fill(h2, dWa);
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+                accum();
+                fill(h2, K.ec.e2m1 * w0 + K.ec.q * k.p.y);
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+                accum();
+                fill(h, K.ec.e2m1 * w0 + K.ec.e2 * dWa + K.ec.q * (T(2) * k.p.y - n1));
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+                const T dW = K.ec.em1 * w0 + accW + K.ec.f3 * k.p.y;
+                del.p = gq_mk<T>(del.p.x + h6 * (acc.p.x + k.p.x) - cw * dW, del.p.y + dW);
+                for (int i = 0; i < 6; ++i) del.sh[i] += h6 * (acc.sh[i] + k.sh[i]);
+                del.o[0] += full01 ? h6 * (acc.o[0] + k.o[0]) : h * k.o[0];
+                del.o[1] += full01 ? h6 * (acc.o[1] + k.o[1]) : h * k.o[1];
+            } else if (ORDER == 3) {
+                // k2 = f(y + h/2 k1), k3 = f(y + h (2 k2 - k1)), y+ = y + h/6 (k1 + 4 k2 + k3);  w: ETD3RK (rk_delta)
+                acc = k;
+                T accW = K.ec.f1 * n1;
+                fill(h2, K.ec.e2m1 * w0 + K.ec.q * n1);
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+                {
+                    const T dWb = K.ec.em1 * w0 + K.ec.hp1 * (T(2) * k.p.y - n1);
+                    xs.p = gq_mk<T>(y.p.x + h * (T(2) * k.p.x - acc.p.x) - cw * dWb, w0 + dWb);
+                    for (int i = 0; i < 6; ++i) xs.sh[i] = y.sh[i] + h * (T(2) * k.sh[i] - acc.sh[i]);
+                    xs.o[0] = y.o[0] + h * (T(2) * k.o[0] - acc.o[0]); xs.o[1] = y.o[1] + h * (T(2) * k.o[1] - acc.o[1]);
+                    xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
+                    acc.p.x += T(4) * k.p.x;
+                    for (int i = 0; i < 6; ++i) acc.sh[i] += T(4) * k.sh[i];
+                    acc.o[0] += T(4) * k.o[0]; acc.o[1] += T(4) * k.o[1];
+                    accW += T(2) * K.ec.f2d * k.p.y;
+                }
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+                const T dW = K.ec.em1 * w0 + accW + K.ec.f3 * k.p.y;
+                del.p = gq_mk<T>(del.p.x + h6 * (acc.p.x + k.p.x) - cw * dW, del.p.y + dW);
+                for (int i = 0; i < 6; ++i) del.sh[i] += h6 * (acc.sh[i] + k.sh[i]);
+                del.o[0] += full01 ? h6 * (acc.o[0] + k.o[0]) : h * k.o[0];
+                del.o[1] += full01 ? h6 * (acc.o[1] + k.o[1]) : h * k.o[1];
+            } else {
+                // midpoint rule: k2 = f(y + h/2 k1), y+ = y + h k2;  w: ETD2RK.  The estimate's comparison stage is 2 k2 - k1
+                estP = gq_mk<T>(-k.p.x, -k.p.y);
+                for (int i = 0; i < 6; ++i) estS[i] = -k.sh[i];
+                fill(h2, K.ec.e2m1 * w0 + K.ec.q * n1);
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+                const T dW = K.ec.em1 * w0 + K.ec.hp1 * k.p.y;
+                del.p = gq_mk<T>(del.p.x + h * k.p.x - cw * dW, del.p.y + dW);
+                for (int i = 0; i < 6; ++i) del.sh[i] += h * k.sh[i];
+                del.o[0] += h * k.o[0]; del.o[1] += h * k.o[1];
+                estP = gq_mk<T>(estP.x + T(2) * k.p.x, estP.y + T(2) * k.p.y);
+                for (int i = 0; i < 6; ++i) estS[i] += T(2) * k.sh[i];
+            }
             del.o[2] += h * k.o[2]; del.o[3] += h * k.o[3];
             ++n_steps;
         };
         sub_step();
         for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
             state_now();
-            GQ_FENCE(); gq_stage<T, false>(role, y, K, s, m, q, k, nullptr);
+            GQ_FENCE(); gq_stage<T, false, PIPE>(role, y, K, s, m, q, k, nullptr);
             sub_step();
         }
-        estP = k.p;                                        // the last stage of the window's last sub-step
-        for (int i = 0; i < 6; ++i) estS[i] = k.sh[i];
+        if (ORDER != 2) {                                  // the last stage of the window's last sub-step (midpoint: set in sub_step)
+            estP = k.p;
+            for (int i = 0; i < 6; ++i) estS[i] = k.sh[i];
+        }
         // ---- window end
         {
             T end7[7];
@@ -475,7 +542,7 @@ template <class T> __device__ __forceinline__ void gq_phys_pair(int role, const 
 }
 
 // ---- the guard: rk4_delta_guarded of gl_model.hpp over the quad (same ladder, same acceptance rules) ---------------------------------
-template <class T, int WIN, bool LDSQ>
+template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
 __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
                                                       const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps,
                                                       bool verify, int* first_flags)
@@ -490,7 +557,7 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         if (done) break;                                   // uniform inside the quad: every decision below is
         ScStat<T> st;
-        rk_delta_quad<T, WIN, LDSQ>(role, z0, s, K, m, cr, dt, n, del, st);
+        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st);
         total += st.n_steps;
         const int n_nom = ((n + WIN - 1) / WIN) * WIN;
         if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);

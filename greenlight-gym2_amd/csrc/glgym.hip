@@ -109,6 +109,7 @@ template <class T> struct StepArgsT {
     int nd;                     // weather row stride (10, or 14 with the measured-pipe columns of ODE_pipe)
     float du, u_min[NU], u_max[NU];      // action_to_control: clip(u + action * delta_u_max, u_min, u_max)
     int verify;                 // 1: step-doubling verified integration (rk4_delta_guarded), see glgym_set_verify
+    int pipe;                   // 1: the handle's ODE variant is GLGYM_ODE_PIPE (kernels that select the variant at run time)
 };
 
 template <class T> __device__ __forceinline__ T wave_sum(T v)
@@ -142,18 +143,6 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #ifndef GL_RK4_WIN_F64
 #define GL_RK4_WIN_F64 3
 #endif
- // kernels that integrate in fp64 take the LDS mailbox of gl_model.hpp (rhs_stage_f64) as dynamic LDS
-#define GL_LAUNCH_T(kern, crop, grid, block, st, ...)                                                                       \
-    do {                                                                                                               \
-        auto kf_ = kern;                                                                                               \
-        const size_t lds_ = sizeof(T) == 8 ? glm::gl_f64_lds_bytes(crop) : 0;                                           \
-        /* the attribute is per device: set it on every launch that needs it (cheap), and report a refusal */            \
-        if (lds_ > 0) {                                                                                                \
-            const hipError_t ea_ = hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
-            if (ea_ != hipSuccess) g_err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(ea_); \
-        }                                                                                                              \
-        hipLaunchKernelGGL(kf_, grid, block, lds_, st, __VA_ARGS__);                                                   \
-    } while (0)
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : GL_RK4_WIN_F64; };
 // SCH (template argument of the integrating kernels) = GLGYM_SCHEME_*: 0 classical RK4, 1 explicit midpoint (four sub-steps
 // per tier-2b window), 2 Bogacki-Shampine (three)
@@ -307,9 +296,12 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
 // ---------------------------------------------------------------------------------------------------
 // fused env-step, FOUR LANES PER ENVIRONMENT (gl_model_quad.hpp): 16 environments per wavefront; for batches that leave SIMDs
 // idle (B <= 16 384: profiles/r03_lanes_stage_proto.txt).  Same prologue / epilogue as step_kernel; lane 0 of a quad writes the
-// per-env outputs, every lane the states it owns.  Classical RK4, default ODE, shared crop parameters, interlights off.
+// per-env outputs, every lane the states it owns.
 // ---------------------------------------------------------------------------------------------------
-template <class T, bool DEFAULT_P>
+// SCH / CROP as in step_kernel: every scheme of the family, per-env crop blocks (config 5).  PIPE: ODE_pipe compiled in, selected at run
+// time by a.pipe (gq_stage) -- in fp64 this kernel is the only step kernel (round 4: the one-lane fp64 kernels with their LDS mailbox
+// and 2-3 KB of scratch are gone) and is always built with it.
+template <class T, bool DEFAULT_P, int SCH = 0, bool PIPE = false, bool CROP = false>
 __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
@@ -335,21 +327,38 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     T d[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) d[j] = a.weather[(size_t)row * a.nd + j];
-    const CropConst<T>& cr = m.crop;
-    // fp64: the coefficient blocks live in LDS (rk_delta_quad<LDSQ>): StepCoef once per quad, LaneK per lane, records padded to an
-    // odd number of 8-byte words (conflict-free ds_read_b64 across the lanes)
+    // fp64: the coefficient blocks live in LDS (rk_delta_quad<LDSQ>): StepCoef (and the env's crop constants) once per quad, LaneK per
+    // lane, records padded to an odd number of 8-byte words (conflict-free ds_read_b64 across the lanes)
     constexpr bool LDSQ = sizeof(T) == 8;
     struct SRec { StepCoef<T> s; T pad[(sizeof(StepCoef<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
     struct KRec { LaneK<T> k; T pad[(sizeof(LaneK<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
+    struct CRec { CropConst<T> c; T pad[(sizeof(CropConst<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
     __shared__ SRec sh_s[LDSQ ? WAVE / 4 : 1];
     __shared__ KRec sh_k[LDSQ ? WAVE : 1];
+    __shared__ CRec sh_c[(LDSQ && CROP) ? WAVE / 4 : 1];
     StepCoef<T> s_reg;
     LaneK<T> k_reg;
-    if (!LDSQ || role == 0) precompute(u, d, m, cr, s_reg);
+    CropConst<T> cr_reg;
+    if (CROP && (!LDSQ || role == 0)) {
+        T pc[NCROP];
+#pragma unroll
+        for (int i = 0; i < NCROP; ++i) pc[i] = a.crop_p[(size_t)i * a.ld + bb];
+        make_crop_const<T, T>(pc, a.gasR, a.tCanMin, cr_reg);
+    }
+    if (!LDSQ || role == 0) {
+        precompute(u, d, m, CROP ? cr_reg : m.crop, s_reg);
+        if (PIPE && a.pipe) {                                                 // ode.hpp:184-189
+            const T tPipe = a.weather[(size_t)row * a.nd + 10], swOff = a.weather[(size_t)row * a.nd + 12];
+            s_reg.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
+            s_reg.tPipeSet = tPipe;
+            s_reg.pipeOde = T(1);
+        }
+    }
     if (LDSQ) {
-        if (role == 0) sh_s[threadIdx.x >> 2].s = s_reg;
+        if (role == 0) { sh_s[threadIdx.x >> 2].s = s_reg; if (CROP) sh_c[threadIdx.x >> 2].c = cr_reg; }
         __syncthreads();                       // one wavefront per block: orders the LDS writes before the quad's reads
     }
+    const CropConst<T>& cr = !CROP ? m.crop : LDSQ ? sh_c[threadIdx.x >> 2].c : cr_reg;
     const StepCoef<T>& s = LDSQ ? sh_s[threadIdx.x >> 2].s : s_reg;
     LaneK<T>& K = LDSQ ? sh_k[threadIdx.x].k : k_reg;
     // the lane's states, in the integrator's coordinates (screens / inner cover face as differences to their air node)
@@ -372,8 +381,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     }
     bool bad;
     int extra_steps, first_flags = 0;
-    const int retries = rk4_delta_guarded_quad<T, RK4_WINDOW<T>::value, LDSQ>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps,
-                                                                             a.verify != 0, &first_flags);
+    const int retries = rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad,
+                                                                                                      &extra_steps, a.verify != 0, &first_flags);
     // ---- new state: physical increments of what the lane owns.  Nothing but the integrator's own state is kept live across the
     // integrator (the fp64 build is at its register limit there): the old state and the applied control are read again
     P2<T> dP;
@@ -464,6 +473,124 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
             if (threadIdx.x == 0) atomicAdd(mrep + i, sum);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reference-compatible step map, four lanes per row (what fp64 handles run: row-major double I/O, per-row crop blocks)
+// ---------------------------------------------------------------------------------------------------
+template <class T, int SCH, bool PIPE, bool CROP>
+__global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const double* u, const double* d, const double* crop, int B, T dt,
+                                                          int n_sub, T gasR, T tCanMin, ModelConst<T> m, double* x_next, int nd,
+                                                          int* n_failed, int verify, int pipe)
+{
+    const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3, b = gl >> 2;
+    const bool live = b < B;
+    const int bb = live ? b : B - 1;
+    T uu[NU], dd[7];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[(size_t)bb * NU + i]);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[(size_t)bb * nd + i]);
+    constexpr bool LDSQ = sizeof(T) == 8;
+    struct SRec { StepCoef<T> s; T pad[(sizeof(StepCoef<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
+    struct KRec { LaneK<T> k; T pad[(sizeof(LaneK<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
+    struct CRec { CropConst<T> c; T pad[(sizeof(CropConst<T>) / sizeof(T)) % 2 == 0 ? 1 : 2]; };
+    __shared__ SRec sh_s[LDSQ ? WAVE / 4 : 1];
+    __shared__ KRec sh_k[LDSQ ? WAVE : 1];
+    __shared__ CRec sh_c[(LDSQ && CROP) ? WAVE / 4 : 1];
+    StepCoef<T> s_reg;
+    LaneK<T> k_reg;
+    CropConst<T> cr_reg;
+    if (CROP && (!LDSQ || role == 0)) {
+        T pc[NCROP];
+#pragma unroll
+        for (int i = 0; i < NCROP; ++i) pc[i] = T(crop[(size_t)bb * NCROP + i]);
+        make_crop_const<T, T>(pc, gasR, tCanMin, cr_reg);
+    }
+    if (!LDSQ || role == 0) {
+        precompute(uu, dd, m, CROP ? cr_reg : m.crop, s_reg);
+        if (PIPE && pipe) {
+            const T tPipe = T(d[(size_t)bb * nd + 10]), swOff = T(d[(size_t)bb * nd + 12]);
+            s_reg.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
+            s_reg.tPipeSet = tPipe;
+            s_reg.pipeOde = T(1);
+        }
+    }
+    if (LDSQ) {
+        if (role == 0) { sh_s[threadIdx.x >> 2].s = s_reg; if (CROP) sh_c[threadIdx.x >> 2].c = cr_reg; }
+        __syncthreads();
+    }
+    const CropConst<T>& cr = !CROP ? m.crop : LDSQ ? sh_c[threadIdx.x >> 2].c : cr_reg;
+    const StepCoef<T>& s = LDSQ ? sh_s[threadIdx.x >> 2].s : s_reg;
+    LaneK<T>& K = LDSQ ? sh_k[threadIdx.x].k : k_reg;
+    auto X = [&](int i) { return T(x[(size_t)bb * NX + i]); };
+    QVec<T> x0, z0, del;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x0.sh[i] = X(gq_sh_ix(i));
+    x0.p = gq_mk<T>(X(role == 0 ? 4 : role == 1 ? 8 : role == 2 ? 7 : 5), X(role == 0 ? 9 : role == 1 ? 17 : role == 2 ? 20 : 6));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        x0.o[j] = X(role == 0 ? gq_other_ix(0, j) : role == 1 ? gq_other_ix(1, j) : role == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1));
+    z0 = x0;
+    z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x,
+                    role == 2 ? x0.sh[2] - x0.p.y : role == 3 ? x0.p.x - x0.p.y : x0.p.y);
+    bool bad;
+    int extra_steps, first_flags = 0;
+    rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, dt, n_sub, del, &bad, &extra_steps, verify != 0,
+                                                                                  &first_flags);
+    // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
+    P2<T> dP;
+    gq_phys_pair<T>(role, del, dP);
+    asm volatile("" ::: "memory");
+    int gl2 = blockIdx.x * WAVE + threadIdx.x;
+    asm volatile("" : "+v"(gl2));
+    const int role2 = gl2 & 3, b2 = gl2 >> 2;
+    if (b2 < B) {
+        const double nan = __builtin_nan("");
+        auto X2 = [&](int i) { return x[(size_t)b2 * NX + i]; };
+        auto W = [&](int i, T dv) { x_next[(size_t)b2 * NX + i] = bad ? nan : X2(i) + (double)dv; };
+        W(role2 == 0 ? 4 : role2 == 1 ? 8 : role2 == 2 ? 7 : 5, dP.x);
+        W(role2 == 0 ? 9 : role2 == 1 ? 17 : role2 == 2 ? 20 : 6, dP.y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (role2 != 3 || j < 2)
+                W(role2 == 0 ? gq_other_ix(0, j) : role2 == 1 ? gq_other_ix(1, j) : role2 == 2 ? gq_other_ix(2, j) : gq_other_ix(3, j < 2 ? j : 1), del.o[j]);
+        if (role2 == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) W(gq_sh_ix(i), del.sh[i]);
+            if (bad) atomicAdd(n_failed, 1);
+        }
+    }
+}
+
+// the reference's right-hand side at one state per row (test hook behind glgym_rhs)
+template <class T, bool PER_ENV_CROP, bool PIPE>
+__global__ __launch_bounds__(WAVE) void rhs_kernel(const double* x, const double* u, const double* d, const double* crop, int B, T gasR,
+                                                   T tCanMin, ModelConst<T> m, double* dx, int nd)
+{
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B) return;
+    T x0[NX], uu[NU], dd[7];
+    for (int i = 0; i < NX; ++i) x0[i] = T(x[(size_t)b * NX + i]);
+    for (int i = 0; i < NU; ++i) uu[i] = T(u[(size_t)b * NU + i]);
+    for (int i = 0; i < 7; ++i) dd[i] = T(d[(size_t)b * nd + i]);
+    CropConst<T> crLocal;
+    if (PER_ENV_CROP) {
+        T pc[NCROP];
+        for (int i = 0; i < NCROP; ++i) pc[i] = T(crop[(size_t)b * NCROP + i]);
+        make_crop_const<T, T>(pc, gasR, tCanMin, crLocal);
+    }
+    const CropConst<T>& cr = PER_ENV_CROP ? crLocal : m.crop;
+    StepCoef<T> s;
+    precompute(uu, dd, m, cr, s);
+    if (PIPE) {
+        const T tPipe = T(d[(size_t)b * nd + 10]), swOff = T(d[(size_t)b * nd + 12]);
+        s.pipeTrack = ((tPipe < T(1)) || (swOff > T(0))) ? T(0) : T(1);
+        s.tPipeSet = tPipe;
+    }
+    T k[NX];
+    rhs<T, true, PIPE>(x0, s, m, cr, k);
+    for (int i = 0; i < NX; ++i) dx[(size_t)b * NX + i] = (double)k[i];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1254,14 +1381,22 @@ static int ensure_scratch(glgym_handle h, size_t elems)
 
 template <class T, int SCH>
 static void launch_evalf_sch(glgym_handle h, const ModelConst<T>& m, const double* p_used, const double* dx, const double* du,
-                             const double* dd, const double* dcrop, int B, double* dout, int rhs_only, dim3 grid, dim3 block)
+                             const double* dd, const double* dcrop, int B, double* dout, dim3 grid, dim3 block)
 {
-    if (dcrop)
-        GL_LAUNCH_T((evalf_kernel<T, true, false, SCH>), true, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev, h->verify_mode != GLGYM_VERIFY_NEVER);
-    else
-        GL_LAUNCH_T((evalf_kernel<T, false, false, SCH>), false, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                    T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev, h->verify_mode != GLGYM_VERIFY_NEVER);
+    const int verify = h->verify_mode != GLGYM_VERIFY_NEVER;
+    if constexpr (sizeof(T) == 8) {      // fp64: four lanes per row (no one-lane fp64 integrator exists any more)
+        const dim3 qgrid((4 * B + WAVE - 1) / WAVE);
+        const int pipe = h->variant == GLGYM_ODE_PIPE ? 1 : 0;
+        if (dcrop) hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, true>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                                      T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe);
+        else hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, false>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                                T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe);
+    } else {
+        if (dcrop) hipLaunchKernelGGL((evalf_kernel<T, true, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                                      T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify);
+        else hipLaunchKernelGGL((evalf_kernel<T, false, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                                T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify);
+    }
 }
 
 template <class T>
@@ -1269,19 +1404,32 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
                      const double* dd, const double* dcrop, int B, double* dout, int rhs_only)
 {
     const dim3 grid((B + WAVE - 1) / WAVE), block(WAVE);
-    if (h->variant == GLGYM_ODE_PIPE) {
+    const bool pipe = h->variant == GLGYM_ODE_PIPE;
+    if (rhs_only) {                      // the right-hand side at one state per row (test hook): one lane per row in either dtype
+        if (pipe) hipLaunchKernelGGL((rhs_kernel<T, false, true>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(p_used[39]), T(p_used[162]), m, dout, h->nd);
+        else if (dcrop) hipLaunchKernelGGL((rhs_kernel<T, true, false>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(p_used[39]), T(p_used[162]), m, dout, h->nd);
+        else hipLaunchKernelGGL((rhs_kernel<T, false, false>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(p_used[39]), T(p_used[162]), m, dout, h->nd);
+        HIPCHK(hipGetLastError());
+        return GLGYM_OK;
+    }
+    if (pipe) {
         if (dcrop || h->scheme != GLGYM_SCHEME_RK4) {
             g_err = "glgym_evalF: GLGYM_ODE_PIPE supports neither per-row parameter blocks nor schemes other than GLGYM_SCHEME_RK4";
             return GLGYM_EINVAL;
         }
-        GL_LAUNCH_T((evalf_kernel<T, false, true>), dcrop != nullptr, grid, block, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                           T(p_used[39]), T(p_used[162]), m, dout, rhs_only, h->nd, h->fail_dev, h->verify_mode != GLGYM_VERIFY_NEVER);
+        if constexpr (sizeof(T) == 8) {      // (the fp64 kernels select the variant at run time)
+            launch_evalf_sch<T, GLGYM_SCHEME_RK4>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
+        } else {
+            const int verify = h->verify_mode != GLGYM_VERIFY_NEVER;
+            hipLaunchKernelGGL((evalf_kernel<T, false, true>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                               T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify);
+        }
     } else if (h->scheme == GLGYM_SCHEME_RK2) {
-        launch_evalf_sch<T, GLGYM_SCHEME_RK2>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
+        launch_evalf_sch<T, GLGYM_SCHEME_RK2>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
     } else if (h->scheme == GLGYM_SCHEME_RK3) {
-        launch_evalf_sch<T, GLGYM_SCHEME_RK3>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
+        launch_evalf_sch<T, GLGYM_SCHEME_RK3>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
     } else {
-        launch_evalf_sch<T, GLGYM_SCHEME_RK4>(h, m, p_used, dx, du, dd, dcrop, B, dout, rhs_only, grid, block);
+        launch_evalf_sch<T, GLGYM_SCHEME_RK4>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
     }
     HIPCHK(hipGetLastError());
     return GLGYM_OK;
@@ -1364,22 +1512,41 @@ int glgym_rhs(glgym_handle h, const double* x, const double* u, const double* d,
 }  // extern "C"
 
 // ---- device-pointer hot path ----------------------------------------------------------------------
-template <class T, int SCH>
-static void launch_step_sch(const glgym_step_args* a, const StepArgsT<T>& k, const ModelConst<T>& m, const RewardConst<T>& rw,
+// one lane per environment (fp32 only since round 4)
+template <int SCH>
+static void launch_step_sch(const glgym_step_args* a, const StepArgsT<float>& k, const ModelConst<float>& m, const RewardConst<float>& rw,
                             dim3 grid, dim3 block, hipStream_t st, bool def, bool occ2)
 {
-    if constexpr (sizeof(T) == 4) {      // fp64 never takes the specialised kernels (def is false), so no fp64 OCC = 2 build
-        if (occ2) {
-            GL_LAUNCH_T((step_kernel<T, false, true, false, SCH, 2>), false, grid, block, st, k, m, rw);
-            return;
-        }
+    using T = float;
+    if (occ2) {
+        hipLaunchKernelGGL((step_kernel<T, false, true, false, SCH, 2>), grid, block, 0, st, k, m, rw);
+        return;
     }
     if (a->crop_p) {
-        if (def) GL_LAUNCH_T((step_kernel<T, true, true, false, SCH>), true, grid, block, st, k, m, rw);
-        else GL_LAUNCH_T((step_kernel<T, true, false, false, SCH>), true, grid, block, st, k, m, rw);
+        if (def) hipLaunchKernelGGL((step_kernel<T, true, true, false, SCH>), grid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel<T, true, false, false, SCH>), grid, block, 0, st, k, m, rw);
     } else {
-        if (def) GL_LAUNCH_T((step_kernel<T, false, true, false, SCH>), false, grid, block, st, k, m, rw);
-        else GL_LAUNCH_T((step_kernel<T, false, false, false, SCH>), false, grid, block, st, k, m, rw);
+        if (def) hipLaunchKernelGGL((step_kernel<T, false, true, false, SCH>), grid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel<T, false, false, false, SCH>), grid, block, 0, st, k, m, rw);
+    }
+}
+
+// four lanes per environment.  fp64: every scheme, per-env crop blocks, the handle's parameters as a kernel argument; fp32 (small
+// batches): the shared-crop kernels of every scheme, with the default block compiled in where the handle holds it.
+// (The fp64 build with the default block compiled in is NOT shipped: at 504-512 registers per lane hipcc 7.2 produced kernels that
+// computed wrong slow states -- soil layers, the carbohydrate buffer -- and ran away into the guard's ladder, in the RK4 and
+// three-stage variants; the same source with the parameters as an argument is correct in every variant.  GPU tests cover each
+// shipped fp64 variant against the CPU checker.)
+template <class T, int SCH>
+static void launch_quad_sch(const glgym_step_args* a, const StepArgsT<T>& k, const ModelConst<T>& m, const RewardConst<T>& rw,
+                            dim3 qgrid, dim3 block, hipStream_t st, bool def)
+{
+    if constexpr (sizeof(T) == 8) {          // ODE_pipe compiled in, selected by k.pipe
+        if (a->crop_p) hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, true, true>), qgrid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, true, false>), qgrid, block, 0, st, k, m, rw);
+    } else {
+        if (def) hipLaunchKernelGGL((step_kernel_quad<T, true, SCH, false, false>), qgrid, block, 0, st, k, m, rw);
+        else hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, false, false>), qgrid, block, 0, st, k, m, rw);
     }
 }
 
@@ -1398,51 +1565,52 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     for (int j = 0; j < NU; ++j) { k.u_min[j] = h->u_min[j]; k.u_max[j] = h->u_max[j]; }
     // AUTO: verified wherever the control can jump -- raw controls (step_raw_control, the rule-based controller), or an action
     // path whose delta_u_max is wider than the reference's 0.1 (TomatoEnv.yml; base_env.py:74)
+    k.pipe = h->variant == GLGYM_ODE_PIPE ? 1 : 0;
     k.verify = h->verify_mode == GLGYM_VERIFY_ALWAYS || (h->verify_mode == GLGYM_VERIFY_AUTO && (!a->action || h->du > 0.1001f));
-    const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE);
-    if (h->variant == GLGYM_ODE_PIPE) {
-        if (a->crop_p || h->scheme != GLGYM_SCHEME_RK4) {
-            g_err = "glgym_step: GLGYM_ODE_PIPE supports neither per-env crop parameters nor schemes other than GLGYM_SCHEME_RK4";
-            return GLGYM_EINVAL;
-        }
-        GL_LAUNCH_T((step_kernel<T, false, false, true>), a->crop_p != nullptr, grid, block, st, k, m, rw);
+    const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE), qgrid((4 * a->B + WAVE - 1) / WAVE);
+    const bool pipe = h->variant == GLGYM_ODE_PIPE;
+    if (pipe && (a->crop_p || h->scheme != GLGYM_SCHEME_RK4)) {
+        g_err = "glgym_step: GLGYM_ODE_PIPE supports neither per-env crop parameters nor schemes other than GLGYM_SCHEME_RK4";
+        return GLGYM_EINVAL;
+    }
+    // Layout.  fp64 (the parity configuration): four lanes per environment, always -- coefficient blocks in LDS, no mailbox, no scratch
+    // to speak of; it scales with the batch in rounds of 16 384 environments (2.86 ms per round at n_sub 240).  fp32: four lanes per
+    // environment while the batch leaves SIMDs idle (B <= 16 384; shared crop parameters, default ODE), one lane per environment
+    // beyond.  GLGYM_LAYOUT = one | quad overrides for fp32 (read per launch: tests and tools switch it between steps).
+    const bool def = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+    if constexpr (sizeof(T) == 8) {
+        if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);
+        else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def);
+        else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def);
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
-    }
-    // Layout by batch size: four lanes per environment while the batch leaves SIMDs idle (GLGYM_LAYOUT = one | quad overrides).
-    // The quad kernels integrate RK4 of the default ODE with shared crop parameters and the interlights off.  fp64: the coefficient
-    // blocks live in LDS (rk_delta_quad<LDSQ>; with them in registers hipcc 7.2's spill code failed on this kernel), and fp64 takes
-    // the quad kernel at EVERY batch size: it has no mailbox traffic and scales with the batch in rounds of 16 384 environments
-    // (2.86 ms per round; B = 65 536: 11.7 ms, 5.6e6 env-steps/s), where the one-lane fp64 kernel goes memory-bound (7.8 ms at
-    // 24 576 with 6.4 GB of traffic).  profiles/r04_f64_rk4*_pmc_summary.csv, r04_variant_f64_b65536_bench_line.json
-    {
-        const char* le_ = std::getenv("GLGYM_LAYOUT");          // read per launch: tests and tools switch it between steps
+    } else {
+        const char* le_ = std::getenv("GLGYM_LAYOUT");
         const int layout_env = !le_ ? 0 : (le_[0] == 'q' ? 2 : 1);
-        const bool quad_ok = h->scheme == GLGYM_SCHEME_RK4 && !a->crop_p && !m.intLampActive;
+        const bool quad_ok = !pipe && !a->crop_p;
         const int b_small = 4 * h->n_simd * 4;                   // 16 384 on MI355X: one quad-kernel round
-        const bool by_size = a->B <= b_small || sizeof(T) == 8;    // fp64: always (round 4: 5.7 ms against the mailbox kernel's 7.8 at B = 24 576)
-        if (quad_ok && (layout_env == 2 || (layout_env == 0 && by_size))) {
-            const dim3 qgrid((4 * a->B + WAVE - 1) / WAVE);
-            const bool qdef = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
-            if (qdef) hipLaunchKernelGGL((step_kernel_quad<T, true>), qgrid, block, 0, st, k, m, rw);
-            else hipLaunchKernelGGL((step_kernel_quad<T, false>), qgrid, block, 0, st, k, m, rw);
+        if (quad_ok && (layout_env == 2 || (layout_env == 0 && a->B <= b_small))) {
+            if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);
+            else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def);
+            else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def);
             HIPCHK(hipGetLastError());
             return GLGYM_OK;
         }
+        if (pipe) {
+            hipLaunchKernelGGL((step_kernel<T, false, false, true>), grid, block, 0, st, k, m, rw);
+            HIPCHK(hipGetLastError());
+            return GLGYM_OK;
+        }
+        // The two-waves-per-SIMD build (256 registers + scratch) is taken on request only (GLGYM_OCC=2, read per launch): it spills and
+        // runs 0.70x the one-wave build at every batch size (profiles/r03_occupancy2_plain.txt).
+        const char* oe_ = std::getenv("GLGYM_OCC");
+        const bool occ2 = def && !a->crop_p && oe_ && std::atoi(oe_) == 2;
+        if (h->scheme == GLGYM_SCHEME_RK2) launch_step_sch<GLGYM_SCHEME_RK2>(a, k, m, rw, grid, block, st, def, occ2);
+        else if (h->scheme == GLGYM_SCHEME_RK3) launch_step_sch<GLGYM_SCHEME_RK3>(a, k, m, rw, grid, block, st, def, occ2);
+        else launch_step_sch<GLGYM_SCHEME_RK4>(a, k, m, rw, grid, block, st, def, occ2);
+        HIPCHK(hipGetLastError());
+        return GLGYM_OK;
     }
-    // fp64 (parity configuration) always takes the generic kernel: its RHS is an out-of-line call that receives the
-    // constant block by address, and only the kernarg copy has a usable one.
-    const bool def = h->use_specialised && sizeof(T) == 4 && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
-    // The two-waves-per-SIMD build (256 registers + scratch) is taken on request only (GLGYM_OCC=2).  Round 2 measured it 4 % ahead
-    // at B = 262 144; with round 3's integrator (wet surfaces as differences, closing evaluation, four-attempt ladder) it spills
-    // more and runs 0.70x the one-wave build at every batch size (profiles/r03_occupancy2_plain.txt).
-    const char* oe_ = std::getenv("GLGYM_OCC");               // read per launch, like GLGYM_LAYOUT (tests switch it between steps)
-    const bool occ2 = def && !a->crop_p && oe_ && std::atoi(oe_) == 2;
-    if (h->scheme == GLGYM_SCHEME_RK2) launch_step_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, grid, block, st, def, occ2);
-    else if (h->scheme == GLGYM_SCHEME_RK3) launch_step_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, grid, block, st, def, occ2);
-    else launch_step_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, grid, block, st, def, occ2);
-    HIPCHK(hipGetLastError());
-    return GLGYM_OK;
 }
 
 extern "C" int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream)

@@ -46,21 +46,19 @@ variant f32_rk4 "step_kernel<float, false, true, false, 0, 1>" 240 F32
 variant f32_rk3 "step_kernel<float, false, true, false, 2, 1>" 270 F32 --scheme rk3
 variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 336 F32 --scheme rk2
 variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 240 F32 --uncertainty 0.2
-# fp64 RK4 takes the four-lanes-per-environment kernel at every batch size (glgym.hip launch_step); the one-lane fp64 (mailbox) kernel
-# -- what the other fp64 schemes / ODE_pipe / per-env crop blocks still run -- is recorded with GLGYM_LAYOUT=one
-PBATCH=24576
-GLGYM_LAYOUT=one variant f64_rk4 "step_kernel<double, false, false, false, 0, 1>" 240 F64 --dtype f64 --batch 24576
+# fp64 runs the four-lanes-per-environment kernel at every batch size and in every variant (glgym.hip launch_step: the one-lane fp64
+# kernels with their LDS mailbox are gone; the handle's parameters are a kernel argument in fp64)
 PBATCH=65536
-variant f64_rk4_quad_b65536 "step_kernel_quad<double, true>" 240 F64 --dtype f64
+variant f64_rk4_quad_b65536 "step_kernel_quad<double, false, 0, false, false>" 240 F64 --dtype f64
 # the four-lanes-per-environment kernels (what batches up to 16 384 run), recorded at B = 4 096 (config 2 in fp64)
 PBATCH=4096
-variant f64_rk4_quad "step_kernel_quad<double, true>" 240 F64 --dtype f64 --batch 4096
-variant f32_rk4_quad "step_kernel_quad<float, true>" 240 F32 --batch 4096
+variant f64_rk4_quad "step_kernel_quad<double, false, 0, false, false>" 240 F64 --dtype f64 --batch 4096
+variant f32_rk4_quad "step_kernel_quad<float, true, 0, false, false>" 240 F32 --batch 4096
 PBATCH=65536
 python - <<PY
 import json
 out = {}
-for v in ("f32_rk4", "f32_rk3", "f32_rk2", "f32_rk4_config5", "f64_rk4", "f64_rk4_quad_b65536", "f64_rk4_quad", "f32_rk4_quad"):
+for v in ("f32_rk4", "f32_rk3", "f32_rk2", "f32_rk4_config5", "f64_rk4_quad_b65536", "f64_rk4_quad", "f32_rk4_quad"):
     try:
         out[v] = json.load(open("$OUT/%s/constants.json" % v))
     except OSError:
