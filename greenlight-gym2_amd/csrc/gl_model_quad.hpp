@@ -329,8 +329,9 @@ template <class T> __device__ __forceinline__ T gq_fast_max(const QVec<T>& a, P2
 // ORDER: 4 (RK4), 3 (three-stage scheme), 2 (midpoint rule) -- rk_delta's three members of the exponential family.
 // LDSC: the crop constants `cr` are a per-quad LDS record as well (per-env crop blocks); otherwise they are part of `m` and their
 // address must NOT reach the fence (it would force a private copy of the whole kernel argument).
-#define GQ_FENCE() do { if (LDSQ && LDSC) asm volatile("" : : "v"(&s), "v"(&K), "v"(&cr) : "memory"); \
-                        else if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K) : "memory"); } while (0)
+// (LDSQ builds hold the parameter block `m` in LDS too: its address joins the fence)
+#define GQ_FENCE() do { if (LDSQ && LDSC) asm volatile("" : : "v"(&s), "v"(&K), "v"(&m), "v"(&cr) : "memory"); \
+                        else if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K), "v"(&m) : "memory"); } while (0)
 template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
 __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
                                               const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st)

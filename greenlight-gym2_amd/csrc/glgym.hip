@@ -304,7 +304,19 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
 template <class T, bool DEFAULT_P, int SCH = 0, bool PIPE = false, bool CROP = false>
 __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
-    const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
+    // fp64: the handle's parameter block is staged in LDS as well (one uniform record per wavefront, broadcast reads behind the stage
+    // fence): as a kernel argument its ~180 doubles live in SGPRs, of which there are 100 -- the compiler parks the rest in VGPR
+    // lanes and pays two v_readlane per use (2 000 of the kernel's 20 000 static instructions)
+    constexpr bool LDSM = sizeof(T) == 8 && !DEFAULT_P;
+    __shared__ ModelConst<T> sh_m[1];
+    if (LDSM) {
+        static_assert(sizeof(ModelConst<T>) % 4 == 0, "word copy");
+        const unsigned* src = reinterpret_cast<const unsigned*>(&m_arg);
+        unsigned* dst = reinterpret_cast<unsigned*>(&sh_m[0]);
+        for (int i = threadIdx.x; i < (int)(sizeof(ModelConst<T>) / 4); i += WAVE) dst[i] = src[i];
+        __syncthreads();                       // one wavefront per block
+    }
+    const ModelConst<T>& m = LDSM ? sh_m[0] : DEFAULT_P ? device_default<T>() : m_arg;
     const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3;
     const int b = gl >> 2;
     const bool live = b < a.B;
@@ -480,9 +492,18 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
 // ---------------------------------------------------------------------------------------------------
 template <class T, int SCH, bool PIPE, bool CROP>
 __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const double* u, const double* d, const double* crop, int B, T dt,
-                                                          int n_sub, T gasR, T tCanMin, ModelConst<T> m, double* x_next, int nd,
+                                                          int n_sub, T gasR, T tCanMin, ModelConst<T> m_arg, double* x_next, int nd,
                                                           int* n_failed, int verify, int pipe)
 {
+    constexpr bool LDSM = sizeof(T) == 8;      // the parameter block in LDS (step_kernel_quad)
+    __shared__ ModelConst<T> sh_m[1];
+    if (LDSM) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&m_arg);
+        unsigned* dst = reinterpret_cast<unsigned*>(&sh_m[0]);
+        for (int i = threadIdx.x; i < (int)(sizeof(ModelConst<T>) / 4); i += WAVE) dst[i] = src[i];
+        __syncthreads();
+    }
+    const ModelConst<T>& m = LDSM ? sh_m[0] : m_arg;
     const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3, b = gl >> 2;
     const bool live = b < B;
     const int bb = live ? b : B - 1;
