@@ -240,9 +240,11 @@ int glgym_set_obs_modules(glgym_handle h, const int32_t* modules, int n);
 int glgym_obs_dim(glgym_handle h, int Np);
 
 /* Device pointers; asynchronous on `stream` (a hipStream_t, NULL = default stream).
- * glgym_step picks its kernel layout per launch: one lane per environment, or -- RK4, shared crop parameters,
- * interlights off; B <= 16 384, and in fp64 at every batch size -- four lanes per environment (csrc/gl_model_quad.hpp).  Same scheme
- * decision for decision, results equal to rounding.  Environment variable GLGYM_LAYOUT = one | quad overrides (read per launch). */
+ * glgym_step picks its kernel layout per launch.  GLGYM_F64: four lanes per environment (csrc/gl_model_quad.hpp) in every scheme,
+ * ODE variant and batch size -- the only fp64 integrator on the device.  GLGYM_F32: four lanes per environment for B <= 16 384 with
+ * shared crop parameters and the default ODE (every scheme), one lane per environment otherwise; environment variable
+ * GLGYM_LAYOUT = one | quad overrides that choice (fp32 only; read per launch).  Same scheme decision for decision in both layouts,
+ * results equal to rounding. */
 int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream);
 int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream);
 int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream);

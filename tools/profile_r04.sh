@@ -9,6 +9,7 @@ OUT=gpurun_out/r04_prof
 mkdir -p $OUT
 variant() {   # name, kernel-name pattern, n_sub, counter suffix, bench args...
   name=$1; pat=$2; nsub=$3; sfx=$4; shift 4
+  if [ -n "$ONLY" ] && [[ ! "$name" =~ $ONLY ]]; then return; fi       # ONLY=regex: re-record a subset of the variants
   V=$OUT/$name; mkdir -p $V
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" \
@@ -39,9 +40,11 @@ PY
 }
 # default workload: kernel-trace --stats summary + bench line (--no-parity: the accuracy leg launches the same kernel 961 times at B = 64,
 # which would mix into the per-kernel average)
+if [ -z "$ONLY" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 300 --warmup 100 --no-parity > $OUT/bench_stats.log 2>&1
 grep "^{" $OUT/bench_stats.log > $OUT/r04_rk4_bench_line.json
 f=$(ls $OUT/stats/*/*kernel_stats.csv | head -1); python tools/condense_stats.py $f $OUT/r04_rk4_bench_kernel_stats.csv; rm -rf $OUT/stats
+fi
 variant f32_rk4 "step_kernel<float, false, true, false, 0, 1>" 240 F32
 variant f32_rk3 "step_kernel<float, false, true, false, 2, 1>" 270 F32 --scheme rk3
 variant f32_rk2 "step_kernel<float, false, true, false, 1, 1>" 336 F32 --scheme rk2
@@ -49,10 +52,10 @@ variant f32_rk4_config5 "step_kernel<float, true, true, false, 0, 1>" 240 F32 --
 # fp64 runs the four-lanes-per-environment kernel at every batch size and in every variant (glgym.hip launch_step: the one-lane fp64
 # kernels with their LDS mailbox are gone; the handle's parameters are a kernel argument in fp64)
 PBATCH=65536
-variant f64_rk4_quad_b65536 "step_kernel_quad<double, false, 0, false, false>" 240 F64 --dtype f64
+variant f64_rk4_quad_b65536 "step_kernel_quad<double, false, 0, true, false>" 240 F64 --dtype f64
 # the four-lanes-per-environment kernels (what batches up to 16 384 run), recorded at B = 4 096 (config 2 in fp64)
 PBATCH=4096
-variant f64_rk4_quad "step_kernel_quad<double, false, 0, false, false>" 240 F64 --dtype f64 --batch 4096
+variant f64_rk4_quad "step_kernel_quad<double, false, 0, true, false>" 240 F64 --dtype f64 --batch 4096
 variant f32_rk4_quad "step_kernel_quad<float, true, 0, false, false>" 240 F32 --batch 4096
 PBATCH=65536
 python - <<PY
