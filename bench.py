@@ -291,12 +291,10 @@ def main():
     def one_step(i, ev=None):
         # the full SB3-semantics step: control update + fused ODE step kernel + observation block + auto-reset of
         # finished envs (new episode start drawn in-kernel, terminal observation kept, their obs rows recomputed).
-        # The random policy draws a FRESH U(-1, 1) action block every step, inside the timed region (two small
-        # device kernels).  (Rounds 1-3 cycled through 32 pre-drawn blocks: with period-32 increments every control drifts
+        # The random policy draws a FRESH U(-1, 1) action block every step, inside the timed region.  (Rounds 1-3 cycled through 32 pre-drawn blocks: with period-32 increments every control drifts
         # to one of its bounds and stays there -- half of the environments with the vents fully open is not what a random
-        # policy does.)
-        torch.rand(B, 6, generator=gen, device=dev, out=env.action_t)
-        env.action_t.mul_(2.0).sub_(1.0)
+        # policy does.)  One device kernel: uniform_ draws U(-1, 1) in place.
+        env.action_t.uniform_(-1.0, 1.0, generator=gen)
         if ev is not None:
             ev[0].record()
         env._launch_step(raw_control=False)
