@@ -182,7 +182,7 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const P2<T> fluxA = hecA * dA;                                   // into the surface
     // ---- second exchange: screens -> top compartment
     const P2<T> dB = Tp - gq_sp<T>(tTop);
-    const P2<T> hecB = K.cB * gq_mk<T>(M::powa(M::abs(dB.x + eps), third), M::powa(M::abs(dB.y + eps), third));
+    const P2<T> hecB = K.cB * gq_mk<T>(M::cbrta(M::abs(dB.x + eps)), M::cbrta(M::abs(dB.y + eps)));
     const P2<T> fluxB = hecB * dB;
     // ---- saturation pressure, condensation gate, transpiration
     const P2<T> rr = gq_mk<T>(M::rcp(Tp.x + T(238.3)), M::rcp(Tp.y + T(238.3)));
