@@ -407,6 +407,45 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     env.close()
 
 
+@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 3), ("rk2", 2, 4), ("rk3", 3, 3)])
+def test_fp64_per_env_crop_blocks_in_every_scheme(golden, oracle, scheme, order, win):
+    """The fp64 kernels that take PER-ENVIRONMENT crop constants (a per-quad record in LDS; `step_kernel_quad<double, ..., CROP>` and
+    `evalf_kernel_quad<double, ..., CROP>`, one instantiation per scheme) against the CPU checker's restatement fed each
+    environment's own 208-vector: 48 environments with +-10 % crop noise, three env-steps from a spun-up state through glgym_step,
+    and the same tuples through glgym_evalF with per-row parameter blocks, to rounding level."""
+    import torch
+    from gl_gym_amd import GreenLight
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    w = golden("rollout_10day")["weather"]
+    B = 48
+    env = TomatoVecEnv(B, weather=w, dtype="float64", scheme=scheme, season_length=2, uncertainty_scale=0.2, seed=5, start_rows=[0, 130, 400],
+                       auto_reset=False)
+    env.reset()
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme)
+    m.set_verify("never")                                      # the action path below integrates guarded, unverified
+    gen = torch.Generator(device=env.device); gen.manual_seed(23)
+    w_off = env.w_off_t.cpu().numpy()
+    worst_step, worst_evalf = 0.0, 0.0
+    for k in range(3):
+        x_prev = env.x.double().cpu().numpy().copy()
+        env.step_tensor(torch.rand(B, 6, generator=gen, device=env.device) * 2 - 1, want_obs=False)
+        crop = env.crop_T[:, :B].double().cpu().numpy()          # the blocks the kernel integrated with (re-drawn every step)
+        u = env.u.double().cpu().numpy()
+        xg = env.x.double().cpu().numpy()
+        P = np.tile(env.p.astype(np.float64), (B, 1)); P[:, 128:162] = crop.T
+        D = np.array([w[w_off[b] + k] for b in range(B)])
+        Y = m.evalF_batch(x_prev, u, D, P)
+        for b in range(B):
+            ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[b], u[b], D[b], P[b], 900.0, env.n_sub, order, win)
+            assert not failed
+            worst_step = max(worst_step, scaled_err(xg[b][None], ref[None]))
+            worst_evalf = max(worst_evalf, scaled_err(np.asarray(Y[b])[None], ref[None]))
+    print(f"fp64 per-env crop blocks, {scheme}: glgym_step {worst_step:.1e}, glgym_evalF {worst_evalf:.1e} vs the checker's scheme")
+    assert worst_step < 1e-10 and worst_evalf < 1e-10
+    assert np.std(crop[0] / env.p[128]) > 0.03                   # the blocks really differ between environments
+    env.close(); m.close()
+
+
 def test_stability_control_in_storm(golden, oracle):
     """Wind 19.5 m/s with vents and screens open pushes the top-compartment exchange rate past RK4-256's stability
     limit during the step: the plain fixed-step scheme overflows there.  The stability control gives those windows
