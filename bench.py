@@ -141,18 +141,20 @@ def cpu_baseline(n_sub: int, budget_s: float = 8.0):
 
     per = 32
     done, evals, el = timed(lambda k: bdf_slice((k * per) % n, (k * per) % n + per), per, 1, budget_s)
-    bdf_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port-adaptive-implicit",
+    bdf_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+               "algorithm": "variable-order BDF, rtol = atol = 1e-6 (the reference integrator's family and tolerances)",
                "rhs_evaluations_per_env_step": evals / done,
                "sample": f"{done} env-steps (fp64 C restatement: variable-order BDF, rtol = atol = 1e-6, ODE step only) in {el:.1f} s"}
     done, evals, el = timed(lambda k: bdf_slice((k * per) % n, (k * per) % n + per), per, cores, budget_s / 2)
-    bdf_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port-adaptive-implicit",
+    bdf_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+               "algorithm": "variable-order BDF, rtol = atol = 1e-6",
                "rhs_evaluations_per_env_step": evals / done,
                "sample": f"{done} env-steps on {cores} threads (= CPUs granted to this container) in {el:.1f} s"}
 
     def rk(k):
         O.rk4_batch(X[:64], U[:64], D[:64], p, 900.0, n_sub)
     done, _, el = timed(rk, 64, 1, budget_s / 2)
-    rk_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "rhs_evaluations_per_env_step": 4 * n_sub,
+    rk_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "algorithm": "the kernels' own scheme family: RK4, fixed sub-steps", "rhs_evaluations_per_env_step": 4 * n_sub,
               "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
     done, _, el = timed(rk, 64, cores, budget_s / 2)
     rk_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port", "rhs_evaluations_per_env_step": 4 * n_sub,

@@ -642,8 +642,8 @@ def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
 
 @pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 3), ("rk2", 2, 4), ("rk3", 3, 3)])
 def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win):
-    """The fp64 kernels sit at the register limit and hipcc 7.2 has miscompiled them before (round 4: the
-    builds with the default parameter block compiled in computed wrong slow states and are not shipped): every env-step of a short
+    """The fp64 kernels sit at the register limit and hipcc 7.2 has miscompiled them before (round 4: builds
+    with the default parameter block compiled in computed wrong slow states -- traced to the max-ilp scheduler flag, since removed): every env-step of a short
     rollout must agree with the oracle's restatement of the same scheme to rounding level, through glgym_step AND glgym_evalF (two
     different kernels around the same four-lanes-per-environment integrator)."""
     import torch

@@ -6,7 +6,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 csrc = ROOT / "greenlight-gym2_amd" / "csrc"
 out = Path("/tmp/glgym_isa.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize",
                        "--offload-arch=gfx950", "-std=c++17", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out),
                        str(csrc / "glgym.hip")] + sys.argv[1:])
 s = out.read_text()
