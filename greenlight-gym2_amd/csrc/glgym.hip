@@ -144,21 +144,21 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #define GL_RK4_WIN_F64 3
 #endif
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : GL_RK4_WIN_F64; };
-// SCH (template argument of the integrating kernels) = GLGYM_SCHEME_*: 0 classical RK4, 1 explicit midpoint (four sub-steps
-// per tier-2b window), 2 Bogacki-Shampine (three)
+// SCH (template argument of the integrating kernels) = GLGYM_SCHEME_*: 0 RK4, 1 the midpoint member (four sub-steps per tier-2b
+// window), 2 the three-stage member (three) of the exponential family (gl_model.hpp rk_delta)
 constexpr int gl_order(int sch) { return sch == 0 ? 4 : sch == 1 ? 2 : 3; }
 template <class T, int SCH> struct SchemeWin { static constexpr int value = SCH == 0 ? RK4_WINDOW<T>::value : SCH == 1 ? 4 : 3; };
 
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
-// SCH = GLGYM_SCHEME_RK2 / _RK3: explicit-midpoint / Bogacki-Shampine sub-steps, tier 2b and the harvest flow shared by four / three of them
-// instead of classical RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.
+// SCH = GLGYM_SCHEME_RK2 / _RK3: midpoint / three-stage sub-steps, tier 2b and the harvest flow shared by four / three of them,
+// instead of RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.  One lane per environment: fp32 only.
 // OCC = waves per SIMD the kernel is compiled for.  1 (default): up to 512 registers per lane, no scratch -- the right choice
 // when the batch gives every SIMD one wave (B <= 65 536).  2: 256 registers per lane (spills go to scratch) so that two
 // waves share a SIMD -- a lone wave issues a vector instruction only every ~5 cycles, two co-resident waves one every
 // ~2.7 (tools/microbench.hip with verified placement, profiles/r02_microbench_issue_rates.txt).  Measured on this kernel
-// (profiles/r02_occupancy2_variant.txt): the spills eat most of it -- B = 131 072: 5.64e7 vs 5.60e7 env-steps/s,
-// B = 262 144: 6.04e7 vs 5.75e7 -- so it is used from four waves per SIMD on; at B = 65 536 the dispatcher packs the 1 024
-// waves two per SIMD onto half the chip (3.1e7).
+// (profiles/r02_occupancy2_variant.txt, r03_occupancy2_plain.txt): the spills eat all of it -- 0.70x the one-wave build since
+// round 3 -- so it is taken on request only (GLGYM_OCC=2, launch_step); at B = 65 536 the dispatcher would pack its 1 024 waves two
+// per SIMD onto half the chip (3.1e7).
 template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, int SCH = 0, int OCC = GL_STEP_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
