@@ -420,6 +420,10 @@ def main():
             # proportional to 1 / live kernel time.
             need_guide = wide * ((valu - trans) * CYC_PLAIN_GUIDE + trans * CYC_TRANS_GUIDE)
             need_meas = wide * ((valu - trans) * CYC_PLAIN + trans * CYC_TRANS)
+            # a v_pk_*_f32 op is two lane-operations: it holds the SIMD for 4 cycles (same flop rate as two plain ops), but the PMC
+            # counts it once; with the packed share of the shipped ISA's sub-step loop the slots the instruction stream really needs
+            pk = valu * float(pmc.get("pk_share_static") or 0.0)
+            need_pk = wide * ((valu - trans - pk) * CYC_PLAIN_GUIDE + pk * 2 * CYC_PLAIN_GUIDE + trans * CYC_TRANS_GUIDE)
             roof.update({
                 # executed flops (64 lanes; FMA = 2; packed ops are counted once by the PMC, so this is a lower bound)
                 "achieved": 64 * (2 * fma + mul + add) / t_s / 1e12,
@@ -427,6 +431,12 @@ def main():
                 "frac_note": "executed issue slots / available on the GUIDE's ruler: ((INSTS_VALU - TRANS) x 2 + TRANS x 8 cycles"
                              + (", x 2 for fp64" if wide > 1 else "") + ") / (1024 SIMDs x live kernel time x 2.4 GHz), instruction "
                              "counts from the recorded PMC passes of this variant; <= 1 by construction",
+                "frac_packed_weighted": need_pk / (N_SIMD * t_s * CLOCK_GUIDE_HZ),
+                "frac_packed_weighted_note": "the guide's ruler with packed fp32 ops at their real cost of 4 cycles (%.0f %% of this "
+                                             "variant's vector instructions, tools/pk_share.py on the shipped ISA): the share of the "
+                                             "issue capacity this instruction stream could occupy at ANY occupancy; `frac` counts a "
+                                             "packed op as one 2-cycle slot and is the conservative figure"
+                                             % (100 * float(pmc.get("pk_share_static") or 0.0)),
                 "frac_measured_ruler": need_meas / (N_SIMD * t_s * clk * 1e9),
                 "frac_measured_ruler_note": "same with the issue costs measured on this chip with >= 2 co-resident waves (2.3 / 7.7 "
                                             "cycles, profiles/r02_microbench_issue_rates.txt) and " + clk_note,
