@@ -132,16 +132,19 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 #ifndef GL_STEP_WAVES_PER_SIMD
 #define GL_STEP_WAVES_PER_SIMD 1
 #endif
-// Tier-2b / harvest window of the RK4 scheme: THREE sub-steps (11.25 s at the default n_sub 240) in both precisions (round 4; two
-// before).  Measured on the GPU against the two-sub-step window at the same n_sub: 7.64e7 against 6.82e7 env-steps/s; 10-day fixture
-// 2.43e-5 against 2.41e-5 (fp32), one-step stress identical (kinds 0-3 clean, 99.9 % quantile 4.4e-5 against 5.2e-5); the tight
-// one-step tuples 3.5e-5 against 2.4e-5 in fp64 -- all of it one artificial tuple that starts with an EMPTY carbohydrate buffer
-// (the CPU study rk3e_study).  (Midpoint scheme: 4 sub-steps, three-stage scheme: 3.)
+// Tier-2b / harvest window of the RK4 scheme: FOUR sub-steps (15 s at the default n_sub 240) in both precisions (round 4; two in
+// round 3, three mid-round).  The per-window work -- tier 2b, the rate-bound stage, estimate, limiter: 820 instructions -- is then
+// shared by 16 stages.  Measured on the GPU, window 2 / 3 / 4 at n_sub 240: 6.82e7 / 7.7e7 / 8.15e7 env-steps/s; 10-day fixture
+// fp32 2.41e-5 / 2.43e-5 / 2.93e-5, fp64 8.3e-6 / 8.5e-6 / 1.5e-5; storm fixture 4e-6 -> 8e-6, jump fixture 2.5e-5 -> 4.5e-5 (0 of
+// 576 above 1e-4, 0 failed); tight one-step tuples 2.4e-5 / 3.5e-5 / 6.2e-5 in fp64 -- all of the growth one artificial tuple that
+// starts with an EMPTY carbohydrate buffer (every other tuple 2.4e-5 at any window; the CPU studies); 0 flagged
+// first attempts in 1.3e8 env-steps of the bench workload.  Window 5 would put that tuple at 9.6e-5: not taken.
+// (Midpoint scheme: 4 sub-steps, three-stage scheme: 3.)
 #ifndef GL_RK4_WIN_F32
-#define GL_RK4_WIN_F32 3
+#define GL_RK4_WIN_F32 4
 #endif
 #ifndef GL_RK4_WIN_F64
-#define GL_RK4_WIN_F64 3
+#define GL_RK4_WIN_F64 4
 #endif
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : GL_RK4_WIN_F64; };
 // SCH (template argument of the integrating kernels) = GLGYM_SCHEME_*: 0 RK4, 1 the midpoint member (four sub-steps per tier-2b

@@ -25,13 +25,13 @@ SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3}
 # exponential family (stability interval 2.513: 270 covers 0.69 1/s), "rk2" its midpoint rule (2.0: 336 covers 0.69 1/s).
 DEFAULT_N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270}
 VERIFY_MODES = {"auto": 0, "always": 1, "never": 2}     # glgym_verify (include/glgym.h)
-N_SUB_MULTIPLE = {"rk4": 3, "rk2": 4, "rk3": 3}          # widest tier-2b window of the scheme
+N_SUB_MULTIPLE = {"rk4": 4, "rk2": 4, "rk3": 3}          # widest tier-2b window of the scheme
 
 
 def default_n_sub(scheme: str, dt: float) -> int:
     """Nominal sub-steps per env-step when the caller gives none: the scheme's count for the reference's dt = 900 s,
-    scaled with dt so that the nominal sub-step h = dt / n_sub stays the same (3.75 s RK4, 3.33 s three-stage scheme, 2.68 s midpoint) -- e.g. 81 for
-    the dt = 300 s of experiments/run_time.py; rounded up to a multiple of the scheme's tier-2b window (3, 4, 3)."""
+    scaled with dt so that the nominal sub-step h = dt / n_sub stays the same (3.75 s RK4, 3.33 s three-stage scheme, 2.68 s midpoint) -- e.g. 80 for
+    the dt = 300 s of experiments/run_time.py; rounded up to a multiple of the scheme's tier-2b window (4, 4, 3)."""
     n = DEFAULT_N_SUB[scheme] * float(dt) / 900.0
     mult = N_SUB_MULTIPLE[scheme]
     return max(mult, int(-(-n // mult) * mult))

@@ -83,10 +83,10 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     nominal sub-step is then set by the top compartment's air exchange: use n_sub 240 (nominal environments cover rates up to
  *     0.68 1/s).  An environment whose rate bound at the start of the env-step asks for a shorter sub-step gets proportionally
  *     more windows (up to 2x); what changes during the env-step is followed window by window.  The slow sub-expressions and the
- *     harvest flow are evaluated once per window of three nominal sub-steps in both precisions (n_sub is rounded up to a multiple of 3).
- *     That window is what sets the accuracy at a given n_sub (max scaled error on the tight one-step tuples, fp64: 3.5e-5 at 240,
- *     8.7e-6 at 480, 3.9e-6 at 720; 10-day rollout 8.5e-6 at 240): for PARITY runs against the reference's solver set n_sub 480,
- *     which sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances (tests/test_gpu_parity.py).
+ *     harvest flow are evaluated once per window of four nominal sub-steps in both precisions (n_sub is rounded up to a multiple of 4).
+ *     That window is what sets the accuracy at a given n_sub (max scaled error on the tight one-step tuples, fp64: 6.2e-5 at 240,
+ *     1.5e-5 at 480, 8.7e-6 at 640, 6.9e-6 at 720; 10-day rollout 1.5e-5 at 240): for PARITY runs against the reference's solver set
+ *     n_sub 640, which sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances (tests/test_gpu_parity.py).
  *   GLGYM_SCHEME_RK2: the midpoint rule of the same family (ETD2RK on the cover conduction, explicit midpoint elsewhere; stability
  *     interval 2.0): use n_sub 336.  30 % fewer right-hand sides than RK4; the slow sub-expressions and the harvest flow are shared
  *     by four nominal sub-steps (n_sub is rounded up to a multiple of 4).  Second order: the least accurate of the three (tight

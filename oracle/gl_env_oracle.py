@@ -155,8 +155,8 @@ class OracleTomatoEnv:
     def _evalF(self, x, u, d, p):
         p = np.asarray(p, dtype=np.float64)
         if self.integrator == "rk4":            # the kernels' scheme: stability-controlled RK4, Strang-split exact harvest
-            # flow, tier 2b once per window of three sub-steps, guard retries
-            return O.rk_sc_guarded(x, u, d, p, self.dt, self.n_sub, 4, getattr(self, "window", 3))[0]
+            # flow, tier 2b once per window of four sub-steps, guard retries
+            return O.rk_sc_guarded(x, u, d, p, self.dt, self.n_sub, 4, getattr(self, "window", 4))[0]
         if self.integrator == "rk4_plain":      # classical RK4 of the complete RHS
             return O.rk4(x, u, d, p, self.dt, self.n_sub)
         if self.integrator == "stiff":

@@ -129,7 +129,7 @@ def rk4_lagged(x, u, d, p, dt=900.0, n_sub=256, pipe=False):
 
 def rk_lagged(x, u, d, p, dt=900.0, n_sub=256, order=4, window=1, pipe=False):
     """The kernels' fixed-step schemes without the stability control: RK order 2 / 3 / 4 with tier 2b and the harvest flow
-    shared by `window` sub-steps (the kernels: RK4 window 2, RK3 window 3, midpoint window 4)."""
+    shared by `window` sub-steps (the kernels: RK4 window 4, three-stage scheme window 3, midpoint window 4)."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, 14 if pipe else ND), _c(p, NP)
     out = np.empty(NX)
     (lib().gl_oracle_rk_lagged_pipe if pipe else lib().gl_oracle_rk_lagged)(
@@ -137,7 +137,7 @@ def rk_lagged(x, u, d, p, dt=900.0, n_sub=256, order=4, window=1, pipe=False):
     return out
 
 
-def rk_sc(x, u, d, p, dt=900.0, n_sub=240, order=4, window=3):
+def rk_sc(x, u, d, p, dt=900.0, n_sub=240, order=4, window=4):
     """The kernels' stability-controlled sub-stepper (gl_oracle.c rk_sc_impl).  Returns (x_next, stats) with
     stats = [sub-steps taken, max error-estimate ratio, max rate bound, flags]."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, ND), _c(p, NP)
@@ -147,7 +147,7 @@ def rk_sc(x, u, d, p, dt=900.0, n_sub=240, order=4, window=3):
     return out, st
 
 
-def rk_sc_guarded(x, u, d, p, dt=900.0, n_sub=240, order=4, window=3, pipe=False, verify=False, want_flags=False):
+def rk_sc_guarded(x, u, d, p, dt=900.0, n_sub=240, order=4, window=4, pipe=False, verify=False, want_flags=False):
     """rk_sc with the kernels' guard (step-doubling ladder n, 2n, 4n, 8n).  Returns (x_next, retries, refined sub-steps beyond
     n_sub, failed) and, with want_flags, the kernels' step_flags word (include/glgym.h GLGYM_SF_*) as a fifth entry."""
     x, u, d, p = _c(x, NX), _c(u, NU), _c(d, 14 if pipe else ND), _c(p, NP)

@@ -149,7 +149,7 @@ def hostmath():
         assert rc == 0, "unsupported (order, window)"
         return (out, st) if stats else out            # st = [sub-steps taken, SC_FLAG_* bits]
 
-    def _step_guarded(x, u, d_, p, f32=False, dt=900.0, n_sub=240, order=4, window=3, verify=False):
+    def _step_guarded(x, u, d_, p, f32=False, dt=900.0, n_sub=240, order=4, window=4, verify=False):
         """The guarded step map as the kernels call it: (x_next, retries, extra sub-steps, failed)."""
         out = np.empty(28)
         st = np.zeros(2)

@@ -172,15 +172,15 @@ def test_quad_kernel_isa_keeps_its_spill_free_inner_loops(tmp_path):
 
 def test_scheme_table_and_default_sub_step_counts():
     """Host-side scheme constants agree with include/glgym.h, and the nominal sub-step keeps its length when dt changes
-    (multiples of the scheme's tier-2b window: RK4 -> 4, Bogacki-Shampine -> 3, midpoint -> 4)."""
+    (multiples of the scheme's tier-2b window: RK4 -> 4, three-stage scheme -> 3, midpoint -> 4)."""
     import re
     from gl_gym_amd import _lib as L
     hdr = (ROOT / "include" / "glgym.h").read_text()
     enum = dict((k, int(v)) for k, v in re.findall(r"(GLGYM_SCHEME_RK\d) = (\d)", hdr))
     assert enum == {"GLGYM_SCHEME_RK4": L.SCHEMES["rk4"], "GLGYM_SCHEME_RK2": L.SCHEMES["rk2"], "GLGYM_SCHEME_RK3": L.SCHEMES["rk3"]}
     assert [L.default_n_sub(s, 900.0) for s in ("rk4", "rk3", "rk2")] == [240, 270, 336]
-    assert [L.default_n_sub(s, 300.0) for s in ("rk4", "rk3", "rk2")] == [81, 90, 112]
+    assert [L.default_n_sub(s, 300.0) for s in ("rk4", "rk3", "rk2")] == [80, 90, 112]
     assert [L.default_n_sub(s, 1800.0) for s in ("rk4", "rk3", "rk2")] == [480, 540, 672]
-    assert L.default_n_sub("rk3", 1.0) == 3 and L.default_n_sub("rk4", 1.0) == 3
+    assert L.default_n_sub("rk3", 1.0) == 3 and L.default_n_sub("rk4", 1.0) == 4
     assert int(re.search(r"#define GLGYM_METRIC_REPLICAS (\d+)", hdr).group(1)) == L.METRIC_REPLICAS
     assert int(re.search(r"#define GLGYM_METRIC_STRIDE (\d+)", hdr).group(1)) == L.METRIC_STRIDE >= L.NMETRIC

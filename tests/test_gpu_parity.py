@@ -58,28 +58,30 @@ def test_evalF_signature_and_value(models, golden, oracle):
     out = m64.evalF(X[0], U[0], D[0], P[0])
     assert isinstance(out, list) and len(out) == 28 and all(isinstance(v, float) for v in out)
     ok = np.ones(len(X), dtype=bool)          # every tuple, incl. the harvest-switch zone (exact sub-flow)
-    ref = np.array([oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, 256, 4, 3)[0] for i in range(len(X))])
+    ref = np.array([oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, 256, 4, 4)[0] for i in range(len(X))])
     got64 = np.array([m64.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
     got32 = np.array([m32.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
     assert scaled_err(got64[ok], ref[ok]) < 1e-9
     assert scaled_err(got32[ok], ref[ok]) < 2e-5
     # vs the tight stiff solve on perturbed (off-equilibrium) tuples; the CVODES-tolerance proxy (BDF rtol=atol=1e-6) sits
-    # at 1.3e-5 on the same tuples.  Round 4 (cover conduction exact, nominal sub-step 3.5 - 3.75 s, two-sub-step tier-2b
-    # window of 10.5 - 11.25 s): 3.0e-5 / 3.5e-5 -- one artificial tuple that starts with an empty carbohydrate buffer carries it
-    # (cBuf 0 -> 274 mg in the step, 0.01 mg off; every other state of every tuple < 2.4e-5) -- a third of the 1e-4 bar
-    assert scaled_err(got64[ok], XT[ok]) < 3.6e-5
+    # at 1.3e-5 on the same tuples.  Round 4 (cover conduction exact, nominal sub-step 3.5 - 3.75 s, four-sub-step tier-2b
+    # window of 14 - 15 s): 5.4e-5 / 6.2e-5 -- one artificial tuple that starts with an empty carbohydrate buffer carries it
+    # (cBuf 0 -> 274 mg in the step, 0.02 mg off; every other state of every tuple < 2.4e-5, asserted below) -- inside the 1e-4 bar
+    assert scaled_err(got64[ok], XT[ok]) < 5.6e-5
+    rest = np.array([i for i in range(len(X)) if i != 61])
+    assert scaled_err(got64[rest], XT[rest]) < 2.5e-5
     from gl_gym_amd import GreenLight
     m_def = GreenLight(28, 6, 10, 208, 900.0, dtype="float64")
     assert m_def.n_sub == 240
     e_def = scaled_err(m_def.evalF_batch(X, U, D, P), XT)
     m_def.close()
     print(f"fp64 RK4 vs tight one-step solutions: n_sub 256 {scaled_err(got64[ok], XT[ok]):.2e}, default 240 {e_def:.2e}")
-    assert e_def < 3.6e-5
-    # the PARITY configuration (include/glgym.h): n_sub 480 sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances
-    m_par = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=480)
+    assert e_def < 6.3e-5
+    # the PARITY configuration (include/glgym.h): n_sub 640 sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances
+    m_par = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=640)
     e_par = scaled_err(m_par.evalF_batch(X, U, D, P), XT)
     m_par.close()
-    print(f"fp64 RK4 parity configuration n_sub 480: {e_par:.2e} (BDF rtol = atol = 1e-6 on the same tuples: {scaled_err(g['X_bdf1e6'], XT):.2e})")
+    print(f"fp64 RK4 parity configuration n_sub 640: {e_par:.2e} (BDF rtol = atol = 1e-6 on the same tuples: {scaled_err(g['X_bdf1e6'], XT):.2e})")
     assert e_par < 1.3e-5
     # batched call with per-row crop parameters == row-by-row calls
     got_b = m64.evalF_batch(X[:16], U[:16], D[:16], P[:16])
@@ -130,8 +132,8 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme):
     n_steps = len(acts)
     if dtype == "float64":
         # the midpoint rule at n_sub = 336: second order, 7.6e-6 / 9.6e-6 in fp64; RK4 at its round-4 nominal count of 240
-        # (3.75 s sub-steps, 7.5 s tier-2b windows): 3.8e-6 / 6.0e-6; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6
-        tol = 1e-5
+        # (3.75 s sub-steps, 15 s tier-2b windows): 1.5e-5 / 1.4e-5; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6
+        tol = 2e-5 if scheme == "rk4" else 1e-5
     env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
                        auto_reset=False)
     env.reset()
@@ -274,7 +276,7 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
             xg = env.x.double().cpu().numpy()
             for b in range(0, 64, 9):
                 u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-                ref = oracle.rk_sc_guarded(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256, 4, 3)[0]
+                ref = oracle.rk_sc_guarded(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256, 4, 4)[0]
                 assert scaled_err(xg[b], ref) < tol, (dtype, k, b)
         env.close()
 
@@ -295,7 +297,7 @@ def test_config1_rule_based_day_against_fixture(golden):
     X, R, U, INFO, OBS = g["x"], g["reward"], g["u"], g["info"], g["obs"]
     keys = [str(k) for k in g["info_keys"]]
     ctrl = RuleBasedController()
-    for n_sub, tol in ((1024, 2.5e-6), (256, 6e-5)):     # 1024: tier-2b windows of 2.6 s (three sub-steps): 1.8e-6
+    for n_sub, tol in ((1024, 4e-6), (256, 8e-5)):       # 1024: tier-2b windows of 3.5 s (four sub-steps)
         env = TomatoVecEnv(8, weather=g["weather"], params=g["p"], dtype="float64", n_sub=n_sub, season_length=1,
                            start_rows=[0], start_days=[0.0], auto_reset=False)
         obs = env.reset()
@@ -345,7 +347,7 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
         for b in range(0, B, 11):
             p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
             u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-            ref = oracle.rk_sc_guarded(x_prev[b], u, w[k], p, 900.0, 256, 4, 3)[0]
+            ref = oracle.rk_sc_guarded(x_prev[b], u, w[k], p, 900.0, 256, 4, 4)[0]
             assert scaled_err(xg[b], ref) < 5e-5
     assert len(np.unique(crop[1])) > B // 2                                            # envs really differ
     assert env.metrics()["n_ode_fail"] == 0
@@ -394,7 +396,7 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     for j, b in enumerate(pick):
         p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
         u = np.clip(u_prev[j] + a[j] * np.float32(0.1), 0, 1)
-        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 240, 4, 3)
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 240, 4, 4)
         assert not failed
         worst = max(worst, scaled_err(xg[j], ref))
     m = env.metrics()
@@ -407,7 +409,7 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     env.close()
 
 
-@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 3), ("rk2", 2, 4), ("rk3", 3, 3)])
+@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 4), ("rk2", 2, 4), ("rk3", 3, 3)])
 def test_fp64_per_env_crop_blocks_in_every_scheme(golden, oracle, scheme, order, win):
     """The fp64 kernels that take PER-ENVIRONMENT crop constants (a per-quad record in LDS; `step_kernel_quad<double, ..., CROP>` and
     `evalf_kernel_quad<double, ..., CROP>`, one instantiation per scheme) against the CPU checker's restatement fed each
@@ -463,8 +465,8 @@ def test_stability_control_in_storm(golden, oracle):
     for k in range(12):
         x_prev = env.x.double().cpu().numpy().copy()
         env.step_raw_control(ctrl)
-        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 3)
-        plain_failed |= not np.all(np.isfinite(oracle.rk_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 3)))     # fixed step, no control
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 4)
+        plain_failed |= not np.all(np.isfinite(oracle.rk_lagged(x_prev[0], ctrl[0], w[k], p, 900.0, 256, 4, 4)))     # fixed step, no control
         assert np.all(np.isfinite(ref)) and not failed
         assert scaled_err(env.x[0].double().cpu().numpy(), ref) < 5e-5, k
     m = env.metrics()
@@ -593,7 +595,7 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     for k in range(env.N + 1):
         u = rng.uniform(0, 1, 6)
         xs, term = env.step_raw_control_pipeinput(np.repeat(u[None], 4, 0))
-        x = oracle.rk_sc_guarded(x, u, w14[k], p64, 300.0, 256, 4, 3, pipe=True)[0]
+        x = oracle.rk_sc_guarded(x, u, w14[k], p64, 300.0, 256, 4, 4, pipe=True)[0]
         assert scaled_err(xs[0], x) < 1e-9 and np.array_equal(xs[0], xs[3])
         assert bool(term[0]) == (k == env.N)
     env.close(); ref_env.close()
@@ -640,7 +642,7 @@ def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
     assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3").n_sub == 90 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2").n_sub == 336
 
 
-@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 3), ("rk2", 2, 4), ("rk3", 3, 3)])
+@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 4), ("rk2", 2, 4), ("rk3", 3, 3)])
 def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win):
     """The fp64 kernels sit at the register limit and hipcc 7.2 has miscompiled them before (round 4: builds
     with the default parameter block compiled in computed wrong slow states -- traced to the max-ilp scheduler flag, since removed): every env-step of a short
@@ -668,13 +670,13 @@ def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, sche
 
 
 def test_default_n_sub_scales_with_dt(golden, oracle):
-    """Without an explicit n_sub the nominal sub-step stays 3.75 s for any dt (81 sub-steps at the dt = 300 s of the
+    """Without an explicit n_sub the nominal sub-step stays 3.75 s for any dt (80 sub-steps at the dt = 300 s of the
     reference's experiments/run_time.py, 480 at 1 800 s); accuracy against plain RK4 with 8 192 sub-steps."""
     from gl_gym_amd import GreenLight
     g = golden("step_tight")
     X, U, D, P = g["X"], g["U"], g["D"], g["P"].astype(np.float64)
     scale = 1e-3 * np.abs(X).max(axis=0)
-    for dt, n_expect in ((300.0, 81), (1800.0, 480)):
+    for dt, n_expect in ((300.0, 80), (1800.0, 480)):
         for dtype in ("float64", "float32"):
             m = GreenLight(28, 6, 10, 208, dt, dtype=dtype)
             assert m.n_sub == n_expect
@@ -774,7 +776,7 @@ def test_bench_workload_at_full_batch_against_oracle_and_fine_truth(oracle):
         u = env.u[pick].double().cpu().numpy()                                         # the control the kernel applied
         x_gpu = env.x[pick].double().cpu().numpy()
         flags = env.step_flags_t.cpu().numpy()[pick]
-        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 240, 4, 3, want_flags=True), range(64)))
+        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 240, 4, 4, want_flags=True), range(64)))
         for j in range(64):
             assert not ref[j][3] and not (flags[j] & 128)
             worst_one = max(worst_one, scaled_err(x_gpu[j][None], ref[j][0][None]))

@@ -57,7 +57,7 @@ def test_storm_step_maps_through_step_kernel(golden, oracle, scheme, n_sub, dtyp
     assert m["n_ode_fail"] == 0 and not done.any()
     assert m["n_refined_substeps"] > 0                           # lanes in the storm took more than n_sub sub-steps
     if dtype == "float64":                                       # the oracle's restatement takes the same sub-steps
-        order, win = {"rk4": (4, 3), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
+        order, win = {"rk4": (4, 4), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
         ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, order, win, verify=True)
                for i in range(B)]        # step_raw_control integrates verified (glgym_set_verify: AUTO)
         assert m["n_refined_substeps"] == sum(r_[2] for r_ in ref)
@@ -212,7 +212,7 @@ def test_fp64_large_ragged_batch_against_the_cpu_checker(golden, oracle):
         x_gpu = env.x[pick].double().cpu().numpy()
         flags = env.step_flags_t.cpu().numpy()[pick]
         for j in range(len(pick)):
-            ref = oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, env.n_sub, 4, 3, want_flags=True)
+            ref = oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, env.n_sub, 4, 4, want_flags=True)
             assert not ref[3] and not (flags[j] & 128)
             worst = max(worst, scaled_err(x_gpu[j][None], ref[0][None]))
             worst_flags += int((flags[j] & 0xffff) != (ref[4] & 0xffff))

@@ -56,7 +56,7 @@ def test_step_flags_say_how_an_env_step_was_accepted():
     fl = env.step_flags_t.cpu().numpy()
     assert not (fl & L.SF_FAILED).any() and not done.any()
     assert (((fl >> 8) & 7) >= 1).all()                                    # verified: at least n_sub and 2 n_sub
-    ref = np.array([O.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, env.n_sub, 4, 3, verify=True, want_flags=True)[4]
+    ref = np.array([O.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, env.n_sub, 4, 4, verify=True, want_flags=True)[4]
                     for i in range(B)])
     assert np.array_equal(fl & 0xffff, ref & 0xffff), np.nonzero((fl & 0xffff) != (ref & 0xffff))
     assert np.abs((fl >> 16) - (ref >> 16)).max() <= 2                     # sub-step counts (a ceil() may flip on a last bit)
