@@ -20,7 +20,7 @@
 // What is measured: n_sub classical RK4 sub-steps (4 stages each, fixed h, tier 2b frozen -- the product's inner loop without
 // its per-window control) from identical inputs, (a) product layout, (b) quad layout; max |difference| of the 28 states; time
 // per env-step at several batch sizes; fp32 and fp64.
-// Build:  hipcc -O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp --offload-arch=gfx950 -std=c++17 -Iinclude
+// Build:  hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -std=c++17 -Iinclude
 //               -Igreenlight-gym2_amd/csrc tools/lanes_stage_proto.hip -o tools/lanes_stage_proto
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -274,6 +274,201 @@ __global__ __launch_bounds__(64) void quad_kernel(const T* __restrict__ X0, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// EIGHT lanes per environment (round 4; review item 8: the next point on the way to a wavefront per environment): lane r of an
+// 8-lane group owns ONE radiating surface -- 0 Can, 1 Pipe, 2 Flr, 3 Lamp | 4 ThScr, 5 BlScr, 6 CovIn, 7 CovE -- the same row
+// algebra as above with scalar per-lane coefficients; the six air-side states are carried redundantly by all eight lanes.  Inside
+// the group: quad_perm for the lane's own quad, row_half_mirror (lane i <-> 7 - i) to reach the other one -- 9 DPP operations gather
+// the eight q's, three DPP adds reduce a sum over the group, one quad_perm move fetches the cover pair's partner.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T hmir(T v) { return dpp<0x141>(v); }                    // row_half_mirror
+template <class T> __device__ __forceinline__ T octo_sum(T v) { v += dpp<0xB1>(v); v += dpp<0x4E>(v); v += hmir(v); return v; }
+template <class T> struct LaneK8 {
+    T cA, nA, cA2, nA2, cB, src, iCap, wetC, mAir, mTop, trK, cSky, cP;
+    T fir[8];                   // slot s < 4: member s of the lane's own quad; s >= 4: member s - 4 of the half-mirrored other quad
+    int role;
+};
+__host__ __device__ constexpr int surf_state(int r) { return r == 0 ? 4 : r == 1 ? 9 : r == 2 ? 8 : r == 3 ? 17 : r == 4 ? 7 : r == 5 ? 20 : r == 6 ? 5 : 6; }
+__host__ __device__ constexpr int other8_ix(int r, int j)
+{
+    return r == 0 ? (j ? 26 : 21) : r == 1 ? (j ? 11 : 10) : r == 2 ? (j ? 13 : 12) : r == 3 ? (j ? 19 : 14) : r == 4 ? (j ? 23 : 22)
+           : r == 5 ? (j ? 25 : 24) : (j ? 27 : 18);                                                   // lanes 6, 7: (18, 27); lane 7's are not stored
+}
+template <class T>
+__device__ void make_lane8(int r, const StepCoef<T>& s, const ModelConst<T>& m, const SlowCoef<T>& q, LaneK8<T>& K)
+{
+    const T z = T(0), one = T(1), third = T(1.0 / 3.0), L64 = T(6.4e-9);
+    T C[8][8], S[8];
+    for (int i = 0; i < 8; ++i) { S[i] = z; for (int j = 0; j < 8; ++j) C[i][j] = z; }
+    auto set = [&](int i, int j, T c) { C[i][j] = c; C[j][i] = c; };
+    enum { CAN, PIPE, FLR, LAMP, TH, BL, CIN, CE };
+    set(CAN, CIN, q.kCanCovIn); set(CAN, TH, q.kCanThScr); set(CAN, FLR, q.kCanFlr); set(CAN, BL, q.kCanBlScr);
+    set(PIPE, CIN, q.kPipeCovIn); set(PIPE, TH, q.kPipeThScr); set(PIPE, BL, q.kPipeBlScr); set(PIPE, FLR, m.fPipeFlr);
+    set(PIPE, CAN, q.kPipeCan); set(FLR, CIN, q.kFlrCovIn); set(FLR, TH, q.kFlrThScr); set(FLR, BL, q.kFlrBlScr);
+    set(TH, CIN, s.cThScrCovIn); set(LAMP, FLR, q.kLampFlr); set(LAMP, PIPE, q.kLampPipe); set(LAMP, CAN, q.kLampCan);
+    set(LAMP, TH, s.cLampThScr); set(LAMP, CIN, s.cLampCovIn); set(LAMP, BL, s.cLampBlScr); set(BL, TH, s.cBlScrThScr);
+    set(BL, CIN, s.cBlScrCovIn);
+    S[CAN] = q.kCanSky; S[PIPE] = q.kPipeSky; S[FLR] = q.kFlrSky; S[TH] = s.cThScrSky; S[CE] = m.fCovESky; S[LAMP] = s.cLampSky;
+    S[BL] = s.cBlScrSky;
+    const bool inA = r < 4;
+    for (int sl = 0; sl < 8; ++sl) {
+        const int surf = inA ? (sl < 4 ? sl : 11 - sl) : (sl < 4 ? 4 + sl : 7 - sl);
+        K.fir[sl] = C[r][surf];
+    }
+    K.cSky = S[r]; K.role = r;
+    auto pk = [&](T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7) { return r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : r == 3 ? a3 : r == 4 ? a4 : r == 5 ? a5 : r == 6 ? a6 : a7; };
+    K.cA = pk(q.hCanAirK, m.cPipeAir, T(1.3), m.cLampAir, s.hTh, s.hBl, m.cTopCov, s.covOutK);
+    K.cA2 = pk(q.hCanAirK, m.cPipeAir, T(1.7), m.cLampAir, s.hTh, s.hBl, m.cTopCov, s.covOutK);
+    K.nA = pk(z, T(0.32), T(0.25), z, third, third, third, z);
+    K.nA2 = pk(z, T(0.32), third, z, third, third, third, z);
+    K.cB = pk(z, z, z, z, s.hTh, s.hBl, z, z);
+    K.src = pk(q.swCan + q.rGroPipeCan, s.hBoilPipe, q.swFlr - q.hFlrSo1, s.lampNet, z, z, z, s.sunCovE);
+    K.iCap = pk(q.iCapCan, m.iCapPipe, m.iCapFlr, m.iCapLamp, m.iCapThScr, m.iCapBlScr, m.iCapCov, m.iCapCov);
+    K.wetC = pk(z, z, z, z, L64, L64, L64, z);
+    K.mAir = pk(one, one, one, one, one, one, z, z);
+    K.mTop = pk(z, z, z, z, z, z, one, z);
+    K.trK = pk(q.mvCanK, z, z, z, z, z, z, z);
+    K.cP = pk(z, z, z, z, z, z, m.cCovCond, m.cCovCond);
+}
+
+template <class T>
+__device__ __forceinline__ void stage_octo(T Tp, const T* sh, const LaneK8<T>& K, const StepCoef<T>& s, const ModelConst<T>& m,
+                                           const SlowCoef<T>& q, T& dTp, T* dsh, T& tCanOut)
+{
+    using M = Math<T>;
+    const T one = T(1), eps = T(1e-10), c2k = Kelvin<T>::c2k(), third = T(1.0 / 3.0);
+    const T co2Air = sh[0], co2Top = sh[1], tAir = sh[2], tTop = sh[3], vpAir = sh[4], vpTop = sh[5];
+    const int r = K.role;
+    const bool inA = r < 4;
+    // ---- long wave: the eight q's -- own quad by quad_perm, the other quad through its half-mirror image
+    const T kk = Tp + c2k, k2 = kk * kk, qp = k2 * k2;
+    const T qm = hmir(qp);
+    T fir = K.cSky * (s.qSky - qp);
+    fir += K.fir[0] * (bcast<0>(qp) - qp); fir += K.fir[1] * (bcast<1>(qp) - qp);
+    fir += K.fir[2] * (bcast<2>(qp) - qp); fir += K.fir[3] * (bcast<3>(qp) - qp);
+    fir += K.fir[4] * (bcast<0>(qm) - qp); fir += K.fir[5] * (bcast<1>(qm) - qp);
+    fir += K.fir[6] * (bcast<2>(qm) - qp); fir += K.fir[7] * (bcast<3>(qm) - qp);
+    // ---- exchange with node A (air | top compartment for CovIn | outside for CovE)
+    const T TA = r == 6 ? tTop : r == 7 ? s.tOut : tAir;
+    const T dA = TA - Tp;
+    const T nA = dA < T(0) ? K.nA2 : K.nA, cA = dA < T(0) ? K.cA2 : K.cA;
+    const T hecA = cA * M::powa(M::abs(dA) + eps, nA);
+    const T fluxA = hecA * dA;
+    // ---- second exchange: screens -> top compartment
+    const T dB = Tp - tTop;
+    const T fluxB = K.cB * M::powa(M::abs(dB) + eps, third) * dB;
+    // ---- saturation pressure, condensation gate, transpiration
+    const T rr = M::rcp(Tp + T(238.3));
+    const T sv = T(610.78) * M::expk(T(17.2694), Tp * rr);
+    const T dv = (r == 6 ? vpTop : vpAir) - sv;
+    const T g = dv * M::rcp(one + M::expk(T(-0.1), dv));
+    const T mv = K.wetC * hecA * g;
+    const T vpd = sv - vpAir;                                        // lane 0: canopy
+    const T co2Dev = m.etaMgPpm * co2Air - T(200);
+    const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
+    const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
+    const T mvCan = vpd * K.trK * M::rcp(m.rB + s.rSK * rfCo2 * rfVp);
+    // ---- the surface's balance; the cover pair's conduction needs the partner (lane ^ 1)
+    const T Tpartner = dpp<0xB1>(Tp);
+    const T L = m.latent;
+    const T net = K.src + fir + fluxA + L * mv - fluxB - L * mvCan + K.cP * (Tpartner - Tp);
+    dTp = K.iCap * net;
+    // ---- sums the air / top balances need
+    const T sHeatAir = octo_sum(-(fluxA * K.mAir));
+    const T sHeatTop = octo_sum(fluxB - fluxA * K.mTop);
+    const T sVapAir = octo_sum(mvCan - mv * K.mAir);
+    const T sVapTop = octo_sum(-(mv * K.mTop));
+    {   // canopy temperature (lane 0) to the whole group
+        const T t0 = bcast<0>(Tp), tm = hmir(t0);
+        tCanOut = inA ? t0 : tm;
+    }
+    // ---- air side (identical in the eight lanes)
+    const T dTOut = tAir - s.tOut;
+    const T buoy = m.gHVent * dTOut * M::rcp(tAir + s.tOutK2);
+    const T fVentRoof = s.ventK * M::sqrt(M::abs(buoy + s.windTerm)) + s.ventElse + s.leakTop;
+    const T tAirK = tAir + c2k, tTopK = tTop + c2k;
+    const T iAirK = M::rcp(tAirK), iTopK = M::rcp(tTopK);
+    const T rhoMean = T(0.5) * m.kRho * (iAirK + iTopK);
+    const T dRho = M::abs(m.kRho * (tTop - tAir) * iAirK * iTopK);
+    const T pw66 = M::powa(M::abs(tAir - tTop + eps), T(0.66));
+    const T iRhoMean = M::rcp(rhoMean);
+    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
+    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
+    const T fScrAbs = M::abs(M::min(fTh, fBl)), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
+    T vAirOverT, vTopOverT;
+    if (sizeof(T) == 8) { vAirOverT = vpAir * M::rcp(tAir + Kelvin<T>::c2kF32()); vTopOverT = vpTop * M::rcp(tTop + Kelvin<T>::c2kF32()); }
+    else { vAirOverT = vpAir * iAirK; vTopOverT = vpTop * iTopK; }
+    const T kMv = T(0.002165);
+    const T hAirTop = m.rhoCp * fScrAbs * (tAir - tTop), hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
+    const T mvAirTop = kMv * fScrAbs * (vAirOverT - vTopOverT), mvTopOut = kMv * fRoofAbs * (vTopOverT - s.vpOutOverT);
+    const T mcAirTop = fScrAbs * (co2Air - co2Top), mcTopOut = fRoofAbs * (co2Top - s.co2Out);
+    const T mvAirOut = kMv * fSideAbs * (vAirOverT - s.vpOutOverT), mcAirOut = fSideAbs * (co2Air - s.co2Out);
+    const T hAirOut = s.hAirOutK * dTOut;
+    dsh[0] = m.iCapCo2Air * (s.mcExtAir - q.mcAirCan - mcAirTop - mcAirOut);
+    dsh[1] = m.iCapCo2Top * (mcAirTop - mcTopOut);
+    dsh[2] = m.iCapAir * (sHeatAir + q.swAir - hAirOut - hAirTop + q.hGroPipeAir);
+    dsh[3] = m.iCapTop * (sHeatTop + hAirTop - hTopOut);
+    dsh[4] = m.kCapVpAir * tAirK * (sVapAir - mvAirTop - mvAirOut);
+    dsh[5] = m.kCapVpTop * tTopK * (sVapTop + mvAirTop - mvTopOut);
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void octo_kernel(const T* __restrict__ X0, const T* __restrict__ U, const T* __restrict__ D,
+                                                  ModelConst<T> m, T* __restrict__ X1, int B, int n_sub, T h)
+{
+    const int gl = blockIdx.x * 64 + threadIdx.x, r = gl & 7;
+    const int b = min(gl >> 3, B - 1);
+    T x0[NX], u[NU], d[7];
+    for (int i = 0; i < NX; ++i) x0[i] = X0[(size_t)b * NX + i];
+    for (int i = 0; i < NU; ++i) u[i] = U[(size_t)b * NU + i];
+    for (int i = 0; i < 7; ++i) d[i] = D[(size_t)b * ND + i];
+    StepCoef<T> s; SlowCoef<T> q;
+    precompute(u, d, m, m.crop, s);
+    slow_coef(x0, s, m, m.crop, q);
+    LaneK8<T> K;
+    make_lane8(r, s, m, q, K);
+    T yP = x0[surf_state(r)];
+    T ysh[6], yo[2], ro[2];
+    for (int i = 0; i < 6; ++i) ysh[i] = x0[sh_ix(i)];
+    T rate[NX];
+    for (int i = 0; i < NX; ++i) rate[i] = T(0);
+    rate[10] = q.dSo1; rate[11] = q.dSo2; rate[12] = q.dSo3; rate[13] = q.dSo4; rate[14] = q.dSo5; rate[19] = q.dGro;
+    rate[22] = q.dBuf; rate[23] = q.dLeaf; rate[24] = q.dStem; rate[25] = q.dFruit; rate[27] = T(1.0 / 86400.0);
+    for (int j = 0; j < 2; ++j) { yo[j] = x0[other8_ix(r, j)]; ro[j] = rate[other8_ix(r, j)]; }
+    const T perDay = T(1.0 / 86400.0), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+    const bool lane0 = r == 0;
+    for (int it = 0; it < n_sub; ++it) {
+        T kP, accP, xP, ksh[6], accsh[6], xsh[6], ko[2], acco[2], xo[2], tCan;
+        auto eval = [&](T p, const T* shv, const T* ov) {
+            stage_octo<T>(p, shv, K, s, m, q, kP, ksh, tCan);
+            ko[0] = lane0 ? perDay * (tCan - ov[0]) : ro[0];      // lane 0: tCan24, tCanSum
+            ko[1] = lane0 ? perDay * tCan : ro[1];
+        };
+        eval(yP, ysh, yo);
+        accP = kP; xP = yP + h2 * kP;
+        for (int i = 0; i < 6; ++i) { accsh[i] = ksh[i]; xsh[i] = ysh[i] + h2 * ksh[i]; }
+        for (int j = 0; j < 2; ++j) { acco[j] = ko[j]; xo[j] = yo[j] + h2 * ko[j]; }
+        eval(xP, xsh, xo);
+        accP += T(2) * kP; xP = yP + h2 * kP;
+        for (int i = 0; i < 6; ++i) { accsh[i] += T(2) * ksh[i]; xsh[i] = ysh[i] + h2 * ksh[i]; }
+        for (int j = 0; j < 2; ++j) { acco[j] += T(2) * ko[j]; xo[j] = yo[j] + h2 * ko[j]; }
+        eval(xP, xsh, xo);
+        accP += T(2) * kP; xP = yP + h * kP;
+        for (int i = 0; i < 6; ++i) { accsh[i] += T(2) * ksh[i]; xsh[i] = ysh[i] + h * ksh[i]; }
+        for (int j = 0; j < 2; ++j) { acco[j] += T(2) * ko[j]; xo[j] = yo[j] + h * ko[j]; }
+        eval(xP, xsh, xo);
+        yP += h6 * (accP + kP);
+        for (int i = 0; i < 6; ++i) ysh[i] += h6 * (accsh[i] + ksh[i]);
+        for (int j = 0; j < 2; ++j) yo[j] += h6 * (acco[j] + ko[j]);
+    }
+    if ((gl >> 3) < B) {
+        T* o = X1 + (size_t)b * NX;
+        o[surf_state(r)] = yP;
+        if (r < 7) for (int j = 0; j < 2; ++j) o[other8_ix(r, j)] = yo[j];
+        if (r == 0) for (int i = 0; i < 6; ++i) o[sh_ix(i)] = ysh[i];
+    }
+}
+
 // the product layout: one lane per environment, rhs_fast as the kernels call it (packed FIR / screen / balance blocks in fp32)
 template <class T>
 __global__ __launch_bounds__(64) void one_kernel(const T* __restrict__ X0, const T* __restrict__ U, const T* __restrict__ D,
@@ -327,9 +522,9 @@ template <class T> int run(const char* name, const double* p, const std::vector<
                                5.0, 0, 0};
         for (int i = 0; i < ND; ++i) hd[(size_t)b * ND + i] = (T)dd[i];
     }
-    T *dx, *du, *dd_, *o1, *o4;
+    T *dx, *du, *dd_, *o1, *o4, *o8;
     CHK(hipMalloc(&dx, hx.size() * sizeof(T))); CHK(hipMalloc(&du, hu.size() * sizeof(T))); CHK(hipMalloc(&dd_, hd.size() * sizeof(T)));
-    CHK(hipMalloc(&o1, hx.size() * sizeof(T))); CHK(hipMalloc(&o4, hx.size() * sizeof(T)));
+    CHK(hipMalloc(&o1, hx.size() * sizeof(T))); CHK(hipMalloc(&o4, hx.size() * sizeof(T))); CHK(hipMalloc(&o8, hx.size() * sizeof(T)));
     CHK(hipMemcpy(dx, hx.data(), hx.size() * sizeof(T), hipMemcpyHostToDevice));
     CHK(hipMemcpy(du, hu.data(), hu.size() * sizeof(T), hipMemcpyHostToDevice));
     CHK(hipMemcpy(dd_, hd.data(), hd.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -338,7 +533,7 @@ template <class T> int run(const char* name, const double* p, const std::vector<
     if (getenv("N_IT")) n_sub = atoi(getenv("N_IT"));
     printf("%s: %d classical RK4 sub-steps (4 stages each) per env-step, h = %.4f s\n", name, n_sub, (double)h);
     for (int B : batches) {
-        float ms1 = 0, ms4 = 0;
+        float ms1 = 0, ms4 = 0, ms8 = 0;
         for (int rep = 0; rep < 3; ++rep) {
             CHK(hipEventRecord(e0));
             hipLaunchKernelGGL(one_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, 0, dx, du, dd_, m, o1, B, n_sub, h);
@@ -346,11 +541,23 @@ template <class T> int run(const char* name, const double* p, const std::vector<
             CHK(hipEventRecord(e0));
             hipLaunchKernelGGL(quad_kernel<T>, dim3((4 * B + 63) / 64), dim3(64), 0, 0, dx, du, dd_, m, o4, B, n_sub, h);
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms4, e0, e1));
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(octo_kernel<T>, dim3((8 * B + 63) / 64), dim3(64), 0, 0, dx, du, dd_, m, o8, B, n_sub, h);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms8, e0, e1));
         }
         CHK(hipGetLastError());
-        std::vector<T> a((size_t)B * NX), c((size_t)B * NX);
+        std::vector<T> a((size_t)B * NX), c((size_t)B * NX), c8((size_t)B * NX);
         CHK(hipMemcpy(a.data(), o1, a.size() * sizeof(T), hipMemcpyDeviceToHost));
         CHK(hipMemcpy(c.data(), o4, c.size() * sizeof(T), hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(c8.data(), o8, c8.size() * sizeof(T), hipMemcpyDeviceToHost));
+        double worst8 = 0; int wi8 = -1;
+        for (size_t i = 0; i < a.size(); ++i) {
+            if ((i % NX) == 18) continue;
+            const double sc = fmax(fabs((double)a[i]), 1e-3 * fabs(x0[i % NX]) + 1e-30);
+            if (!std::isfinite((double)a[i]) && !std::isfinite((double)c8[i])) continue;       // plain RK4 without stability control: the same envs overflow in every layout
+            const double e = std::isfinite((double)c8[i]) ? fabs((double)a[i] - (double)c8[i]) / sc : 1e30;
+            if (e > worst8) { worst8 = e; wi8 = (int)(i % NX); }
+        }
         double worst = 0; int wi = -1; bool fin = true; long nan1 = 0, nan4 = 0;
         for (size_t i = 0; i < a.size(); ++i) {
             if ((i % NX) == 18) continue;                          // interlight temperature: not integrated by the quad layout (inactive)
@@ -362,6 +569,8 @@ template <class T> int run(const char* name, const double* p, const std::vector<
         }
         printf("  B = %6d: one lane per env %8.3f ms (%.3e env-steps/s) | four lanes per env %8.3f ms (%.3e env-steps/s) | x%.2f | max scaled "
                "|difference| %.1e (state %d)", B, ms1, B / (ms1 * 1e-3), ms4, B / (ms4 * 1e-3), ms1 / ms4, worst, wi);
+        printf("\n             eight lanes per env %8.3f ms (%.3e env-steps/s) | x%.2f vs one lane, x%.2f vs four | max scaled |difference| %.1e (state %d)",
+               ms8, B / (ms8 * 1e-3), ms1 / ms8, ms4 / ms8, worst8, wi8);
         if (!fin) printf("  NON-FINITE entries: one-lane %ld, four-lane %ld; first env one-lane x[2..6] = %g %g %g %g %g, four-lane %g %g %g %g %g", nan1, nan4,
                          (double)a[2], (double)a[3], (double)a[4], (double)a[5], (double)a[6], (double)c[2], (double)c[3], (double)c[4], (double)c[5], (double)c[6]);
         printf("\n");
