@@ -1255,6 +1255,21 @@ static int refresh(glgym_handle h)
     return GLGYM_OK;
 }
 
+// The device-pointer entry points launch on the CALLER's stream; HIP wants the calling thread's current device to be the stream's.
+// One process per GPU (the layout this library is built for) never notices; a process that holds handles on several devices does:
+// bind the handle's device for the duration of the call and put the caller's back (a no-op when it already is current).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 extern "C" {
 
 const char* glgym_version(void) { return "glgym 0.4 (gfx950; stability-controlled, step-doubling-verified RK4 / RK3 / midpoint sub-steppers in delta form)"; }
@@ -1637,6 +1652,7 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
 
 extern "C" int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
         !a->reward || !a->done || (!a->action) == (!a->control) || a->weather_rows < 1) {
         g_err = "glgym_step: bad arguments (exactly one of action/control, ld >= B, non-null state/outputs)";
@@ -1675,6 +1691,7 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
 
 extern "C" int glgym_weather(glgym_handle h, const glgym_weather_args* a, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !a || a->n_raw < 3 || a->n_out < 1 || a->nd < ND || !a->time || !a->i_glob || !a->t_out || !a->rh || !a->wind ||
         !a->t_sky || !a->out || !a->workspace) {
         g_err = "glgym_weather: bad arguments (>= 3 raw samples, nd >= 10, non-null device pointers)";
@@ -1704,6 +1721,7 @@ extern "C" int glgym_weather(glgym_handle h, const glgym_weather_args* a, void* 
 
 extern "C" int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !a || a->B < 1 || a->dim < 1 || !a->obs || !a->obs_out || !a->obs_mean || !a->obs_var || !a->obs_count ||
         !a->workspace || (a->reward && (!a->reward_out || !a->ret_stats || !a->returns))) {
         g_err = "glgym_vecnorm: bad arguments";
@@ -1761,6 +1779,7 @@ extern "C" {
 
 int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
         !a->start_day || !a->obs || a->Np < 0 || a->Np > OBS_MAX_NP) {
         g_err = "glgym_obs: bad arguments (null pointer, ld < B, or Np outside 0..128)";
@@ -1797,6 +1816,7 @@ int glgym_obs_dim(glgym_handle h, int Np)
 
 int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->timestep || !a->weather || !a->w_off) {
         g_err = "glgym_reset: bad arguments";
         return GLGYM_EINVAL;
@@ -1819,6 +1839,7 @@ int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
 int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, uint64_t seed, uint64_t draw_index,
                      void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !crop_p || B < 1 || ld < B) return GLGYM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((B + 255) / 256), block(256);
@@ -1834,6 +1855,7 @@ int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, 
 
 int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule_args* a, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !cfg || !a || a->B < 1 || a->ld < a->B || !a->x || !a->weather || !a->w_off || !a->timestep || !a->control ||
         a->weather_rows < 1 || (!a->start_day && !a->doy) || cfg->vent_heat_Pband == 0 || cfg->vent_rh_Pband == 0 ||
         cfg->vent_cold_Pband == 0 || cfg->thScrPband == 0 || cfg->thScrRhPband == 0 || cfg->tHeatBand == 0 ||
@@ -1858,6 +1880,7 @@ int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule
 
 int glgym_timer_start(glgym_handle h, void* stream)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h) return GLGYM_EINVAL;
     HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
     return GLGYM_OK;
@@ -1865,6 +1888,7 @@ int glgym_timer_start(glgym_handle h, void* stream)
 
 int glgym_timer_stop(glgym_handle h, void* stream, float* elapsed_ms)
 {
+    DeviceGuard dev_guard(h ? h->device : 0);
     if (!h || !elapsed_ms) return GLGYM_EINVAL;
     HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(h->ev1));
