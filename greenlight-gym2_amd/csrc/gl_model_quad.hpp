@@ -178,14 +178,20 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const bool negx = dA.x < T(0), negy = dA.y < T(0);
     const P2<T> nA = gq_mk<T>(negx ? K.nA2.x : K.nA.x, negy ? K.nA2.y : K.nA.y), cA = gq_mk<T>(negx ? K.cA2.x : K.cA.x, negy ? K.cA2.y : K.cA.y);
     const T sgx = role == 1 ? (negx ? -one : one) : K.sgA.x;
-    const P2<T> hecA = cA * gq_mk<T>(M::powa(M::abs(sgx * dA.x + eps), nA.x), M::powa(M::abs(K.sgA.y * dA.y + eps), nA.y));
+    // fp64 (a power is 57 instructions there, 3 in fp32): lane 0's x law is linear -- the canopy, exponent 0, its power slot would
+    // evaluate x^0 = 1 -- so that slot computes the air side's |tAir - tTop|^0.66 for the whole quad instead (one power per stage less)
+    constexpr bool SHARE_POW = sizeof(T) == 8;
+    const T powArgX = (SHARE_POW && lane0) ? M::abs(tAir - tTop + eps) : M::abs(sgx * dA.x + eps);
+    const T powExpX = (SHARE_POW && lane0) ? T(0.66) : nA.x;
+    const T powX = M::powa(powArgX, powExpX);
+    const P2<T> hecA = cA * gq_mk<T>((SHARE_POW && lane0) ? one : powX, M::powa(M::abs(K.sgA.y * dA.y + eps), nA.y));
     const P2<T> fluxA = hecA * dA;                                   // into the surface
     // ---- second exchange: screens -> top compartment
     const P2<T> dB = Tp - gq_sp<T>(tTop);
     const P2<T> hecB = K.cB * gq_mk<T>(M::cbrta(M::abs(dB.x + eps)), M::cbrta(M::abs(dB.y + eps)));
     const P2<T> fluxB = hecB * dB;
     // ---- saturation pressure, condensation gate, transpiration
-    const P2<T> rr = gq_mk<T>(M::rcp(Tp.x + T(238.3)), M::rcp(Tp.y + T(238.3)));
+    const P2<T> rr = gq_mk<T>(M::rcpn(Tp.x + T(238.3)), M::rcpn(Tp.y + T(238.3)));
     const P2<T> sv = gq_sp<T>(T(610.78)) * gq_mk<T>(M::expk(T(17.2694), Tp.x * rr.x), M::expk(T(17.2694), Tp.y * rr.y));
     const P2<T> dv = gq_mk<T>(cov ? vpTop : vpAir, vpAir) - sv;
     const P2<T> g = dv * gq_mk<T>(M::rcp(one + M::expk(T(-0.1), dv.x)), M::rcp(one + M::expk(T(-0.1), dv.y)));
@@ -194,7 +200,7 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T co2Dev = m.etaMgPpm * co2Air - T(200);
     const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
     const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
-    const T mvCan = vpd * K.trK.x * M::rcp(m.rB + s.rSK * rfCo2 * rfVp);
+    const T mvCan = vpd * K.trK.x * M::rcpn(m.rB + s.rSK * rfCo2 * rfVp);
     // ---- the pair's balances
     const T L = m.latent;
     const P2<T> net = K.src + fir + fluxA + gq_sp<T>(L) * mv - fluxB + gq_mk<T>(-(L * mvCan), T(0));
@@ -208,19 +214,19 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T tCan = gq_bcast<0>(Tp.x);
     // ---- air side (identical in the four lanes): ventilation, screen air flux, air streams (rhs_fast)
     const T dTOut = tAir - s.tOut;
-    const T buoy = m.gHVent * dTOut * M::rcp(tAir + s.tOutK2);
-    const T fVentRoof = s.ventK * M::sqrt(M::abs(buoy + s.windTerm)) + s.ventElse + s.leakTop;
+    const T buoy = m.gHVent * dTOut * M::rcpn(tAir + s.tOutK2);
+    const T fVentRoof = s.ventK * M::sqrt0(M::abs(buoy + s.windTerm)) + s.ventElse + s.leakTop;
     const T tAirK = tAir + c2k, tTopK = tTop + c2k;
-    const T iAirK = M::rcp(tAirK), iTopK = M::rcp(tTopK);
+    const T iAirK = M::rcpn(tAirK), iTopK = M::rcpn(tTopK);
     const T rhoMean = T(0.5) * m.kRho * (iAirK + iTopK);
     const T dRho = M::abs(m.kRho * (tTop - tAir) * iAirK * iTopK);
-    const T pw66 = M::powa(M::abs(tAir - tTop + eps), T(0.66));
-    const T iRhoMean = M::rcp(rhoMean);
-    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
-    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrt(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
+    const T pw66 = SHARE_POW ? gq_bcast<0>(powX) : M::powa(M::abs(tAir - tTop + eps), T(0.66));
+    const T iRhoMean = M::rcpn(rhoMean);
+    const T fTh = s.kTh * pw66 + s.oneMinusUTh * iRhoMean * M::sqrtn(m.gHalf * rhoMean * s.oneMinusUTh * dRho + eps);
+    const T fBl = s.kBl * pw66 + s.oneMinusUBl * iRhoMean * M::sqrtn(m.gHalf * rhoMean * s.oneMinusUBl * dRho + eps);
     const T fScrAbs = M::abs(M::min(fTh, fBl)), fRoofAbs = M::abs(fVentRoof), fSideAbs = M::abs(s.fVentSide);
     T vAirOverT, vTopOverT;
-    if (sizeof(T) == 8) { vAirOverT = vpAir * M::rcp(tAir + Kelvin<T>::c2kF32()); vTopOverT = vpTop * M::rcp(tTop + Kelvin<T>::c2kF32()); }
+    if (sizeof(T) == 8) { vAirOverT = vpAir * M::rcpn(tAir + Kelvin<T>::c2kF32()); vTopOverT = vpTop * M::rcpn(tTop + Kelvin<T>::c2kF32()); }
     else { vAirOverT = vpAir * iAirK; vTopOverT = vpTop * iTopK; }
     const T kMv = T(0.002165);
     const T hAirTop = m.rhoCp * fScrAbs * (tAir - tTop), hTopOut = m.rhoCp * fRoofAbs * (tTop - s.tOut);
