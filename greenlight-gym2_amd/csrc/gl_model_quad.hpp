@@ -23,8 +23,12 @@
 // that scheme is the reference for both layouts (tests/).  Every member of the scheme family (RK4 / three-stage / midpoint, all
 // with the exponential cover conduction), both ODE variants, shared or per-environment crop constants, interlights on or off: in
 // fp64 this layout is the only integrator on the device (round 4); in fp32 it serves the small batches.
-// Measured (tools/lanes_stage_proto.hip, profiles/r03_lanes_stage_proto.txt): the bare RK4 chain runs 1.48x (fp32) / 1.43x (fp64)
-// the env-steps per second of the one-lane layout for B <= 16 384 and 0.73x at B = 65 536 -- hence the dispatch by batch size.
+// Measured (tools/lanes_stage_proto.hip, profiles/r04_lanes_stage_proto.txt): the bare RK4 chain runs 1.47x (fp32) / 1.57x (fp64)
+// the env-steps per second of the one-lane layout for B <= 4 096 and 0.73x at B = 65 536 -- hence the dispatch by batch size.  As
+// PRODUCT kernels the gain in fp32 is 1.08x at B = 8 ... 1.11x at 16 384 (profiles/r04_small_batch_rate_fp32.txt): a quarter of this
+// kernel is window-level work every lane repeats (tier 2b, LaneK, rate bound: 2.6 us per window); in fp64 there
+// is no one-lane kernel to compare with any more (the last one took 7.8 ms per 24 576 environments against this layout's 5.7).
+// Eight lanes per environment were measured too: 0.94x of this layout in fp32, 1.16x in fp64.
 #pragma once
 #include "gl_model.hpp"
 
