@@ -665,6 +665,7 @@ template <class T> struct SlowCoef {
     T kPipeCovIn, kPipeSky, kPipeThScr, kPipeBlScr, kFlrCovIn, kFlrSky, kFlrThScr, kFlrBlScr, kLampFlr, kLampPipe;
     T iFlr, iPipe, iCan, iLamp, iBlScr, iThScr, iCovIn, iSky;       // interlights (zero power in the reference)
     T hCanAirK, mvCanK, iCapCan;            // 2 p0 LAI ; kVec LAI ; 1 / (capLeaf LAI)
+    T aCan, gap;                            // canopy view factor / gap themselves (gl_model_quad.hpp builds its rows from them)
     // crop block (aux_states.hpp:1041-1194, a191..a216): photosynthesis, carbohydrate flows, respiration.  It feeds only
     // the four crop pools and, through mcAirCan, the CO2 balance of the air.
     T mcAirCan;                             // net CO2 uptake of the canopy (a216)
@@ -729,6 +730,7 @@ GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, 
     q.kFlrCovIn = s.cFlrCovIn * gap; q.kFlrSky = s.cFlrSky * gap; q.kFlrThScr = s.cFlrThScr * gap;
     q.kFlrBlScr = s.cFlrBlScr * gap;
     q.kLampFlr = m.fLampFlr_g * gap; q.kLampPipe = m.fLampPipe_g * gap;
+    q.aCan = aCan; q.gap = gap;
     q.iFlr = q.iPipe = q.iCan = q.iLamp = q.iBlScr = q.iThScr = q.iCovIn = q.iSky = T(0);
     if (m.intLampActive) {
         const T eUp = M::expk(m.nkIntFirUp, lai), eDn = M::expk(m.nkIntFirDown, lai);

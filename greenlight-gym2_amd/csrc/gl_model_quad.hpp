@@ -25,8 +25,8 @@
 // fp64 this layout is the only integrator on the device (round 4); in fp32 it serves the small batches.
 // Measured (tools/lanes_stage_proto.hip, profiles/r04_lanes_stage_proto.txt): the bare RK4 chain runs 1.47x (fp32) / 1.57x (fp64)
 // the env-steps per second of the one-lane layout for B <= 4 096 and 0.73x at B = 65 536 -- hence the dispatch by batch size.  As
-// PRODUCT kernels the gain in fp32 is 1.08x at B = 8 ... 1.11x at 16 384 (profiles/r04_small_batch_rate_fp32.txt): a quarter of this
-// kernel is window-level work every lane repeats (tier 2b, LaneK, rate bound: 2.6 us per window); in fp64 there
+// PRODUCT kernels the gain in fp32 is 1.15x at B = 8 ... 1.18x at 16 384 (profiles/r04_small_batch_rate_fp32.txt): a fifth of this
+// kernel is window-level work every lane repeats (tier 2b, rate bound, estimate: 1.9 us per window); in fp64 there
 // is no one-lane kernel to compare with any more (the last one took 7.8 ms per 24 576 environments against this layout's 5.7).
 // Eight lanes per environment were measured too: 0.94x of this layout in fp32, 1.16x in fp64.
 #pragma once
@@ -131,6 +131,82 @@ __device__ __forceinline__ void gq_make_lane(int role, const StepCoef<T>& s, con
     K.mTop = gq_mk<T>(pk(z, z, z, one), z);
     K.trK = gq_mk<T>(pk(q.mvCanK, z, z, z), z);
     K.iC = gq_mk<T>(pk(q.iCan, q.iFlr, q.iThScr, q.iCovIn), pk(q.iPipe, q.iLamp, q.iBlScr, z));
+    K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
+    K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
+}
+
+// ---- the same record built in two parts (the register build, fp32): the selects by role cost 365 instructions per window when the
+// whole record is rebuilt there (measured: 0.75 of the 2.6 us a window costs at B = 8).  Only the canopy-dependent part changes
+// from window to window, and all of its long-wave entries are  c x aCan,  c x gap  or  c  (slow_coef): with the three coefficient
+// sets (f0, fa, fg) selected ONCE per env-step an entry is  fa aCan + (fg gap + f0)  -- two packed FMAs, exact (one of the three
+// coefficients is non-zero, so each entry is the one rounded product slow_coef forms) -- and the rest of the record is written once.
+template <class T> struct LaneStep {
+    P2<T> f0[8], fa[8], fg[8];     // entries 0..3 firX[0..3], 4..6 firY[0..2], 7 cSky
+    T cAx, iCapx;                  // the step-level x components lane 0 overrides per window (canopy: q.hCanAirK, q.iCapCan)
+};
+template <class T>
+__device__ __forceinline__ void gq_make_lane_step(int role, const StepCoef<T>& s, const ModelConst<T>& m, LaneK<T>& K, LaneStep<T>& LS)
+{
+    const T z = T(0), one = T(1), third = T(1.0 / 3.0), L64 = T(6.4e-9);
+    auto pk = [&](T a0, T a1, T a2, T a3) { return role == 0 ? a0 : role == 1 ? a1 : role == 2 ? a2 : a3; };
+    // kind of an entry: 'C' constant, 'A' times aCan, 'G' times gap.  X(...) / Y(...) fill the x / y component of entry e from the four
+    // roles' (kind, coefficient) pairs
+    struct E { int kind; T c; };
+    auto C = [&](T c) { return E{0, c}; };
+    auto A = [&](T c) { return E{1, c}; };
+    auto G = [&](T c) { return E{2, c}; };
+    auto put = [&](int e, bool ycomp, E e0, E e1, E e2, E e3) {
+        const int kind = role == 0 ? e0.kind : role == 1 ? e1.kind : role == 2 ? e2.kind : e3.kind;
+        const T c = pk(e0.c, e1.c, e2.c, e3.c);
+        const T v0 = kind == 0 ? c : z, va = kind == 1 ? c : z, vg = kind == 2 ? c : z;
+        if (ycomp) { LS.f0[e].y = v0; LS.fa[e].y = va; LS.fg[e].y = vg; }
+        else { LS.f0[e].x = v0; LS.fa[e].x = va; LS.fg[e].x = vg; }
+    };
+    // rows of the symmetric long-wave matrix (gq_make_lane), by source lane;  q.kCanX = c aCan,  q.kPipeX / q.kFlrX / q.kLamp{Flr,Pipe} = c gap
+    put(0, false, C(z), A(m.fCanFlr_a), A(s.cCanThScr), A(s.cCanCovIn));            put(0, true, A(m.fPipeCan_a), A(m.fLampCan_a), A(s.cCanBlScr), C(z));      // source Can
+    put(4, false, A(m.fPipeCan_a), C(m.fPipeFlr), G(s.cPipeThScr), G(s.cPipeCovIn)); put(4, true, C(z), G(m.fLampPipe_g), G(s.cPipeBlScr), C(z));                // source Pipe
+    put(1, false, A(m.fCanFlr_a), C(z), G(s.cFlrThScr), G(s.cFlrCovIn));            put(1, true, C(m.fPipeFlr), G(m.fLampFlr_g), G(s.cFlrBlScr), C(z));        // source Flr
+    put(5, false, A(m.fLampCan_a), G(m.fLampFlr_g), C(s.cLampThScr), C(s.cLampCovIn)); put(5, true, G(m.fLampPipe_g), C(z), C(s.cLampBlScr), C(z));            // source Lamp
+    put(2, false, A(s.cCanThScr), G(s.cFlrThScr), C(z), C(s.cThScrCovIn));          put(2, true, G(s.cPipeThScr), C(s.cLampThScr), C(s.cBlScrThScr), C(z));     // source ThScr
+    put(6, false, A(s.cCanBlScr), G(s.cFlrBlScr), C(s.cBlScrThScr), C(s.cBlScrCovIn)); put(6, true, G(s.cPipeBlScr), C(s.cLampBlScr), C(z), C(z));             // source BlScr
+    put(3, false, A(s.cCanCovIn), G(s.cFlrCovIn), C(s.cThScrCovIn), C(z));          put(3, true, G(s.cPipeCovIn), C(s.cLampCovIn), C(s.cBlScrCovIn), C(z));     // source CovIn
+    put(7, false, A(s.cCanSky), G(s.cFlrSky), C(s.cThScrSky), C(z));                put(7, true, G(s.cPipeSky), C(s.cLampSky), C(s.cBlScrSky), C(m.fCovESky));  // sky
+    K.firY[3] = gq_mk<T>(z, z);                                                     // source CovE: sky only
+    // the entries no window changes
+    LS.cAx = pk(z, T(1.3), s.hTh, m.cTopCov);
+    K.cA = gq_mk<T>(LS.cAx, pk(m.cPipeAir, m.cLampAir, s.hBl, s.covOutK));
+    K.cA2 = gq_mk<T>(pk(z, T(1.7), s.hTh, m.cTopCov), K.cA.y);
+    K.nA = gq_mk<T>(pk(z, T(0.25), third, third), pk(T(0.32), z, third, z));
+    K.nA2 = gq_mk<T>(pk(z, third, third, third), K.nA.y);
+    K.sgA = gq_mk<T>(one, pk(-one, one, one, one));
+    K.cB = gq_mk<T>(pk(z, z, s.hTh, z), pk(z, z, s.hBl, z));
+    LS.iCapx = pk(z, m.iCapFlr, m.iCapThScr, m.iCapCov);
+    K.iCap = gq_mk<T>(LS.iCapx, pk(m.iCapPipe, m.iCapLamp, m.iCapBlScr, m.iCapCov));
+    K.wetC = gq_mk<T>(pk(z, z, L64, L64), pk(z, z, L64, z));
+    K.mAir = gq_mk<T>(pk(one, one, one, z), pk(one, one, one, z));
+    K.mTop = gq_mk<T>(pk(z, z, z, one), z);
+    K.src = gq_mk<T>(z, pk(s.hBoilPipe, s.lampNet, z, s.sunCovE));
+    K.trK = gq_mk<T>(z, z);
+    K.iC = gq_mk<T>(z, z);
+}
+template <class T>
+__device__ __forceinline__ void gq_make_lane_win(int role, const StepCoef<T>& s, const ModelConst<T>& m, const SlowCoef<T>& q, LaneK<T>& K,
+                                                 const LaneStep<T>& LS)
+{
+    const T z = T(0);
+    auto pk = [&](T a0, T a1, T a2, T a3) { return role == 0 ? a0 : role == 1 ? a1 : role == 2 ? a2 : a3; };
+    const bool lane0 = role == 0;
+    const P2<T> aC = gq_sp<T>(q.aCan), gp = gq_sp<T>(q.gap);
+    auto row = [&](int e) { return LS.fa[e] * aC + (LS.fg[e] * gp + LS.f0[e]); };
+    K.firX[0] = row(0); K.firX[1] = row(1); K.firX[2] = row(2); K.firX[3] = row(3);
+    K.firY[0] = row(4); K.firY[1] = row(5); K.firY[2] = row(6);
+    K.cSky = row(7);
+    K.cA = gq_mk<T>(lane0 ? q.hCanAirK : LS.cAx, K.cA.y);
+    K.cA2 = gq_mk<T>(lane0 ? q.hCanAirK : K.cA2.x, K.cA2.y);
+    K.iCap = gq_mk<T>(lane0 ? q.iCapCan : LS.iCapx, K.iCap.y);
+    K.src = gq_mk<T>(pk(q.swCan + q.rGroPipeCan, q.swFlr - q.hFlrSo1, z, z), K.src.y);
+    K.trK = gq_mk<T>(lane0 ? q.mvCanK : z, z);
+    if (m.intLampActive) K.iC = gq_mk<T>(pk(q.iCan, q.iFlr, q.iThScr, q.iCovIn), pk(q.iPipe, q.iLamp, q.iBlScr, z));
     K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
     K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
 }
@@ -385,6 +461,8 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         return r;
     };
     SlowCoef<T> q;
+    LaneStep<T> LS;
+    if (!LDSQ) gq_make_lane_step<T>(role, s, m, K, LS);
     for (int it = -1; it <= n_win; ++it) {
         flags |= (T(n_cap) * hw > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
         if (flags & SC_FLAG_CAP) break;
@@ -405,7 +483,8 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             ym[19] = gq_bcast<1>(mid[6]);
             ym[22] = gq_bcast<2>(mid[3]); ym[23] = gq_bcast<2>(mid[4]); ym[24] = gq_bcast<2>(mid[5]); ym[25] = gq_bcast<2>(mid[6]);
             slow_coef<T>(ym, s, m, cr, q);
-            gq_make_lane<T>(role, s, m, q, K);
+            if (LDSQ) gq_make_lane<T>(role, s, m, q, K);
+            else gq_make_lane_win<T>(role, s, m, q, K, LS);
         }
         // ---- first stage of the window's first sub-step with the rate bound; branch invariant; error estimate of the last sub-step
         QRates<T> R;
