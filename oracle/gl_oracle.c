@@ -664,6 +664,22 @@ static void rhs_lagged(const double *xs, const double *ymid, const double *u, co
 }
 
 extern int gl_sc_exp;
+/* Round 5 study hook (oracle/studies/lsrk_study.py): order == 5 = a FIVE-stage fourth-order scheme in Williamson's 2N-storage form
+ *   dy <- A_i dy + h f(y),  y <- y + B_i dy,   i = 1..5
+ * with the coefficients below (default: Carpenter-Kennedy 1994, z^5 coefficient 1/200, real-axis stability interval 4.657) --
+ * settable, so that members of the same family with another z^5 coefficient can be tried; gl_ls_S = the interval the stability
+ * control may use.  Classical (no exponential part): the cover conduction stays in the right-hand side and in the rate bound. */
+double gl_ls_A[5] = {0.0, -567301805773.0 / 1357537059087.0, -2404267990393.0 / 2016746695238.0, -3550918686646.0 / 2091501179385.0,
+                     -1275806237668.0 / 842570457699.0};
+double gl_ls_B[5] = {1432997174477.0 / 9575080441755.0, 5161836677717.0 / 13612068292357.0, 1720146321549.0 / 2090206949498.0,
+                     3134564353537.0 / 4481467310338.0, 2277821191437.0 / 14882151754819.0};
+double gl_ls_S = 4.657;
+int gl_ls_est = 1;      /* 1: trapezoid comparison e = |dy - h/2 (k1 + k1')| as the safety net; 0: none */
+void gl_oracle_set_lsrk(const double *A, const double *B, double S, int est)
+{
+    for (int i = 0; i < 5; ++i) { gl_ls_A[i] = A[i]; gl_ls_B[i] = B[i]; }
+    gl_ls_S = S; gl_ls_est = est;
+}
 static void rk4_exp_substep(double *x, const double *k1, const double *ym, const double *u, const double *d, const double *p,
                             int pipe, double h, int em, double *est, double *est_ar, double *est_w);
 /* order = 4 RK4 / 3 the three-stage third-order scheme (both with the cover pair's conduction integrated exactly: gl_sc_exp,
@@ -686,7 +702,13 @@ static void rk_lagged_impl(const double *x0, const double *u, const double *d, c
             for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];   /* predicted middle of the window */
             memcpy(xw, x, sizeof xw);
         }
-        if (order == 4 && gl_sc_exp) {
+        if (order == 5) {
+            double dy[GL_NX] = {0};
+            for (int st = 0; st < 5; ++st) {
+                rhs_lagged(x, ym, u, d, p, k1, pipe);
+                for (int i = 0; i < GL_NX; ++i) { dy[i] = gl_ls_A[st] * dy[i] + h * k1[i]; x[i] += gl_ls_B[st] * dy[i]; }
+            }
+        } else if (order == 4 && gl_sc_exp) {
             rhs_lagged(x, ym, u, d, p, k1, pipe);
             rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, gl_sc_exp, NULL, NULL, NULL);
         } else if (order == 4) {
@@ -1033,8 +1055,9 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
 {
     double x[GL_NX], k1[GL_NX], k2[GL_NX], k3[GL_NX], k4[GL_NX], xs[GL_NX], ym[GL_NX], dprev[GL_NX], xw[GL_NX];
     double est[9] = {0}, est_w[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, est_ar[GL_NX] = {0};
-    const double S = SC_SAFETY * (order == 4 ? 2.785 : order == 3 ? 2.5127 : 2.0);
-    const double est_fac = 1.0 / 6.0;
+    const double S = SC_SAFETY * (order == 5 ? gl_ls_S : order == 4 ? 2.785 : order == 3 ? 2.5127 : 2.0);
+    const double est_fac = (order == 5) ? 1.0 : 1.0 / 6.0;
+    double ls_y0[9] = {0}, ls_k0[9] = {0};
     /* what is integrated exponentially: the cover conduction, in every scheme -- RK4 (order 4), the three-stage scheme (order 3; bit 16
      * selects its formulas in rk4_exp_substep) and the midpoint rule (order 2; bit 32); gl_sc_exp = 0 (studies): the classical schemes */
     const int em = (order == 4) ? gl_sc_exp : (order == 3) ? (gl_sc_exp | 16) : (order == 2) ? (gl_sc_exp | 32) : 0;
@@ -1100,6 +1123,11 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                     if (getenv("SC_TRACE") && est_w[j] * fabs(est[j] - v) / SC_TOL[j] > worst) fprintf(stderr, "   j %d est %.6g v %.6g w %.3f\n", j, est[j], v, est_w[j]);
                     worst = fmax(worst, est_w[j] * fabs(est[j] - v) / SC_TOL[j]);
                 }
+            } else if (order == 5) {
+                /* trapezoid comparison of the last sub-step: (dy - h/2 (k1 + k1')) / h  (est[] holds dy / h - k1 / 2) */
+                if (gl_ls_est == 1) for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - 0.5 * kz(k1, SC_FAST[j])) / SC_TOL[j]);
+                /* 2: the last stage (c5 ~ 1) against the next sub-step's first one, weight B5 -- the analogue of RK4's h/6 |k4 - k1'| */
+                if (gl_ls_est == 2) for (int j = 0; j < 9; ++j) worst = fmax(worst, gl_ls_B[4] * fabs(est[j] - kz(k1, SC_FAST[j])) / SC_TOL[j]);
             } else
             for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - kz(k1, SC_FAST[j])) / SC_TOL[j]);
             worst *= h_last * est_fac;
@@ -1128,7 +1156,16 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         h_last = h;
         for (int r = 0; r < n; ++r) {
             if (r > 0) rhs_lagged(x, ym, u, d, p, k1, pipe);
-            if (em) {
+            if (order == 5) {
+                double dy[GL_NX] = {0};
+                for (int j = 0; j < 9; ++j) { ls_y0[j] = kz(x, SC_FAST[j]); ls_k0[j] = kz(k1, SC_FAST[j]); }
+                for (int st = 0; st < 5; ++st) {
+                    if (st > 0) rhs_lagged(x, ym, u, d, p, k1, pipe);
+                    for (int i = 0; i < GL_NX; ++i) { dy[i] = gl_ls_A[st] * dy[i] + h * k1[i]; x[i] += gl_ls_B[st] * dy[i]; }
+                }
+                if (gl_ls_est == 2) for (int j = 0; j < 9; ++j) est[j] = kz(k1, SC_FAST[j]);        /* k1 holds the fifth stage here */
+                else for (int j = 0; j < 9; ++j) est[j] = (kz(x, SC_FAST[j]) - ls_y0[j]) / h - 0.5 * ls_k0[j];
+            } else if (em) {
                 rk4_exp_substep(x, k1, ym, u, d, p, pipe, h, em, est, est_ar, est_w);
             } else if (order == 4) {
                 for (int i = 0; i < GL_NX; ++i) xs[i] = x[i] + 0.5 * h * k1[i];
