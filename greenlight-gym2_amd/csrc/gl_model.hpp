@@ -1597,6 +1597,50 @@ template <class T> GL_HD void etd_coefs(T a, T h, EtdCoef<T>& c)
     c.hp1 = h * p1;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 5: ORDER = 5, the scheme "ls5" (GLGYM_SCHEME_LS5) -- a FIVE-stage FOURTH-order explicit Runge-Kutta scheme in Williamson's
+// 2N-storage form
+//     dy <- A_i dy + h f(y),   y <- y + B_i dy,   i = 1..5         (stage i is evaluated at t + c_i h)
+// Two registers per state (here: del and dy; the stage input is z0 + del) where RK4 in delta form holds four (y, xs, k-sum, del).
+// The family has 9 coefficients and 8 order conditions: one free parameter, the z^5 coefficient alpha of the stability polynomial
+// 1 + z + z^2/2 + z^3/6 + z^4/24 + alpha z^5.  Carpenter-Kennedy's published member has alpha = 1/200 (real-axis interval 4.657); this
+// one has alpha = 0.0044: interval 5.4588, |R| <= 0.5 on [2, 0.92 x 5.4588] -- 1.09 per right-hand side where classical RK4 has
+// 2.785 / 4 = 0.70, and better damped at its working point than RK4 at its own (0.71).  Coefficients by continuation in alpha from the
+// published set (oracle/studies/lsrk_study.py; order conditions satisfied to 3e-16).  Nominal n_sub 120 at dt = 900 s (7.5 s
+// sub-steps: rates up to 0.67 1/s), tier-2b window of two sub-steps (15 s, the window RK4 runs with): 600 stages + 60 windows per
+// env-step where RK4-240 takes 960 + 60, same accuracy on every fixture (oracle/studies/lsrk_study_result.txt).
+// The cover conduction is integrated exactly here too, in a form that needs no stage history: with N0 = N_w at the start of the
+// sub-step,  w(t) = w_c(t) + v(t),  w_c(t) = w0 + t phi1(-a t) (N0 - a w0)  (the exact solution for the forcing frozen at N0),
+// dv/dt = -a v + (N_w(t) - N0),  v(0) = 0,  and v is integrated by the same 2N scheme applied to e^(a t) v (Lawson's transformation).
+// Lawson's scheme alone does not keep the steady state of w (1 % off at a h = 2.4); applied to the DEVIATION of the forcing from its
+// frozen value that defect multiplies N_w(t) - N0 = O(h) only.  For a = 0 the formulas ARE the plain 2N scheme (what every other
+// state gets; gl_model_quad.hpp uses that to keep one instruction stream).  Per stage the pair (v, dv) is carried to the next stage
+// time by E_st = e^(-a h (c_st+1 - c_st)) and the frozen part advances by dphi_st (N0 - a w0), dphi_st = [t phi1(-a t)] between the
+// two times = e^(-a h c_st) h (c_st+1 - c_st) phi1(-a h (c_st+1 - c_st)).  oracle/gl_oracle.c (ls5_substep) restates it.
+// ---------------------------------------------------------------------------------------------------
+template <class T> struct Ls5 {
+    static constexpr double A(int i) { return i == 1 ? -0.3987683969951118 : i == 2 ? -1.1661466227104529 : i == 3 ? -1.7586643387140779 : i == 4 ? -2.015154140060639 : 0.0; }
+    static constexpr double B(int i) { return i == 0 ? 0.14886333924325532 : i == 1 ? 0.33205346250695417 : i == 2 ? 0.90633370476911845 : i == 3 ? 0.79081068362276141 : 0.12419275116472626; }
+    static constexpr double c(int i) { return i == 0 ? 0.0 : i == 1 ? 0.14886333924325532 : i == 2 ? 0.34850437478963492 : i == 3 ? 0.61938558286865075 : i == 4 ? 0.99452861095775569 : 1.0; }
+    static constexpr double S = 5.4588;             // real-axis stability interval
+};
+template <class T> struct LsCoef { T E[5], dphi[5]; };
+template <class T> GL_HD void ls_coefs(T a, T h, LsCoef<T>& c)
+{
+    // E_st = e^z, dphi_st = e^(-a h c_st) (h dc) phi1(z) at z = -a h dc, dc = c_st+1 - c_st: no division by a, so a = 0 gives E = 1,
+    // dphi = h dc -- the plain 2N scheme -- from the same instructions (etd_phis: series / recurrence, no cancellation)
+    T P = T(1);
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const T hdc = h * T(Ls5<T>::c(st + 1) - Ls5<T>::c(st));
+        T e, p1, p2, p3;
+        etd_phis<T>(-a * hdc, e, p1, p2, p3);
+        c.E[st] = e;
+        c.dphi[st] = P * (hdc * p1);
+        P = P * e;
+    }
+}
+
 // A lane whose rate bound at the START of the env-step asks for a shorter sub-step than the nominal one gets proportionally more
 // windows (SC_PRE_MARGIN x, at most SC_PRE_MAX x) instead of WIN + 1 longer sub-steps per window: a rate 5 % over the nominal limit
 // then costs that lane 5 % more stages, not 50 % -- and at one wave per SIMD the whole launch waits for its slowest lane.  What
@@ -1604,18 +1648,20 @@ template <class T> GL_HD void etd_coefs(T a, T h, EtdCoef<T>& c)
 #define SC_PRE_MARGIN 1.02
 #define SC_PRE_MAX 2.0
 
+// win_rt > 0 overrides the compile-time window WIN at run time (glgym_set_window: e.g. ls5 with one sub-step per window = the parity preset)
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                    int n_sub, T* del, ScStat<T>& st)
+                    int n_sub, T* del, ScStat<T>& st, int win_rt = 0)
 {
-    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 4 (RK4), 3 (three-stage third-order scheme) or 2 (midpoint rule), all with the cover conduction exponential");
+    static_assert(ORDER == 5 || ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 5 (five-stage fourth-order 2N scheme), 4 (RK4), 3 (three-stage third-order scheme) or 2 (midpoint rule), all with the cover conduction exponential");
     using M = Math<T>;
     constexpr bool COVEXP = true;                  // every scheme of the family integrates the cover conduction exactly (round 4)
-    const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
-    const T est_fac = T(1.0 / 6.0);
+    const int WINR = win_rt > 0 ? win_rt : WIN;
+    const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
+    const T est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
     // the environment's windows: nominal count now, its own after the pre-pass (it == -1) below
-    int n_win = (n_sub + WIN - 1) / WIN;
-    T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WIN), hmin = hnom * T(1.0 / SC_MAX_REFINE);
+    int n_win = (n_sub + WINR - 1) / WINR;
+    T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WINR), hmin = hnom * T(1.0 / SC_MAX_REFINE);
     int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
     // the integrator works in the coordinates of rhs_fast<WETDIFF>: slots 5, 7, 20 = tTop - tCovIn, tAir - tThScr, tAir - tBlScr;
@@ -1639,7 +1685,8 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     T t_cap = T(0);                 // time spent with the rate bound beyond what SC_MAX_REFINE covers
     T h_last = hnom;
     EtdCoef<T> ec;
-    T h_ec = T(-1);                 // the sub-step length ec was computed for
+    LsCoef<T> lc;                   // ORDER 5
+    T h_ec = T(-1);                 // the sub-step length ec / lc was computed for
     auto state_now = [&]() {                                      // y = x0 + del
 #pragma unroll
         for (int p = 0; p < GL_NPAIR; ++p)
@@ -1669,7 +1716,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
             if (sc > T(1)) {                                      // (a NaN rate leaves the nominal count)
                 n_win = (int)ceil_pos(T(n_win) * sc - T(1e-9));
-                hw = dt / T(n_win); hw2 = T(0.5) * hw; hnom = hw / T(WIN); hmin = hnom * T(1.0 / SC_MAX_REFINE);
+                hw = dt / T(n_win); hw2 = T(0.5) * hw; hnom = hw / T(WINR); hmin = hnom * T(1.0 / SC_MAX_REFINE);
                 n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
                 h_last = hnom;
             }
@@ -1694,7 +1741,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
             for (int j = 0; j < SC_NFAST; ++j) {
                 // (the ETD component's estimate carries f3 instead of h/6)
-                const T wj = (ORDER != 2 && sc_fast(j) == 6) ? T(sc_itol(j)) * ec.w3 : T(sc_itol(j));
+                const T wj = ((ORDER == 4 || ORDER == 3) && sc_fast(j) == 6) ? T(sc_itol(j)) * ec.w3 : T(sc_itol(j));
                 worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * wj);
             }
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
@@ -1729,10 +1776,40 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
         const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h;
         h_last = h;
-        if (COVEXP && h != h_ec) { etd_coefs<T>(T(2) * gamCov, h, ec); h_ec = h; }
+        if (COVEXP && h != h_ec) {
+            if (ORDER == 5) ls_coefs<T>(T(2) * gamCov, h, lc); else etd_coefs<T>(T(2) * gamCov, h, ec);
+            h_ec = h;
+        }
         // one sub-step from (y, k = f(y)): leaves the increment in del and the scheme's last stage in k
         auto sub_step = [&]() {
-            if (ORDER == 4) {
+            if (ORDER == 5) {
+                // the five-stage 2N scheme: acc holds dy / h (dy' <- A_i dy' + k, del <- del + (B_i h) dy'); the stage input is z0 + del.
+                // Slot 6 (w) by the exponential form above, slot 5 (tTop - tCovIn) assembled from the classical part k[5] and w's increments
+                const T w0 = y[6], N0 = k[6];
+                const T F0 = N0 - (T(2) * gamCov) * w0;                  // dw/dt at the start of the sub-step
+                T vv = T(0), dv = T(0);
+#pragma unroll
+                for (int stg = 0; stg < 5; ++stg) {
+                    if (stg > 0) { state_now(); rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k); }
+                    const T Ai = T(Ls5<T>::A(stg)), Bi = T(Ls5<T>::B(stg)), Bh = Bi * h;
+#pragma unroll
+                    for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                        if (p != 3)
+                            RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
+                                r.st(acc, stg == 0 ? r.ld(k) : r.sp(Ai) * r.ld(acc) + r.ld(k)); r.st(del, r.ld(del) + r.sp(Bh) * r.ld(acc)); });
+                    acc[5] = (stg == 0) ? k[5] : Ai * acc[5] + k[5];
+                    dv = (stg == 0) ? T(0) : Ai * dv + h * (k[6] - N0);
+                    const T vnext = lc.E[stg] * (vv + Bi * dv);
+                    dv = lc.E[stg] * dv;
+                    const T dW = lc.dphi[stg] * F0 + (vnext - vv);
+                    vv = vnext;
+                    del[6] += dW;
+                    del[5] += Bh * acc[5] - T(0.5) * dW;
+                }
+#pragma unroll
+                for (int p = GL_NPAIR_FAST; p < GL_NPAIR; ++p)          // constant-rate states
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.sp(h) * r.ld(k)); });
+            } else if (ORDER == 4) {
                 // classical RK4 on every fast pair but (5, 6) (acc = k1 + 2 k2 + 2 k3: ONE rounding per sub-step into del --
                 // accumulating del stage by stage instead was measured 4x noisier in fp32 over 2e4 refined sub-steps);
                 // slot 6 (w) by the ETD formulas above, slot 5 assembled from tTop, sigma and w
@@ -1904,9 +1981,10 @@ template <class T> GL_HD bool all_finite(const T* v)
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                             int n_sub, T* del, bool* failed, int* extra_steps = nullptr, bool verify = false,
-                            int* first_flags = nullptr)
+                            int* first_flags = nullptr, int win_rt = 0)
 {
     using M = Math<T>;
+    const int WINR = win_rt > 0 ? win_rt : WIN;
     int n = n_sub, extra = 0, total = 0;
     bool done = false, ok = false, have_prev = false;
     T prev[SC_NFAST];
@@ -1915,10 +1993,10 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         if (done) break;
         ScStat<T> st;
-        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del, st);
+        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del, st, win_rt);
         {
             total += st.n_steps;
-            const int n_nom = ((n + WIN - 1) / WIN) * WIN;
+            const int n_nom = ((n + WINR - 1) / WINR) * WINR;
             // diagnostics: why the FIRST attempt was not accepted as it stood (SC_FLAG_* | 16 = SC_HEAVY sub-steps)
             if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);
             const bool complete = all_finite(del) && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE));
@@ -1948,7 +2026,7 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
         n *= 2;
     }
     *failed = !ok;
-    if (extra_steps) { const int ex = total - ((n_sub + WIN - 1) / WIN) * WIN; *extra_steps = ex > 0 ? ex : 0; }
+    if (extra_steps) { const int ex = total - ((n_sub + WINR - 1) / WINR) * WINR; *extra_steps = ex > 0 ? ex : 0; }
     return extra;
 }
 

@@ -420,15 +420,17 @@ template <class T> __device__ __forceinline__ T gq_fast_max(const QVec<T>& a, P2
                         else if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K), "v"(&m) : "memory"); } while (0)
 template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
 __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
-                                              const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st)
+                                              const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st, int win_rt = 0)
 {
-    static_assert(ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER");
+    static_assert(ORDER == 5 || ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER");
     using M = Math<T>;
+    const int WINR = win_rt > 0 ? win_rt : WIN;               // run-time window (glgym_set_window), rk_delta
     // the quad's windows: nominal count now, its own after the pre-pass (it == -1; rk_delta)
-    int n_win = (n_sub + WIN - 1) / WIN;
-    T hw = dt / T(n_win), hnom = hw / T(WIN);
+    int n_win = (n_sub + WINR - 1) / WINR;
+    T hw = dt / T(n_win), hnom = hw / T(WINR);
     int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
-    const T S = T(SC_SAFETY * (ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(1.0 / 6.0);
+    const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
+    LsCoef<T> lc;                 // ORDER 5: the pair's y component by the exponential 2N formulas (gl_model.hpp ls_coefs), in registers
     const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
     const T gam = m.iCapCov * m.cCovCond, cw = cov ? T(0.5) : T(0);
     QVec<T> y, xs, k, acc;
@@ -497,7 +499,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
             if (sc > T(1)) {
                 n_win = (int)ceil_pos(T(n_win) * sc - T(1e-9));
-                hw = dt / T(n_win); hnom = hw / T(WIN);
+                hw = dt / T(n_win); hnom = hw / T(WINR);
                 n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
             }
             harvest(T(0.5) * hw);
@@ -509,7 +511,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             QVec<T> dif;
             dif.p = estP - k.p;
             for (int i = 0; i < 6; ++i) dif.sh[i] = estS[i] - k.sh[i];
-            const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, ORDER != 2 ? gq_tol<T>(role).est.y * K.ec.w3 : gq_tol<T>(role).est.y)));     // (the ETD component's estimate carries f3)
+            const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, (ORDER == 4 || ORDER == 3) ? gq_tol<T>(role).est.y * K.ec.w3 : gq_tol<T>(role).est.y)));     // (the ETD component's estimate carries f3)
             const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
             flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;
         }
@@ -526,7 +528,9 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         capped_prev = capped;
         T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
         const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
-        if (h != h_last) etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
+        if (h != h_last) {
+            if (ORDER == 5) ls_coefs<T>(cov ? T(2) * gam : T(0), h, lc); else etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
+        }
         h_last = h;
         // one sub-step from (y, k = f(y)): the classical scheme on the pair's x component, the shared states and lane 0's / lane 3's first
         // two "others" (tCan24, tCanSum | tIntLamp, time), its ETD sibling on the pair's y component (classical coefficients off the
@@ -539,7 +543,31 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                 for (int i = 0; i < 6; ++i) xs.sh[i] = y.sh[i] + c * k.sh[i];
                 xs.o[0] = y.o[0] + c * k.o[0]; xs.o[1] = y.o[1] + c * k.o[1]; xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
             };
-            if (ORDER == 4) {
+            if (ORDER == 5) {
+                // the five-stage 2N scheme (gl_model.hpp rk_delta ORDER 5): acc holds dy / h; the stage input is z0 + del.  The pair's y
+                // component by the exponential form with per-lane coefficients -- a = 2 gam on the cover lane; a = 0 elsewhere, for
+                // which E = 1, dphi = h dc and the formulas ARE the plain 2N scheme: one instruction stream for the four lanes
+                const T F0 = n1 - (cov ? T(2) * gam : T(0)) * w0;
+                T vv = T(0), dv = T(0);
+#pragma unroll
+                for (int stg = 0; stg < 5; ++stg) {
+                    if (stg > 0) { state_now(); GQ_FENCE(); gq_stage<T, false, PIPE>(role, y, K, s, m, q, k, nullptr); }
+                    const T Ai = T(Ls5<T>::A(stg)), Bi = T(Ls5<T>::B(stg)), Bh = Bi * h;
+                    acc.p.x = (stg == 0) ? k.p.x : Ai * acc.p.x + k.p.x;
+                    for (int i = 0; i < 6; ++i) { acc.sh[i] = (stg == 0) ? k.sh[i] : Ai * acc.sh[i] + k.sh[i]; del.sh[i] += Bh * acc.sh[i]; }
+                    acc.o[0] = (stg == 0) ? k.o[0] : Ai * acc.o[0] + k.o[0]; acc.o[1] = (stg == 0) ? k.o[1] : Ai * acc.o[1] + k.o[1];
+                    dv = (stg == 0) ? T(0) : Ai * dv + h * (k.p.y - n1);
+                    const T vnext = lc.E[stg] * (vv + Bi * dv);
+                    dv = lc.E[stg] * dv;
+                    const T dW = lc.dphi[stg] * F0 + (vnext - vv);
+                    vv = vnext;
+                    del.p = gq_mk<T>(del.p.x + Bh * acc.p.x - cw * dW, del.p.y + dW);
+                    del.o[0] += full01 ? Bh * acc.o[0] : T(0);
+                    del.o[1] += full01 ? Bh * acc.o[1] : T(0);
+                }
+                del.o[0] += full01 ? T(0) : h * k.o[0];
+                del.o[1] += full01 ? T(0) : h * k.o[1];
+            } else if (ORDER == 4) {
                 T dWa, accW;
                 auto accum = [&]() {
                     acc.p.x += T(2) * k.p.x;
@@ -635,9 +663,10 @@ template <class T> __device__ __forceinline__ void gq_phys_pair(int role, const 
 template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
 __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
                                                       const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps,
-                                                      bool verify, int* first_flags)
+                                                      bool verify, int* first_flags, int win_rt = 0)
 {
     using M = Math<T>;
+    const int WINR = win_rt > 0 ? win_rt : WIN;
     const QTol<T> tol = gq_tol<T>(role);
     int n = n_sub, extra = 0, total = 0;
     bool done = false, ok = false, have_prev = false;
@@ -647,9 +676,9 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         if (done) break;                                   // uniform inside the quad: every decision below is
         ScStat<T> st;
-        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st);
+        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
         total += st.n_steps;
-        const int n_nom = ((n + WIN - 1) / WIN) * WIN;
+        const int n_nom = ((n + WINR - 1) / WINR) * WINR;
         if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);
         T chk = (del.p.x + del.p.y) * T(0);
         for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
@@ -674,7 +703,7 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
         n *= 2;
     }
     *failed = !ok;
-    if (extra_steps) { const int ex = total - ((n_sub + WIN - 1) / WIN) * WIN; *extra_steps = ex > 0 ? ex : 0; }
+    if (extra_steps) { const int ex = total - ((n_sub + WINR - 1) / WINR) * WINR; *extra_steps = ex > 0 ? ex : 0; }
     return extra;
 }
 

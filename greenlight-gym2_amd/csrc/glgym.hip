@@ -110,6 +110,7 @@ template <class T> struct StepArgsT {
     float du, u_min[NU], u_max[NU];      // action_to_control: clip(u + action * delta_u_max, u_min, u_max)
     int verify;                 // 1: step-doubling verified integration (rk4_delta_guarded), see glgym_set_verify
     int pipe;                   // 1: the handle's ODE variant is GLGYM_ODE_PIPE (kernels that select the variant at run time)
+    int window;                 // > 0: nominal sub-steps per tier-2b window, overriding the scheme's own (glgym_set_window)
 };
 
 template <class T> __device__ __forceinline__ T wave_sum(T v)
@@ -149,8 +150,9 @@ template <class T> __device__ __forceinline__ T sat_vp_exact(T t)
 template <class T> struct RK4_WINDOW { static constexpr int value = sizeof(T) == 4 ? GL_RK4_WIN_F32 : GL_RK4_WIN_F64; };
 // SCH (template argument of the integrating kernels) = GLGYM_SCHEME_*: 0 RK4, 1 the midpoint member (four sub-steps per tier-2b
 // window), 2 the three-stage member (three) of the exponential family (gl_model.hpp rk_delta)
-constexpr int gl_order(int sch) { return sch == 0 ? 4 : sch == 1 ? 2 : 3; }
-template <class T, int SCH> struct SchemeWin { static constexpr int value = SCH == 0 ? RK4_WINDOW<T>::value : SCH == 1 ? 4 : 3; };
+// 3 (GLGYM_SCHEME_LS5): the five-stage fourth-order 2N scheme, two sub-steps per window (gl_model.hpp rk_delta ORDER 5)
+constexpr int gl_order(int sch) { return sch == 0 ? 4 : sch == 1 ? 2 : sch == 2 ? 3 : 5; }
+template <class T, int SCH> struct SchemeWin { static constexpr int value = SCH == 0 ? RK4_WINDOW<T>::value : SCH == 1 ? 4 : SCH == 2 ? 3 : 2; };
 
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
 // SCH = GLGYM_SCHEME_RK2 / _RK3: midpoint / three-stage sub-steps, tier 2b and the harvest flow shared by four / three of them,
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
     T del[NX];
     bool bad;
     int extra_steps, first_flags = 0;
-    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags);
+    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags, a.window);
     const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
         a.timestep[b] = ts + 1;
         a.reward[b] = reward;
         a.done[b] = term ? 1 : 0;
-        if (a.step_flags) a.step_flags[b] = first_flags | (retries << 8) | (bad ? GLGYM_SF_FAILED : 0) | (min(extra_steps, 65535) << 16);
+        if (a.step_flags) a.step_flags[b] = first_flags | (retries << 8) | (bad ? GLGYM_SF_FAILED : 0) | (min(extra_steps, 32767) << 16);
         if (a.info) {
             const T inf[GLGYM_NINFO] = {profit, gains, varc, rw.fixedCosts, co2c, heat, elec, viol[1], viol[0], viol[2], T(0)};
 #pragma unroll
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     bool bad;
     int extra_steps, first_flags = 0;
     const int retries = rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad,
-                                                                                                      &extra_steps, a.verify != 0, &first_flags);
+                                                                                                      &extra_steps, a.verify != 0, &first_flags, a.window);
     // ---- new state: physical increments of what the lane owns.  Nothing but the integrator's own state is kept live across the
     // integrator (the fp64 build is at its register limit there): the old state and the applied control are read again
     P2<T> dP;
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
             a.timestep[b2] = ts2 + 1;
             a.reward[b2] = reward;
             a.done[b2] = term ? 1 : 0;
-            if (a.step_flags) a.step_flags[b2] = first_flags | (retries << 8) | (bad ? GLGYM_SF_FAILED : 0) | (min(extra_steps, 65535) << 16);
+            if (a.step_flags) a.step_flags[b2] = first_flags | (retries << 8) | (bad ? GLGYM_SF_FAILED : 0) | (min(extra_steps, 32767) << 16);
             if (a.info) {
                 const T inf[GLGYM_NINFO] = {profit, gains, varc, rw.fixedCosts, co2c, heat, elec, viol[1], viol[0], viol[2], T(0)};
 #pragma unroll
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
 template <class T, int SCH, bool PIPE, bool CROP>
 __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const double* u, const double* d, const double* crop, int B, T dt,
                                                           int n_sub, T gasR, T tCanMin, ModelConst<T> m_arg, double* x_next, int nd,
-                                                          int* n_failed, int verify, int pipe)
+                                                          int* n_failed, int verify, int pipe, int window)
 {
     constexpr bool LDSM = sizeof(T) == 8;      // the parameter block in LDS (step_kernel_quad)
     __shared__ ModelConst<T> sh_m[1];
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const
     bool bad;
     int extra_steps, first_flags = 0;
     rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, dt, n_sub, del, &bad, &extra_steps, verify != 0,
-                                                                                  &first_flags);
+                                                                                  &first_flags, window);
     // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
     P2<T> dP;
     gq_phys_pair<T>(role, del, dP);
@@ -624,7 +626,7 @@ template <class T, bool PER_ENV_CROP, bool PIPE = false, int SCH = 0>
 __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const double* u, const double* d,
                                                      const double* crop, int B, T dt, int n_sub, T gasR, T tCanMin,
                                                      ModelConst<T> m, double* x_next, int rhs_only, int nd,
-                                                     int* n_failed, int verify)
+                                                     int* n_failed, int verify, int window)
 {
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= B) return;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel(const double* x, const doub
     }
     T del[NX];
     bool failed;
-    rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, dt, n_sub, del, &failed, nullptr, verify != 0);
+    rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, dt, n_sub, del, &failed, nullptr, verify != 0, nullptr, window);
     // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
     for (int i = 0; i < NX; ++i)
         x_next[(size_t)b * NX + i] = failed ? __builtin_nan("") : (double)x0[i] + (double)del[i];
@@ -1223,6 +1225,9 @@ struct glgym_handle_s {
     int scheme = GLGYM_SCHEME_RK4;      // GLGYM_SCHEME_RK4 | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3
     int verify_mode = GLGYM_VERIFY_AUTO;   // glgym_set_verify
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
+    int window = 0;                     // glgym_set_window: 0 = the scheme's own
+    int layout = GLGYM_LAYOUT_AUTO;     // glgym_set_layout (fp32); initial value from GLGYM_LAYOUT at glgym_create
+    int occupancy = 1;                  // glgym_set_occupancy (one-lane fp32 kernel); initial value from GLGYM_OCC at glgym_create
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
     float du = 0.1f, u_min[NU] = {0, 0, 0, 0, 0, 0}, u_max[NU] = {1, 1, 1, 1, 1, 1};   // glgym_set_control_limits
     int obs_modules[6] = {0, 1, 2, 3, 4, 5};   // observation modules in output order (glgym_set_obs_modules)
@@ -1261,9 +1266,10 @@ static int refresh(glgym_handle h)
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
-    explicit DeviceGuard(int dev)
+    // a null handle binds nothing (the entry point then returns GLGYM_EINVAL without having created a context on any device)
+    explicit DeviceGuard(const glgym_handle_s* h)
     {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
     }
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete;
@@ -1272,7 +1278,8 @@ struct DeviceGuard {
 
 extern "C" {
 
-const char* glgym_version(void) { return "glgym 0.4 (gfx950; stability-controlled, step-doubling-verified RK4 / RK3 / midpoint sub-steppers in delta form)"; }
+const char* glgym_version(void) { return "glgym 0.5 (gfx950; ABI 5; stability-controlled, step-doubling-verified sub-steppers in delta form: five-stage fourth-order 2N scheme / RK4 / RK3 / midpoint)"; }
+int glgym_abi_version(void) { return GLGYM_ABI_VERSION; }
 const char* glgym_last_error(void) { return g_err.c_str(); }
 
 int glgym_destroy(glgym_handle h);
@@ -1304,6 +1311,10 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     if (const char* e = std::getenv("GLGYM_GENERIC")) h->use_specialised = (e[0] == '1') ? 0 : 1;
     if (const char* e = std::getenv("GLGYM_VERIFY"))          // default of glgym_set_verify: auto | always | never (A/B tests)
         h->verify_mode = (e[0] == 'n') ? GLGYM_VERIFY_NEVER : (e[0] == 'a' && e[1] == 'l') ? GLGYM_VERIFY_ALWAYS : GLGYM_VERIFY_AUTO;
+    // initial values of glgym_set_layout / glgym_set_occupancy, read ONCE here (A/B tools set them before creating their handle); the
+    // launch path reads handle state only
+    if (const char* e = std::getenv("GLGYM_LAYOUT")) h->layout = (e[0] == 'q') ? GLGYM_LAYOUT_QUAD : (e[0] == 'o') ? GLGYM_LAYOUT_ONE : GLGYM_LAYOUT_AUTO;
+    if (const char* e = std::getenv("GLGYM_OCC")) h->occupancy = (std::atoi(e) == 2) ? 2 : 1;
     // from here on a failure must release what was acquired: run the steps through one exit point
     int rc = [&]() -> int {
         HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
@@ -1354,11 +1365,35 @@ int glgym_set_model_variant(glgym_handle h, int variant)
 
 int glgym_set_scheme(glgym_handle h, int scheme)
 {
-    if (!h || (scheme != GLGYM_SCHEME_RK4 && scheme != GLGYM_SCHEME_RK2 && scheme != GLGYM_SCHEME_RK3)) {
-        g_err = "glgym_set_scheme: GLGYM_SCHEME_RK4, GLGYM_SCHEME_RK2 or GLGYM_SCHEME_RK3";
+    if (!h || (scheme != GLGYM_SCHEME_RK4 && scheme != GLGYM_SCHEME_RK2 && scheme != GLGYM_SCHEME_RK3 && scheme != GLGYM_SCHEME_LS5)) {
+        g_err = "glgym_set_scheme: GLGYM_SCHEME_RK4, GLGYM_SCHEME_RK2, GLGYM_SCHEME_RK3 or GLGYM_SCHEME_LS5";
         return GLGYM_EINVAL;
     }
     h->scheme = scheme;
+    return GLGYM_OK;
+}
+
+int glgym_set_window(glgym_handle h, int window)
+{
+    if (!h || window < 0 || window > 8) { g_err = "glgym_set_window: 0 (the scheme's own) or 1..8 nominal sub-steps per window"; return GLGYM_EINVAL; }
+    h->window = window;
+    return GLGYM_OK;
+}
+
+int glgym_set_layout(glgym_handle h, int layout)
+{
+    if (!h || (layout != GLGYM_LAYOUT_AUTO && layout != GLGYM_LAYOUT_ONE && layout != GLGYM_LAYOUT_QUAD)) {
+        g_err = "glgym_set_layout: GLGYM_LAYOUT_AUTO, GLGYM_LAYOUT_ONE or GLGYM_LAYOUT_QUAD";
+        return GLGYM_EINVAL;
+    }
+    h->layout = layout;
+    return GLGYM_OK;
+}
+
+int glgym_set_occupancy(glgym_handle h, int waves_per_simd)
+{
+    if (!h || (waves_per_simd != 1 && waves_per_simd != 2)) { g_err = "glgym_set_occupancy: 1 or 2 waves per SIMD"; return GLGYM_EINVAL; }
+    h->occupancy = waves_per_simd;
     return GLGYM_OK;
 }
 
@@ -1427,14 +1462,14 @@ static void launch_evalf_sch(glgym_handle h, const ModelConst<T>& m, const doubl
         const dim3 qgrid((4 * B + WAVE - 1) / WAVE);
         const int pipe = h->variant == GLGYM_ODE_PIPE ? 1 : 0;
         if (dcrop) hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, true>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                                      T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe);
+                                      T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe, h->window);
         else hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, false>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                                T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe);
+                                T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe, h->window);
     } else {
         if (dcrop) hipLaunchKernelGGL((evalf_kernel<T, true, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                                      T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify);
+                                      T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify, h->window);
         else hipLaunchKernelGGL((evalf_kernel<T, false, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                                T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify);
+                                T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify, h->window);
     }
 }
 
@@ -1461,12 +1496,14 @@ static int run_evalf(glgym_handle h, const ModelConst<T>& m, const double* p_use
         } else {
             const int verify = h->verify_mode != GLGYM_VERIFY_NEVER;
             hipLaunchKernelGGL((evalf_kernel<T, false, true>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
-                               T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify);
+                               T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify, h->window);
         }
     } else if (h->scheme == GLGYM_SCHEME_RK2) {
         launch_evalf_sch<T, GLGYM_SCHEME_RK2>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
     } else if (h->scheme == GLGYM_SCHEME_RK3) {
         launch_evalf_sch<T, GLGYM_SCHEME_RK3>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
+    } else if (h->scheme == GLGYM_SCHEME_LS5) {
+        launch_evalf_sch<T, GLGYM_SCHEME_LS5>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
     } else {
         launch_evalf_sch<T, GLGYM_SCHEME_RK4>(h, m, p_used, dx, du, dd, dcrop, B, dout, grid, block);
     }
@@ -1603,6 +1640,7 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // AUTO: verified wherever the control can jump -- raw controls (step_raw_control, the rule-based controller), or an action
     // path whose delta_u_max is wider than the reference's 0.1 (TomatoEnv.yml; base_env.py:74)
     k.pipe = h->variant == GLGYM_ODE_PIPE ? 1 : 0;
+    k.window = h->window;
     k.verify = h->verify_mode == GLGYM_VERIFY_ALWAYS || (h->verify_mode == GLGYM_VERIFY_AUTO && (!a->action || h->du > 0.1001f));
     const dim3 grid((a->B + WAVE - 1) / WAVE), block(WAVE), qgrid((4 * a->B + WAVE - 1) / WAVE);
     const bool pipe = h->variant == GLGYM_ODE_PIPE;
@@ -1618,17 +1656,18 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     if constexpr (sizeof(T) == 8) {
         if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);
         else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def);
+        else if (h->scheme == GLGYM_SCHEME_LS5) launch_quad_sch<T, GLGYM_SCHEME_LS5>(a, k, m, rw, qgrid, block, st, def);
         else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def);
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
     } else {
-        const char* le_ = std::getenv("GLGYM_LAYOUT");
-        const int layout_env = !le_ ? 0 : (le_[0] == 'q' ? 2 : 1);
+        const int layout_env = h->layout;                        // handle state (glgym_set_layout): 0 auto, 1 one, 2 quad
         const bool quad_ok = !pipe && !a->crop_p;
         const int b_small = 4 * h->n_simd * 4;                   // 16 384 on MI355X: one quad-kernel round
         if (quad_ok && (layout_env == 2 || (layout_env == 0 && a->B <= b_small))) {
             if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);
             else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def);
+            else if (h->scheme == GLGYM_SCHEME_LS5) launch_quad_sch<T, GLGYM_SCHEME_LS5>(a, k, m, rw, qgrid, block, st, def);
             else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def);
             HIPCHK(hipGetLastError());
             return GLGYM_OK;
@@ -1640,10 +1679,10 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
         }
         // The two-waves-per-SIMD build (256 registers + scratch) is taken on request only (GLGYM_OCC=2, read per launch): it spills and
         // runs 0.70x the one-wave build at every batch size (profiles/r03_occupancy2_plain.txt).
-        const char* oe_ = std::getenv("GLGYM_OCC");
-        const bool occ2 = def && !a->crop_p && oe_ && std::atoi(oe_) == 2;
+        const bool occ2 = def && !a->crop_p && h->occupancy == 2;
         if (h->scheme == GLGYM_SCHEME_RK2) launch_step_sch<GLGYM_SCHEME_RK2>(a, k, m, rw, grid, block, st, def, occ2);
         else if (h->scheme == GLGYM_SCHEME_RK3) launch_step_sch<GLGYM_SCHEME_RK3>(a, k, m, rw, grid, block, st, def, occ2);
+        else if (h->scheme == GLGYM_SCHEME_LS5) launch_step_sch<GLGYM_SCHEME_LS5>(a, k, m, rw, grid, block, st, def, occ2);
         else launch_step_sch<GLGYM_SCHEME_RK4>(a, k, m, rw, grid, block, st, def, occ2);
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
@@ -1652,12 +1691,18 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
 
 extern "C" int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
-    if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
+    if (!h || !a) { g_err = "glgym_step: null handle / arguments"; return GLGYM_EINVAL; }
+    if (a->struct_size != (int32_t)sizeof(glgym_step_args)) {     // checked before any pointer member is read
+        g_err = "glgym_step: glgym_step_args.struct_size is " + std::to_string(a->struct_size) + ", this library expects " +
+                std::to_string(sizeof(glgym_step_args)) + " (ABI " + std::to_string(GLGYM_ABI_VERSION) + "): rebuild against include/glgym.h";
+        return GLGYM_EINVAL;
+    }
+    if (a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
         !a->reward || !a->done || (!a->action) == (!a->control) || a->weather_rows < 1) {
         g_err = "glgym_step: bad arguments (exactly one of action/control, ld >= B, non-null state/outputs)";
         return GLGYM_EINVAL;
     }
+    DeviceGuard dev_guard(h);
     hipStream_t st = (hipStream_t)stream;
     return h->dtype == GLGYM_F32 ? launch_step<float>(h, a, h->mf, h->rf, st)
                                  : launch_step<double>(h, a, h->md, h->rd, st);
@@ -1691,7 +1736,7 @@ template <class T> static int launch_obs(glgym_handle h, const glgym_obs_args* a
 
 extern "C" int glgym_weather(glgym_handle h, const glgym_weather_args* a, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !a || a->n_raw < 3 || a->n_out < 1 || a->nd < ND || !a->time || !a->i_glob || !a->t_out || !a->rh || !a->wind ||
         !a->t_sky || !a->out || !a->workspace) {
         g_err = "glgym_weather: bad arguments (>= 3 raw samples, nd >= 10, non-null device pointers)";
@@ -1721,7 +1766,7 @@ extern "C" int glgym_weather(glgym_handle h, const glgym_weather_args* a, void* 
 
 extern "C" int glgym_vecnorm(glgym_handle h, const glgym_vecnorm_args* a, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !a || a->B < 1 || a->dim < 1 || !a->obs || !a->obs_out || !a->obs_mean || !a->obs_var || !a->obs_count ||
         !a->workspace || (a->reward && (!a->reward_out || !a->ret_stats || !a->returns))) {
         g_err = "glgym_vecnorm: bad arguments";
@@ -1779,7 +1824,7 @@ extern "C" {
 
 int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->weather || !a->w_off || !a->timestep ||
         !a->start_day || !a->obs || a->Np < 0 || a->Np > OBS_MAX_NP) {
         g_err = "glgym_obs: bad arguments (null pointer, ld < B, or Np outside 0..128)";
@@ -1816,7 +1861,7 @@ int glgym_obs_dim(glgym_handle h, int Np)
 
 int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !a || a->B < 1 || a->ld < a->B || !a->x || !a->u || !a->timestep || !a->weather || !a->w_off) {
         g_err = "glgym_reset: bad arguments";
         return GLGYM_EINVAL;
@@ -1839,7 +1884,7 @@ int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream)
 int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, uint64_t seed, uint64_t draw_index,
                      void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !crop_p || B < 1 || ld < B) return GLGYM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((B + 255) / 256), block(256);
@@ -1855,7 +1900,7 @@ int glgym_crop_noise(glgym_handle h, void* crop_p, int B, int ld, double scale, 
 
 int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule_args* a, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !cfg || !a || a->B < 1 || a->ld < a->B || !a->x || !a->weather || !a->w_off || !a->timestep || !a->control ||
         a->weather_rows < 1 || (!a->start_day && !a->doy) || cfg->vent_heat_Pband == 0 || cfg->vent_rh_Pband == 0 ||
         cfg->vent_cold_Pband == 0 || cfg->thScrPband == 0 || cfg->thScrRhPband == 0 || cfg->tHeatBand == 0 ||
@@ -1880,7 +1925,7 @@ int glgym_rule_based(glgym_handle h, const glgym_rule_cfg* cfg, const glgym_rule
 
 int glgym_timer_start(glgym_handle h, void* stream)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h) return GLGYM_EINVAL;
     HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
     return GLGYM_OK;
@@ -1888,7 +1933,7 @@ int glgym_timer_start(glgym_handle h, void* stream)
 
 int glgym_timer_stop(glgym_handle h, void* stream, float* elapsed_ms)
 {
-    DeviceGuard dev_guard(h ? h->device : 0);
+    DeviceGuard dev_guard(h);
     if (!h || !elapsed_ms) return GLGYM_EINVAL;
     HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(h->ev1));

@@ -15,7 +15,10 @@ F32, F64 = 0, 1
 ODE, ODE_PIPE = 0, 1
 SCHEME_RK4, SCHEME_RK2 = 0, 1
 SCHEME_RK3 = 2
-SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3}
+SCHEME_LS5 = 3
+SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3, "ls5": SCHEME_LS5}
+ABI_VERSION = 5                                           # include/glgym.h GLGYM_ABI_VERSION
+LAYOUTS = {"auto": 0, "one": 1, "quad": 2}                # glgym_layout
 # NOMINAL sub-steps per 900 s env-step.  RK4 (round 4): the conduction between the two faces of the cover glass -- the 0.65 1/s
 # mode that kept every explicit scheme at >= 224 sub-steps -- is integrated exactly (gl_model.hpp rk_delta, COVEXP), so the nominal
 # sub-step is set by the top compartment's air exchange: 240 covers rates up to 0.68 1/s (exceeded in 2e-5 of random-action
@@ -23,18 +26,33 @@ SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3}
 # environment whose rate bound at the start of the env-step asks for more gets proportionally more windows (its own sub-step
 # length), and what changes inside the env-step is followed window by window.  "rk3" is the three-stage member of the same
 # exponential family (stability interval 2.513: 270 covers 0.69 1/s), "rk2" its midpoint rule (2.0: 336 covers 0.69 1/s).
-DEFAULT_N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270}
+# "ls5" (round 5, the default): the five-stage fourth-order 2N-storage scheme (stability interval 5.459: 1.09 per right-hand side
+# against RK4's 0.70; cover conduction exact as in the others): 120 covers 0.67 1/s, two sub-steps per window = the 15 s window of
+# RK4-240 -- 600 right-hand sides per env-step for RK4-240's 960 at the same accuracy.
+DEFAULT_N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270, "ls5": 120}
+DEFAULT_SCHEME = "ls5"
 VERIFY_MODES = {"auto": 0, "always": 1, "never": 2}     # glgym_verify (include/glgym.h)
-N_SUB_MULTIPLE = {"rk4": 4, "rk2": 4, "rk3": 3}          # widest tier-2b window of the scheme
+N_SUB_MULTIPLE = {"rk4": 4, "rk2": 4, "rk3": 3, "ls5": 2}          # tier-2b window of the scheme
+# PRESETS.  "throughput": the scheme's nominal count with its own window (max scaled error on the tight one-step tuples 6.1e-5 for
+# ls5 and rk4, 10-day rollout 1.5e-5 fp64 / 2.9e-5 fp32; bar 1e-4).  "parity": inside the 1.3e-5 band a BDF solve at the reference's
+# tolerances (greenlight_model.cpp:51-52) keeps from the tight solution -- ls5: n_sub 192 with ONE sub-step per window (1.0e-5), the
+# others: n_sub x 8/3 with their own window (rk4 640: 8.7e-6).  (n_sub, window) at dt = 900 s; window 0 = the scheme's own.
+PRESETS = {"throughput": {k: (v, 0) for k, v in DEFAULT_N_SUB.items()},
+           "parity": {"ls5": (192, 1), "rk4": (640, 0), "rk3": (720, 0), "rk2": (896, 0)}}
+
+
+def preset_n_sub(scheme: str, dt: float, preset: str = "throughput"):
+    """-> (n_sub, window) of `preset` for `scheme`, n_sub scaled with dt so that the nominal sub-step h = dt / n_sub stays the same
+    (e.g. ls5: 7.5 s, 40 sub-steps at the dt = 300 s of experiments/run_time.py) and rounded up to a multiple of the window."""
+    n0, window = PRESETS[preset][scheme]
+    n = n0 * float(dt) / 900.0
+    mult = window if window > 0 else N_SUB_MULTIPLE[scheme]
+    return max(mult, int(-(-n // mult) * mult)), window
 
 
 def default_n_sub(scheme: str, dt: float) -> int:
-    """Nominal sub-steps per env-step when the caller gives none: the scheme's count for the reference's dt = 900 s,
-    scaled with dt so that the nominal sub-step h = dt / n_sub stays the same (3.75 s RK4, 3.33 s three-stage scheme, 2.68 s midpoint) -- e.g. 80 for
-    the dt = 300 s of experiments/run_time.py; rounded up to a multiple of the scheme's tier-2b window (4, 4, 3)."""
-    n = DEFAULT_N_SUB[scheme] * float(dt) / 900.0
-    mult = N_SUB_MULTIPLE[scheme]
-    return max(mult, int(-(-n // mult) * mult))
+    """Nominal sub-steps per env-step of the throughput preset (see preset_n_sub)."""
+    return preset_n_sub(scheme, dt, "throughput")[0]
 OK, EINVAL, ENODEV, EHIP, ENOMEM, EODE = 0, -1, -2, -3, -4, -5
 
 INFO_KEYS = ("EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost",
@@ -61,10 +79,16 @@ class RewardCfg(C.Structure):
 
 
 class StepArgs(C.Structure):
-    _fields_ = [("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("u", C.c_void_p), ("action", C.c_void_p),
+    # struct_size first (ABI 5): glgym_step refuses a struct of another size; make_step_args() fills it
+    _fields_ = [("struct_size", C.c_int32), ("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("u", C.c_void_p), ("action", C.c_void_p),
                 ("control", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p),
                 ("timestep", C.c_void_p), ("crop_p", C.c_void_p), ("N", C.c_int32), ("reward", C.c_void_p),
                 ("info", C.c_void_p), ("done", C.c_void_p), ("metrics", C.c_void_p), ("step_flags", C.c_void_p)]
+
+
+def make_step_args(*args, **kw):
+    """StepArgs(...) without the leading struct_size, which is filled in here."""
+    return StepArgs(C.sizeof(StepArgs), *args, **kw)
 
 
 # step_flags bits (include/glgym.h GLGYM_SF_*)
@@ -120,6 +144,10 @@ class WeatherArgs(C.Structure):
 _DP = C.POINTER(C.c_double)
 PROTOTYPES = {
     "glgym_version": (C.c_char_p, []),
+    "glgym_abi_version": (C.c_int, []),
+    "glgym_set_window": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_layout": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_occupancy": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_last_error": (C.c_char_p, []),
     "glgym_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _DP, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_void_p)]),
@@ -168,6 +196,8 @@ def load():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/glgym.h
             fn.restype, fn.argtypes = res, args
+        if lib.glgym_abi_version() != ABI_VERSION:
+            raise GlgymError(f"{LIB_PATH} has ABI {lib.glgym_abi_version()}, this binding expects {ABI_VERSION}: rebuild the library")
         _lib = lib
     return _lib
 

@@ -18,15 +18,24 @@ from .parameters import init_default_params
 
 
 class GreenLight:
-    def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=None, device=0, variant="ode", scheme="rk4"):
+    def __init__(self, nx, nu, nd, np_, dt, dtype="float64", n_sub=None, device=0, variant="ode", scheme=None, window=None,
+                 preset="parity"):
         """nd = 10, or 14 as in experiments/gl_predefined_controls.py:95 (rows carry the measured pipe columns).
         variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14).
-        scheme = "rk4" (RK4 with the cover conduction integrated exactly, n_sub 240), "rk3" (three-stage third-order scheme, same exact conduction, 270) or "rk2" (midpoint rule, same exact conduction, 336): include/glgym.h."""
+        scheme = "ls5" (default; five-stage fourth-order 2N scheme), "rk4", "rk3" or "rk2" (include/glgym.h).
+        preset = "parity" (default HERE: this class stands in for the reference's CVODES call, so it integrates inside the band that
+        solver's tolerances keep from the tight solution -- ls5: n_sub 192, one sub-step per window, 1.0e-5 on the tight one-step
+        tuples) or "throughput" (n_sub 120, window 2: 6.1e-5; what the batched envs run); n_sub / window override the preset."""
         self._lib = L.load()
+        scheme = L.DEFAULT_SCHEME if scheme is None else scheme
         if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'rk4', 'rk3' or 'rk2'")
-        n_sub = L.default_n_sub(scheme, dt) if n_sub is None else n_sub
-        self.scheme, self.n_sub = scheme, int(n_sub)
+            raise ValueError("scheme must be 'ls5', 'rk4', 'rk3' or 'rk2'")
+        if preset not in L.PRESETS:
+            raise ValueError("preset must be 'parity' or 'throughput'")
+        n_def, w_def = L.preset_n_sub(scheme, dt, preset)
+        window = (w_def if n_sub is None else 0) if window is None else window
+        n_sub = n_def if n_sub is None else n_sub
+        self.scheme, self.n_sub, self.window, self.preset = scheme, int(n_sub), int(window), preset
         self.nx, self.nu, self.nd, self.np = int(nx), int(nu), int(nd), int(np_)
         self.dt = float(dt)
         self._h = C.c_void_p()
@@ -40,6 +49,7 @@ class GreenLight:
         if variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
+        L.check(self._lib.glgym_set_window(self._h, self.window), "glgym_set_window")
 
     @property
     def handle(self):
@@ -48,6 +58,10 @@ class GreenLight:
     def set_n_sub(self, n_sub):
         L.check(self._lib.glgym_set_n_sub(self._h, int(n_sub)), "glgym_set_n_sub")
         self.n_sub = int(n_sub)
+
+    def set_window(self, window):
+        L.check(self._lib.glgym_set_window(self._h, int(window)), "glgym_set_window")
+        self.window = int(window)
 
     def set_verify(self, mode: str):
         """Step-doubling verified integration: "auto" (default; evalF is always verified: it takes any u), "always", "never"

@@ -160,12 +160,16 @@ class TomatoVecEnv:
                  start_rows: Optional[Sequence[int]] = None, start_days: Optional[Sequence[float]] = None,
                  reward_params: Optional[Dict[str, Any]] = None, constraints: Optional[Dict[str, float]] = None,
                  auto_reset: bool = True, collect_metrics: bool = True, lazy_infos: Optional[bool] = None,
-                 model_variant: str = "ode", scheme: str = "rk4",
+                 model_variant: str = "ode", scheme: Optional[str] = None, window: Optional[int] = None,
+                 preset: Optional[str] = None,
                  observation_modules: Optional[Sequence[str]] = None, u_min: Optional[Sequence[float]] = None,
                  u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
-        scheme / n_sub: "rk4" (RK4 with the cover conduction integrated exactly, default n_sub 240), "rk3" (three-stage third-order scheme, same exact conduction, 270) or "rk2" (midpoint rule, same exact conduction, 336);
+        scheme / n_sub / window: "ls5" (default: five-stage fourth-order 2N-storage scheme, n_sub 120, two sub-steps per tier-2b window), "rk4" (classical RK4, 240),
+        "rk3" (three-stage third-order scheme, 270) or "rk2" (midpoint rule, 336), all with the cover conduction integrated exactly (include/glgym.h).
+        preset: "throughput" (the counts above; default for float32) or "parity" (inside the band of the reference solver's tolerances:
+        ls5 n_sub 192 with one sub-step per window; default for float64) -- used for whatever of n_sub / window is not given (_lib.PRESETS);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
@@ -198,10 +202,16 @@ class TomatoVecEnv:
         self.obs_dim = sum(m.n_obs for m in self.observation_modules)
         self.f64 = str(dtype) in ("float64", "f64", "double")
         self.tdtype = torch.float64 if self.f64 else torch.float32
+        scheme = L.DEFAULT_SCHEME if scheme is None else scheme
         if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'rk4', 'rk3' or 'rk2'")
+            raise ValueError("scheme must be 'ls5', 'rk4', 'rk3' or 'rk2'")
+        self.preset = ("parity" if self.f64 else "throughput") if preset is None else preset
+        if self.preset not in L.PRESETS:
+            raise ValueError("preset must be 'throughput' or 'parity'")
         self.scheme = scheme
-        self.n_sub = int(L.default_n_sub(scheme, self.dt) if n_sub is None else n_sub)
+        n_def, w_def = L.preset_n_sub(scheme, self.dt, self.preset)
+        self.n_sub = int(n_def if n_sub is None else n_sub)
+        self.window = int((w_def if n_sub is None else 0) if window is None else window)      # 0 = the scheme's own
         self.uncertainty_scale = float(uncertainty_scale)
         self.auto_reset = auto_reset
         self.lazy_infos = (int(num_envs) > 4096) if lazy_infos is None else bool(lazy_infos)
@@ -216,6 +226,7 @@ class TomatoVecEnv:
         if model_variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
+        L.check(self._lib.glgym_set_window(self._h, self.window), "glgym_set_window")
         self.u_min = np.asarray([0.0] * L.NU if u_min is None else u_min, dtype=np.float32)            # base_env.py:72-74
         self.u_max = np.asarray([1.0] * L.NU if u_max is None else u_max, dtype=np.float32)
         self.delta_u_max = np.ones(L.NU, dtype=np.float32) * np.float32(delta_u_max)
@@ -331,7 +342,7 @@ class TomatoVecEnv:
                                                self.uncertainty_scale, self.seed_value, self._draw, self._stream()),
                     "glgym_crop_noise")
             self._draw += 1
-        a = L.StepArgs(self.B, self.ld, self.x_T.data_ptr(), self.u_T.data_ptr(),
+        a = L.make_step_args(self.B, self.ld, self.x_T.data_ptr(), self.u_T.data_ptr(),
                        None if raw_control else getattr(self, "_action_src", self.action_t).data_ptr(),
                        self.ctrl_T.data_ptr() if raw_control else None, self.weather_t.data_ptr(), self.weather_rows,
                        self.w_off_t.data_ptr(), self.timestep_t.data_ptr(),
@@ -576,13 +587,28 @@ class TomatoVecEnv:
         replay.graph = graph
         return replay
 
-    def set_scheme(self, scheme: str, n_sub: Optional[int] = None):
-        """Switch the sub-stepper ("rk4" | "rk3" | "rk2", include/glgym.h) and its sub-step count (default: the scheme's own)."""
+    def set_scheme(self, scheme: str, n_sub: Optional[int] = None, window: Optional[int] = None):
+        """Switch the sub-stepper ("ls5" | "rk4" | "rk3" | "rk2", include/glgym.h), its sub-step count and tier-2b window (default: what
+        this env's preset gives for the scheme; with an explicit n_sub the scheme's own window)."""
         if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'rk4', 'rk3' or 'rk2'")
+            raise ValueError("scheme must be 'ls5', 'rk4', 'rk3' or 'rk2'")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
         self.scheme = scheme
-        self.set_n_sub(L.default_n_sub(scheme, self.dt) if n_sub is None else n_sub)
+        n_def, w_def = L.preset_n_sub(scheme, self.dt, self.preset)
+        self.set_n_sub(n_def if n_sub is None else n_sub)
+        self.set_window((w_def if n_sub is None else 0) if window is None else window)
+
+    def set_window(self, window: int):
+        """Nominal sub-steps per tier-2b / harvest window (glgym_set_window): 0 = the scheme's own."""
+        self.window = int(window)
+        L.check(self._lib.glgym_set_window(self._h, self.window), "glgym_set_window")
+
+    def set_layout(self, layout: str):
+        """Kernel layout of float32 steps (glgym_set_layout): "auto" | "one" (lane per environment) | "quad" (four lanes)."""
+        L.check(self._lib.glgym_set_layout(self._h, L.LAYOUTS[layout]), "glgym_set_layout")
+
+    def set_occupancy(self, waves_per_simd: int):
+        L.check(self._lib.glgym_set_occupancy(self._h, int(waves_per_simd)), "glgym_set_occupancy")
 
     def set_n_sub(self, n_sub: int):
         self.n_sub = int(n_sub)

@@ -95,8 +95,19 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     conduction, Kutta's RK3 -- stages at 0, h/2, h -- on every other state; stability interval 2.513): use n_sub 270.  19 % fewer
  *     right-hand sides than RK4 at RK4-like accuracy (the error of both is set by the slow tier's window, not by the order); the
  *     slow sub-expressions and the harvest flow are shared by three nominal sub-steps (n_sub is rounded up to a multiple of 3).
- *     (Rounds 2-3 shipped Bogacki-Shampine 3(2) with the conduction in its right-hand side at n_sub 354 under this name.) */
-typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1, GLGYM_SCHEME_RK3 = 2 } glgym_scheme;
+ *     (Rounds 2-3 shipped Bogacki-Shampine 3(2) with the conduction in its right-hand side at n_sub 354 under this name.)
+ *   GLGYM_SCHEME_LS5 (round 5): a FIVE-stage FOURTH-order explicit Runge-Kutta scheme in Williamson's 2N-storage form (two registers per
+ *     state: dy <- A_i dy + h f(y), y <- y + B_i dy).  The 2N five-stage fourth-order family has one free parameter, the z^5 coefficient
+ *     of its stability polynomial; Carpenter-Kennedy's published member (1/200) has a real-axis stability interval of 4.657, the member
+ *     used here (0.0044) 5.4588 with |R| <= 0.5 at its working point: 1.09 per right-hand side against RK4's 0.70.  The cover conduction is
+ *     integrated exactly here too (Lawson's transformation applied to the deviation of the forcing from its value at the start of the
+ *     sub-step: exact for a frozen forcing, no stage history).  Use n_sub 120 (7.5 s sub-steps: rates up to 0.67 1/s); the slow
+ *     sub-expressions and the harvest flow are shared by TWO nominal sub-steps (15 s, the window RK4-240 runs with): 600 right-hand sides
+ *     + 60 windows per env-step where RK4 takes 960 + 60, at RK4's accuracy on every fixture (tight one-step tuples 6.1e-5, 10-day
+ *     rollout 1.5e-5 in fp64 -- the same figures as GLGYM_SCHEME_RK4 at 240).  PARITY preset: n_sub 192 with glgym_set_window(h, 1):
+ *     1.0e-5 on the tight one-step tuples, inside the 1.3e-5 band of a BDF solve at the reference's tolerances, at 960 right-hand sides
+ *     + 192 windows (RK4 needs n_sub 640: 2 560 + 160).  oracle/studies/lsrk_study.py, DESIGN.md section 2.7. */
+typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1, GLGYM_SCHEME_RK3 = 2, GLGYM_SCHEME_LS5 = 3 } glgym_scheme;
 
 /* Step-doubling VERIFIED integration: no attempt is accepted on its own -- the result is the finer of two agreeing attempts (at
  * least n_sub and 2 n_sub: 3x the work, 4e-7 median error instead of 2e-6) -- with ONE exception, in this mode and the unverified one
@@ -129,8 +140,13 @@ typedef struct {
     double co2_min, co2_max, temp_min, temp_max, rh_min, rh_max;
 } glgym_reward_cfg;
 
+/* ABI version of this header; glgym_abi_version() returns the library's.  5: glgym_step_args starts with struct_size (round 5) */
+#define GLGYM_ABI_VERSION 5
+
 /* Device-pointer arguments of one batched env-step.  Exactly one of `action` / `control` is non-null. */
 typedef struct {
+    int32_t struct_size;       /* sizeof(glgym_step_args) as the CALLER compiled it: glgym_step refuses (GLGYM_EINVAL) a struct of another
+                                  size instead of reading pointers that are not there (the struct grew by step_flags in round 4) */
     int32_t B;                 /* environments in this shard */
     int32_t ld;                /* leading dimension of every SoA array (>= B) */
     void* x;                   /* SoA [28][ld] T, in/out: state */
@@ -156,8 +172,8 @@ typedef struct {
 /* step_flags[b]: bits 0..4 = why the FIRST attempt was not accepted as it stood (0 = it was): 1 rate bound beyond 64x the nominal
  * sub-step count for more than 120 s, 2 non-finite, 4 error estimate above tolerance, 8 a wet surface changed sides inside its
  * bistable regime in a capped window, 16 it took >= 3x the nominal number of sub-steps.  Bits 8..10 = extra attempts used
- * (2x, 4x, 8x n_sub).  Bits 16..31 = sub-steps taken beyond the nominal n_sub, all attempts together (saturating).  How the returned
- * state was accepted: */
+ * (2x, 4x, 8x n_sub).  Bits 16..30 = sub-steps taken beyond the nominal n_sub, all attempts together (saturating at 32 767; bit 31 is
+ * never set, so the word is non-negative as an int32).  How the returned state was accepted: */
 #define GLGYM_SF_ACCEPT_AGREE_FLAGGED 32   /* two consecutive attempts agreed, but the accepted (finer) one carried a flag itself */
 #define GLGYM_SF_ACCEPT_LAST_ALONE 64      /* the finest attempt (8x n_sub), unflagged, taken as it stood although it did not agree
                                               with the attempt before it -- in verified mode as well */
@@ -202,6 +218,7 @@ typedef struct {
 } glgym_reset_args;
 
 const char* glgym_version(void);
+int glgym_abi_version(void);                                 /* GLGYM_ABI_VERSION the library was built with */
 const char* glgym_last_error(void);
 
 /* p: host, np doubles (the reference promotes its float32 parameter block to double before evalF). */
@@ -210,7 +227,17 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
 int glgym_destroy(glgym_handle h);
 int glgym_set_params(glgym_handle h, const double* p);
 int glgym_set_n_sub(glgym_handle h, int n_sub);
-int glgym_set_scheme(glgym_handle h, int scheme);            /* GLGYM_SCHEME_RK4 (default) | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3 */
+int glgym_set_scheme(glgym_handle h, int scheme);            /* GLGYM_SCHEME_RK4 (default) | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3 | GLGYM_SCHEME_LS5 */
+/* Nominal sub-steps per tier-2b / harvest window.  0 (default) = the scheme's own (RK4 4, RK2 4, RK3 3, LS5 2); 1..8 overrides it at run
+ * time (n_sub is rounded up to a multiple).  The window's length in seconds is what sets the accuracy at a given n_sub. */
+int glgym_set_window(glgym_handle h, int window);
+/* Kernel layout of glgym_step for GLGYM_F32 handles (GLGYM_F64 has one layout).  Initial value: environment variable GLGYM_LAYOUT =
+ * one | quad read ONCE at glgym_create (A/B tools), else AUTO. */
+typedef enum { GLGYM_LAYOUT_AUTO = 0, GLGYM_LAYOUT_ONE = 1, GLGYM_LAYOUT_QUAD = 2 } glgym_layout;
+int glgym_set_layout(glgym_handle h, int layout);
+/* Waves per SIMD the one-lane fp32 step kernel is built for: 1 (default; up to 512 registers, no scratch) or 2 (256 registers, the rest
+ * in scratch; measured slower at every batch size, on request only).  Initial value: GLGYM_OCC = 1 | 2 read once at glgym_create. */
+int glgym_set_occupancy(glgym_handle h, int waves_per_simd);
 int glgym_set_verify(glgym_handle h, int mode);              /* GLGYM_VERIFY_AUTO (default) | _ALWAYS | _NEVER */
 /* action_to_control (tomato_env.py:109-113): u = clip(u_prev + action * delta_u_max, u_min, u_max), held in float32 like
  * base_env.py:72-74.  Default: the yml's [0, 1] bounds and 0.1 (configs/envs/TomatoEnv.yml:12-14).  The `control` input
@@ -242,9 +269,9 @@ int glgym_obs_dim(glgym_handle h, int Np);
 /* Device pointers; asynchronous on `stream` (a hipStream_t, NULL = default stream).
  * glgym_step picks its kernel layout per launch.  GLGYM_F64: four lanes per environment (csrc/gl_model_quad.hpp) in every scheme,
  * ODE variant and batch size -- the only fp64 integrator on the device.  GLGYM_F32: four lanes per environment for B <= 16 384 with
- * shared crop parameters and the default ODE (every scheme), one lane per environment otherwise; environment variable
- * GLGYM_LAYOUT = one | quad overrides that choice (fp32 only; read per launch).  Same scheme decision for decision in both layouts,
- * results equal to rounding. */
+ * shared crop parameters and the default ODE (every scheme), one lane per environment otherwise; glgym_set_layout overrides that choice
+ * (fp32 only).  Same scheme decision for decision in both layouts; results equal to fp32 rounding accumulated over the sub-steps
+ * (measured on the storm / jump fixtures: <= 2.5e-4 scaled between the two fp32 layouts, tests/test_gpu_storm.py). */
 int glgym_step(glgym_handle h, const glgym_step_args* a, void* stream);
 int glgym_obs(glgym_handle h, const glgym_obs_args* a, void* stream);
 int glgym_reset(glgym_handle h, const glgym_reset_args* a, void* stream);

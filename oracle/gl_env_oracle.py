@@ -157,6 +157,8 @@ class OracleTomatoEnv:
         if self.integrator == "rk4":            # the kernels' scheme: stability-controlled RK4, Strang-split exact harvest
             # flow, tier 2b once per window of four sub-steps, guard retries
             return O.rk_sc_guarded(x, u, d, p, self.dt, self.n_sub, 4, getattr(self, "window", 4))[0]
+        if self.integrator == "ls5":            # the kernels' five-stage fourth-order 2N scheme (gl_oracle.c ls5_substep), window 2
+            return O.rk_sc_guarded(x, u, d, p, self.dt, self.n_sub, 5, getattr(self, "window", 2))[0]
         if self.integrator == "rk4_plain":      # classical RK4 of the complete RHS
             return O.rk4(x, u, d, p, self.dt, self.n_sub)
         if self.integrator == "stiff":

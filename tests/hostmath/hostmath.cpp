@@ -40,7 +40,7 @@ static void run(const double* x, const double* u, const double* d, const double*
     for (int i = 0; i < NX; ++i) out[i] = (double)x0[i] + (double)del[i];
 }
 
-// other integrator settings of rk_delta<T, PIPE, ORDER, WIN>: (order, window) in {(4,1), (4,2), (4,3), (4,4), (2,1), (2,2), (2,4), (3,1), (3,3), (3,4)}
+// other integrator settings of rk_delta<T, PIPE, ORDER, WIN>: (order, window) in {(4,1), (4,2), (4,3), (4,4), (2,1), (2,2), (2,4), (3,1), (3,3), (3,4), (5,1), (5,2)}
 template <class T, int ORDER, int WIN>
 static void run_scheme(const double* x, const double* u, const double* d, const double* p, double dt, int n_sub, double* out,
                        double* stats)
@@ -125,7 +125,7 @@ int hostmath_step_scheme(const double* x, const double* u, const double* d, cons
         else run_scheme<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats);              \
         return 0;                                                                         \
     }
-    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 3) GL_CASE(4, 4) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4) GL_CASE(3, 1) GL_CASE(3, 3) GL_CASE(3, 4)
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 3) GL_CASE(4, 4) GL_CASE(2, 1) GL_CASE(2, 2) GL_CASE(2, 4) GL_CASE(3, 1) GL_CASE(3, 3) GL_CASE(3, 4) GL_CASE(5, 1) GL_CASE(5, 2)
 #undef GL_CASE
     return -1;
 }
@@ -136,7 +136,7 @@ int hostmath_step_guarded2(const double* x, const double* u, const double* d, co
     if (order == O && win == W)                                                                  \
         return f32 ? run_guarded<float, O, W>(x, u, d, p, dt, n_sub, x_next, stats, verify)      \
                    : run_guarded<double, O, W>(x, u, d, p, dt, n_sub, x_next, stats, verify);
-    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 3) GL_CASE(4, 4) GL_CASE(2, 4) GL_CASE(3, 3) GL_CASE(3, 4)
+    GL_CASE(4, 1) GL_CASE(4, 2) GL_CASE(4, 3) GL_CASE(4, 4) GL_CASE(2, 4) GL_CASE(3, 3) GL_CASE(3, 4) GL_CASE(5, 1) GL_CASE(5, 2)
 #undef GL_CASE
     return -1;
 }

@@ -32,7 +32,10 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_header_sizes(lib):
     # 4-byte ints followed by 8-byte pointers: ctypes applies the same natural alignment as the C compiler
     assert C.sizeof(lib.RewardCfg) == 16 * 8
-    assert C.sizeof(lib.StepArgs) == 8 + 8 * 5 + 8 + 8 * 3 + 8 + 8 * 5            # ... + step_flags (round 4)
+    assert C.sizeof(lib.StepArgs) == 8 + 8 + 8 * 5 + 8 + 8 * 3 + 8 + 8 * 5        # struct_size, B | ld | ... + step_flags (ABI 5)
+    assert lib.StepArgs._fields_[0][0] == "struct_size" and lib.make_step_args(1, 2).struct_size == C.sizeof(lib.StepArgs)
+    hdr = (ROOT / "include" / "glgym.h").read_text()
+    assert int(re.search(r"#define GLGYM_ABI_VERSION (\d+)", hdr).group(1)) == lib.ABI_VERSION == lib.load().glgym_abi_version()
     assert C.sizeof(lib.ObsArgs) == 8 + 8 * 3 + 8 + 8 * 3 + 8 + 8 + 8 + 8
     assert C.sizeof(lib.ResetArgs) == 8 + 8 * 5 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
@@ -76,27 +79,36 @@ def test_default_constant_image_is_current(tmp_path):
     assert out == (csrc / "gl_default_const.inc").read_text()
 
 
-def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
-    """ISA regression (SURVEY 8d): the hot fp32 kernels must stay MFMA-free, scratch-free and free of SGPR-spill
-    reloads (v_readlane) in the specialised variant.  hipcc cross-compiles here without a GPU."""
-    import re
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """The device assembly of glgym.hip with the optimisation flags of csrc/Makefile (OPT), cross-compiled ONCE for the ISA tests
+    below (no GPU needed; about a minute)."""
     import shutil
     import subprocess
     if shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
         pytest.skip("hipcc not available")
     csrc = ROOT / "greenlight-gym2_amd" / "csrc"
-    out = tmp_path / "glgym.s"
-    # the optimisation flags of csrc/Makefile (OPT)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize",
-                           "--offload-arch=gfx950", "-std=c++17",
+    out = tmp_path_factory.mktemp("isa") / "glgym.s"
+    opt = (csrc / "Makefile").read_text().split("OPT =")[1].split("\n")[0].split()
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + opt + ["--offload-arch=gfx950", "-std=c++17",
                            f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(csrc / "glgym.hip")])
-    s = out.read_text()
+    return out.read_text()
+
+
+def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(device_asm):
+    """ISA regression (SURVEY 8d): the hot fp32 kernels must stay MFMA-free, scratch-free and free of SGPR-spill
+    reloads (v_readlane) in the specialised variant.  hipcc cross-compiles here without a GPU."""
+    import re
+    s = device_asm
     assert "v_mfma" not in s
     # <T, PER_ENV_CROP, DEFAULT_P, PIPE, SCH, OCC>: the one-wave-per-SIMD builds (OCC = 1) of the classical-RK4 kernels (SCH 0) and
     # the default-parameter Bogacki-Shampine kernel (SCH 2); the
     # OCC = 2 build is limited to 256 registers on purpose and spills to scratch (DESIGN.md section 5)
+    # (round 5: plus the five-stage 2N scheme, SCH 3 -- the default -- with the default block, handle parameters and per-env crop blocks)
     for variant, allow_readlane in (("step_kernelIfLb0ELb1ELb0ELi0ELi1E", False), ("step_kernelIfLb0ELb0ELb0ELi0ELi1E", True),
-                                    ("step_kernelIfLb1ELb1ELb0ELi0ELi1E", False), ("step_kernelIfLb0ELb1ELb0ELi2ELi1E", False)):
+                                    ("step_kernelIfLb1ELb1ELb0ELi0ELi1E", False), ("step_kernelIfLb0ELb1ELb0ELi2ELi1E", False),
+                                    ("step_kernelIfLb0ELb1ELb0ELi3ELi1E", False), ("step_kernelIfLb0ELb0ELb0ELi3ELi1E", True),
+                                    ("step_kernelIfLb1ELb1ELb0ELi3ELi1E", False)):
         m = re.search(r"^(_ZN\S*" + variant + r"\S*):", s, flags=re.M)
         body = s[m.start():]
         body = body[:body.index(".Lfunc_end")]
@@ -120,27 +132,19 @@ def test_fp32_step_kernel_isa_has_no_mfma_no_scratch_no_spill_reloads(tmp_path):
             assert body.count("v_readlane_b32") < 32, (variant, body.count("v_readlane_b32"))
 
 
-def test_quad_kernel_isa_keeps_its_spill_free_inner_loops(tmp_path):
+def test_quad_kernel_isa_keeps_its_spill_free_inner_loops(device_asm):
     """ISA regression for the four-lanes-per-environment kernels, every shipped variant: the fp64 builds sit close to
     the 512-register limit and hipcc 7.2's spill code has produced wrong fp64 results on this kernel before.
     fp32: no scratch at all.  fp64 (coefficient blocks in LDS): at most 256 bytes of private segment reserved, none of it touched inside the sub-step
     loops (window-level bookkeeping at most; the shipped builds contain no scratch instruction at all), no out-of-line call, and the quad_perm DPP moves stay 32-bit -- gfx950 implements 64-bit
     DPP for row_newbcast only."""
     import re
-    import shutil
-    import subprocess
-    if shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
-        pytest.skip("hipcc not available")
     csrc = ROOT / "greenlight-gym2_amd" / "csrc"
-    out = tmp_path / "glgym.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize",
-                           "--offload-arch=gfx950", "-std=c++17",
-                           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(csrc / "glgym.hip")])
-    s = out.read_text()
+    s = device_asm
     names = re.findall(r"^(_ZN\S*(?:step_kernel_quad|evalf_kernel_quad)I[fd]\S*):", s, flags=re.M)
-    # every scheme (SCH 0 / 1 / 2) of both kernels in fp64, with and without per-env crop blocks (ODE_pipe is a run-time selection
-    # inside them); fp32: three schemes x default / handle parameters
-    assert len([n for n in names if "quadId" in n]) == 12 and len([n for n in names if "quadIf" in n]) == 6, names
+    # every scheme (SCH 0 / 1 / 2 / 3) of both kernels in fp64, with and without per-env crop blocks (ODE_pipe is a run-time selection
+    # inside them); fp32: four schemes x default / handle parameters
+    assert len([n for n in names if "quadId" in n]) == 16 and len([n for n in names if "quadIf" in n]) == 8, names
     # round 4: the only fp64 integrator on the device is this layout (no one-lane fp64 kernels, hence no LDS mailbox); fp64 builds
     # with the default block compiled in are not instantiated (0.7 % for six more kernels), and the Makefile must not bring back the
     # scheduler flag under which they -- and a separate ODE_pipe build -- came out wrong
@@ -176,11 +180,18 @@ def test_scheme_table_and_default_sub_step_counts():
     import re
     from gl_gym_amd import _lib as L
     hdr = (ROOT / "include" / "glgym.h").read_text()
-    enum = dict((k, int(v)) for k, v in re.findall(r"(GLGYM_SCHEME_RK\d) = (\d)", hdr))
-    assert enum == {"GLGYM_SCHEME_RK4": L.SCHEMES["rk4"], "GLGYM_SCHEME_RK2": L.SCHEMES["rk2"], "GLGYM_SCHEME_RK3": L.SCHEMES["rk3"]}
-    assert [L.default_n_sub(s, 900.0) for s in ("rk4", "rk3", "rk2")] == [240, 270, 336]
-    assert [L.default_n_sub(s, 300.0) for s in ("rk4", "rk3", "rk2")] == [80, 90, 112]
-    assert [L.default_n_sub(s, 1800.0) for s in ("rk4", "rk3", "rk2")] == [480, 540, 672]
-    assert L.default_n_sub("rk3", 1.0) == 3 and L.default_n_sub("rk4", 1.0) == 4
+    enum = dict((k, int(v)) for k, v in re.findall(r"(GLGYM_SCHEME_[A-Z0-9]+) = (\d)", hdr))
+    assert enum == {"GLGYM_SCHEME_RK4": L.SCHEMES["rk4"], "GLGYM_SCHEME_RK2": L.SCHEMES["rk2"], "GLGYM_SCHEME_RK3": L.SCHEMES["rk3"],
+                    "GLGYM_SCHEME_LS5": L.SCHEMES["ls5"]}
+    assert L.DEFAULT_SCHEME == "ls5"
+    assert [L.default_n_sub(s, 900.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [120, 240, 270, 336]
+    assert [L.default_n_sub(s, 300.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [40, 80, 90, 112]
+    assert [L.default_n_sub(s, 1800.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [240, 480, 540, 672]
+    assert L.default_n_sub("rk3", 1.0) == 3 and L.default_n_sub("rk4", 1.0) == 4 and L.default_n_sub("ls5", 1.0) == 2
+    # the parity preset: ls5 with ONE sub-step per window; the others keep their window and take 8/3 of the nominal count
+    assert L.preset_n_sub("ls5", 900.0, "parity") == (192, 1) and L.preset_n_sub("rk4", 900.0, "parity") == (640, 0)
+    assert L.preset_n_sub("ls5", 300.0, "parity") == (64, 1) and L.preset_n_sub("ls5", 900.0, "throughput") == (120, 0)
+    layouts = dict((k, int(v)) for k, v in re.findall(r"GLGYM_LAYOUT_([A-Z]+) = (\d)", hdr))
+    assert layouts == {k.upper(): v for k, v in L.LAYOUTS.items()}
     assert int(re.search(r"#define GLGYM_METRIC_REPLICAS (\d+)", hdr).group(1)) == L.METRIC_REPLICAS
     assert int(re.search(r"#define GLGYM_METRIC_STRIDE (\d+)", hdr).group(1)) == L.METRIC_STRIDE >= L.NMETRIC

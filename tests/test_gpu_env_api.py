@@ -248,7 +248,7 @@ def test_c_abi_rejects_bad_arguments_and_handles_ragged_batches(golden):
                   timestep=env.timestep_t.data_ptr(), crop_p=None, N=env.N, reward=env.reward_t.data_ptr(),
                   info=env.info_T.data_ptr(), done=env.done_t.data_ptr(), metrics=None, step_flags=None)
         kw.update(over)
-        return L.StepArgs(*[kw[f[0]] for f in L.StepArgs._fields_])
+        return L.make_step_args(*[kw[f[0]] for f in L.StepArgs._fields_[1:]])
 
     x_before = env.x_T.clone()
     for bad in (dict(B=0), dict(B=-3), dict(ld=64), dict(x=None), dict(action=None), dict(control=env.ctrl_T.data_ptr()),
@@ -256,6 +256,10 @@ def test_c_abi_rejects_bad_arguments_and_handles_ragged_batches(golden):
         assert lib.glgym_step(h, C.byref(step_args(**bad)), st) == L.EINVAL, bad
         assert b"glgym_step" in lib.glgym_last_error()
     assert lib.glgym_step(None, C.byref(step_args()), st) == L.EINVAL
+    # a caller built against an older header (a shorter struct: no step_flags) is refused before any pointer is read (ABI 5)
+    old = step_args()
+    old.struct_size = C.sizeof(L.StepArgs) - 8
+    assert lib.glgym_step(h, C.byref(old), st) == L.EINVAL and b"struct_size" in lib.glgym_last_error()
     torch.cuda.synchronize()
     assert torch.equal(env.x_T, x_before)                        # nothing was launched
     oa = L.ObsArgs(env.B, env.ld, env.x_T.data_ptr(), env.u_T.data_ptr(), env.weather_t.data_ptr(), env.weather_rows,

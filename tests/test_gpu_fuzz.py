@@ -35,7 +35,7 @@ def _tuples(n, golden):
     return map(np.array, (X, U, D, P))
 
 
-@pytest.mark.parametrize("scheme,order,win64,win32,n_sub", [("rk4", 4, 4, 4, 256), ("rk2", 2, 4, 4, 360), ("rk3", 3, 3, 3, 282)])
+@pytest.mark.parametrize("scheme,order,win64,win32,n_sub", [("ls5", 5, 2, 2, 128), ("rk4", 4, 4, 4, 256), ("rk2", 2, 4, 4, 360), ("rk3", 3, 3, 3, 282)])
 def test_random_tuples_against_oracle_scheme(golden, oracle, scheme, order, win64, win32, n_sub):
     from gl_gym_amd import GreenLight
     N = 400

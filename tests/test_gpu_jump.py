@@ -13,7 +13,7 @@ from test_jump_fixture import judge, sce
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("rk4", 240), ("rk3", 270), ("rk2", 336)]
+SCHEMES = [("ls5", 120), ("rk4", 240), ("rk3", 270), ("rk2", 336)]
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -70,8 +70,8 @@ def test_unverified_mode_flags_what_round_2_missed(golden):
     from gl_gym_amd import GreenLight
     from gl_gym_amd._lib import GlgymOdeError
     g = golden("step_tight_jump")
-    for dtype in ("float64", "float32"):
-        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=240)
+    for dtype, scheme, n_sub in (("float64", "ls5", 120), ("float32", "ls5", 120), ("float64", "rk4", 240), ("float32", "rk4", 240)):
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
         m.set_verify("never")
         for i in (0, 1):
             try:
@@ -79,5 +79,5 @@ def test_unverified_mode_flags_what_round_2_missed(golden):
             except GlgymOdeError:
                 continue
             wrong, floor = judge(got, g["X_tight"][i:i + 1], 2e-4)
-            assert wrong == 0, (dtype, i, sce(got[0], g["X_tight"][i]).max())
+            assert wrong == 0, (dtype, scheme, i, sce(got[0], g["X_tight"][i]).max())
         m.close()

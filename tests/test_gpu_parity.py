@@ -32,8 +32,8 @@ def _scheme_arithmetic_not_the_verified_ladder():
 @pytest.fixture(scope="module")
 def models():
     from gl_gym_amd import GreenLight
-    m64 = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=256)      # the oracle references below use 256
-    m32 = GreenLight(28, 6, 10, 208, 900.0, dtype="float32", n_sub=256)
+    m64 = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme="rk4", n_sub=256)      # the oracle references below use RK4 at 256
+    m32 = GreenLight(28, 6, 10, 208, 900.0, dtype="float32", scheme="rk4", n_sub=256)
     yield m64, m32
     m64.close(); m32.close()
 
@@ -71,17 +71,31 @@ def test_evalF_signature_and_value(models, golden, oracle):
     rest = np.array([i for i in range(len(X)) if i != 61])
     assert scaled_err(got64[rest], XT[rest]) < 2.5e-5
     from gl_gym_amd import GreenLight
-    m_def = GreenLight(28, 6, 10, 208, 900.0, dtype="float64")
-    assert m_def.n_sub == 240
+    e_bdf = scaled_err(g["X_bdf1e6"], XT)          # a BDF solve at the reference's tolerances (rtol = atol = 1e-6) on the same tuples: 1.3e-5
+    # --- the reference-compatible class as a maintainer gets it (no keyword): the PARITY preset -- the five-stage 2N scheme at n_sub 192
+    # with one sub-step per tier-2b window -- must sit INSIDE the band the reference solver's tolerances keep from the tight solution
+    m_def = GreenLight(28, 6, 10, 208, 900.0)
+    assert (m_def.scheme, m_def.n_sub, m_def.window, m_def.preset) == ("ls5", 192, 1, "parity")
     e_def = scaled_err(m_def.evalF_batch(X, U, D, P), XT)
     m_def.close()
-    print(f"fp64 RK4 vs tight one-step solutions: n_sub 256 {scaled_err(got64[ok], XT[ok]):.2e}, default 240 {e_def:.2e}")
-    assert e_def < 6.3e-5
-    # the PARITY configuration (include/glgym.h): n_sub 640 sits inside the 1.3e-5 band of a BDF solve at the reference's tolerances
-    m_par = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=640)
+    print(f"fp64 vs tight one-step solutions: RK4 n_sub 256 {scaled_err(got64[ok], XT[ok]):.2e}; GreenLight() default = ls5 parity preset {e_def:.2e} "
+          f"(BDF rtol = atol = 1e-6: {e_bdf:.2e})")
+    assert e_def < 1.3e-5 and e_def <= e_bdf
+    # --- the THROUGHPUT preset of both fourth-order schemes (what the batched envs and bench.py's `value` run): inside the 1e-4 bar with
+    # the one artificial tuple at 6.1e-5, every other tuple well below
+    for scheme, n_expect, rest_tol in (("ls5", 120, 4.0e-5), ("rk4", 240, 2.5e-5)):
+        m_thr = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme, preset="throughput")
+        assert m_thr.n_sub == n_expect and m_thr.window == 0
+        got = m_thr.evalF_batch(X, U, D, P)
+        m_thr.close()
+        print(f"fp64 {scheme} throughput preset n_sub {n_expect}: {scaled_err(got, XT):.2e}, without tuple 61 {scaled_err(got[rest], XT[rest]):.2e}")
+        assert scaled_err(got, XT) < 6.3e-5 and scaled_err(got[rest], XT[rest]) < rest_tol
+    # --- the parity configuration of classical RK4 (include/glgym.h): n_sub 640
+    m_par = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme="rk4")
+    assert m_par.n_sub == 640
     e_par = scaled_err(m_par.evalF_batch(X, U, D, P), XT)
     m_par.close()
-    print(f"fp64 RK4 parity configuration n_sub 640: {e_par:.2e} (BDF rtol = atol = 1e-6 on the same tuples: {scaled_err(g['X_bdf1e6'], XT):.2e})")
+    print(f"fp64 RK4 parity configuration n_sub 640: {e_par:.2e}")
     assert e_par < 1.3e-5
     # batched call with per-row crop parameters == row-by-row calls
     got_b = m64.evalF_batch(X[:16], U[:16], D[:16], P[:16])
@@ -97,7 +111,7 @@ def test_n_sub_4_is_refined_to_what_the_ode_needs_or_flagged(golden, oracle):
     Never a non-finite or silently wild state."""
     from gl_gym_amd.tomato_env import TomatoVecEnv
     w = golden("rollout_10day")["weather"]
-    env = TomatoVecEnv(64, weather=w, dtype="float32", n_sub=4, season_length=1, auto_reset=False)
+    env = TomatoVecEnv(64, weather=w, dtype="float32", scheme="rk4", n_sub=4, season_length=1, auto_reset=False)
     env.reset()
     x_before = env.x.double().cpu().numpy().copy()
     obs, r, done, info = env.step(np.zeros((64, 6), np.float32))
@@ -117,11 +131,12 @@ def test_n_sub_4_is_refined_to_what_the_ode_needs_or_flagged(golden, oracle):
     env.close()
 
 
-@pytest.mark.parametrize("scheme", ["rk4", "rk2", "rk3"])
+@pytest.mark.parametrize("scheme,preset", [("ls5", "throughput"), ("ls5", "parity"), ("rk4", "throughput"), ("rk4", "parity"), ("rk2", "throughput"),
+                                           ("rk3", "throughput")])
 @pytest.mark.parametrize("fixture,dtype,tol", [("rollout_10day", "float64", 5e-6), ("rollout_10day", "float32", 1e-4),
                                                ("rollout_3day_synth", "float64", 5e-6),
                                                ("rollout_3day_synth", "float32", 1e-4)])
-def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme):
+def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme, preset):
     """The headline accuracy bar: step() with the fixture's action sequence vs the tight (Radau 1e-11) states.
     rollout_10day: 961 steps on Bleiswijk autumn weather; rollout_3day_synth: 289 steps on midsummer-like synthetic
     weather (670 W/m2 peaks, strong photosynthesis and ventilation, air temperature 6..28 C)."""
@@ -131,10 +146,13 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme):
     B = 64                                    # 64 identical envs: also checks lane-independence
     n_steps = len(acts)
     if dtype == "float64":
-        # the midpoint rule at n_sub = 336: second order, 7.6e-6 / 9.6e-6 in fp64; RK4 at its round-4 nominal count of 240
-        # (3.75 s sub-steps, 15 s tier-2b windows): 1.5e-5 / 1.4e-5; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6
-        tol = 2e-5 if scheme == "rk4" else 1e-5
-    env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
+        # THROUGHPUT presets: the midpoint rule at n_sub = 336: second order, 7.6e-6 / 9.6e-6 in fp64; RK4 at 240 and the five-stage 2N
+        # scheme at 120 (both 15 s tier-2b windows): 1.5e-5 / 1.4e-5; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6.
+        # PARITY presets (ls5 192 / one-sub-step windows: 2.9e-6 / 2.7e-6; rk4 640): the round-3 bound of 5e-6 stays asserted
+        tol = 5e-6 if preset == "parity" else (2e-5 if scheme in ("rk4", "ls5") else 1e-5)
+    elif preset == "parity":
+        tol = 4e-5                            # fp32 at the parity presets: rounding, not the scheme, sets it (2.5e-5 measured)
+    env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, preset=preset, season_length=(n_steps - 1) // 96, pred_horizon=0.5,
                        auto_reset=False)
     env.reset()
     import torch
@@ -146,7 +164,7 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme):
     X = np.array(X)
     assert np.array_equal(env.x[0].cpu().numpy(), env.x[B - 1].cpu().numpy())
     err = scaled_err(X, XR)
-    print(f"{fixture} {dtype} {scheme} (n_sub {env.n_sub}): max scaled rel err vs tight oracle = {err:.3e}")
+    print(f"{fixture} {dtype} {scheme} {preset} (n_sub {env.n_sub}, window {env.window or 'scheme'}): max scaled rel err vs tight oracle = {err:.3e}")
     assert err < tol
     assert not bool(done[0]) or k == n_steps - 1        # no failed integration on the way (done only at the season's end)
     env.close()
@@ -175,26 +193,27 @@ def test_config3_shard_10day_horizon_at_full_batch(golden):
     x = env.x
     assert bool((x == x[0:1]).all())
     m = env.metrics()
-    print(f"config 3 shard: 65 536 envs x {n_steps} steps (10 days), fp32 RK4 n_sub {env.n_sub}: max scaled err vs tight fixture {worst:.2e}; "
+    print(f"config 3 shard: 65 536 envs x {n_steps} steps (10 days), fp32 {env.scheme} n_sub {env.n_sub}: max scaled err vs tight fixture {worst:.2e}; "
           f"failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}")
     assert worst < 1e-4 and m["n_ode_fail"] == 0
     env.close()
 
 
-def test_step_kernel_matches_env_oracle(golden, oracle):
-    """Fused step (control clip, weather row, RK4, reward, info, terminal test) vs the numpy env oracle."""
+@pytest.mark.parametrize("scheme,n_sub", [("ls5", 120), ("rk4", 256)])
+def test_step_kernel_matches_env_oracle(golden, oracle, scheme, n_sub):
+    """Fused step (control clip, weather row, sub-stepper, reward, info, terminal test) vs the numpy env oracle."""
     from gl_gym_amd.tomato_env import TomatoVecEnv
     from oracle.gl_env_oracle import OracleTomatoEnv, INFO_KEYS
     w = golden("rollout_10day")["weather"]
     B = 96
-    env = TomatoVecEnv(B, weather=w, dtype="float64", n_sub=256, season_length=0.05, start_rows=[0, 40, 300],
+    env = TomatoVecEnv(B, weather=w, dtype="float64", scheme=scheme, n_sub=n_sub, season_length=0.05, start_rows=[0, 40, 300],
                        start_days=[0.0, 0.4167, 3.125], seed=5, auto_reset=False)
     obs0 = env.reset()
     w_off = env.w_off_t.cpu().numpy(); sd = env.start_day_t.cpu().numpy()
     rng = np.random.default_rng(1)
     orcs = []
     for b in range(0, B, 6):
-        o = OracleTomatoEnv(weather=w[w_off[b]:], p=env.p, season_length=0.05, integrator="rk4", n_sub=256,
+        o = OracleTomatoEnv(weather=w[w_off[b]:], p=env.p, season_length=0.05, integrator=scheme, n_sub=n_sub,
                             train_years=[0], train_days=[float(sd[b])], seed=0)
         ob = o.reset()
         assert np.allclose(ob, obs0[b], rtol=2e-6, atol=1e-6)
@@ -261,8 +280,9 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
     p[165] = 0.5                              # grow pipes radiate
     p[194], p[195], p[198] = 0.02, 0.8, 1.5   # interlight geometry present (their power stays 0)
     p[8] = 1.2                                # etaRoofThr > 1 -> the "else" ventilation branch
-    for dtype, tol in (("float64", 1e-8), ("float32", 5e-5)):
-        env = TomatoVecEnv(64, weather=w, params=p.astype(np.float32), dtype=dtype, n_sub=256, season_length=1,
+    for dtype, tol, scheme, n_sub, order, win in (("float64", 1e-8, "rk4", 256, 4, 4), ("float32", 5e-5, "rk4", 256, 4, 4),
+                                                  ("float64", 1e-8, "ls5", 120, 5, 2), ("float32", 5e-5, "ls5", 120, 5, 2)):
+        env = TomatoVecEnv(64, weather=w, params=p.astype(np.float32), dtype=dtype, scheme=scheme, n_sub=n_sub, season_length=1,
                            start_rows=[0, 50], seed=2, auto_reset=False)
         p32 = env.p.astype(np.float64)
         env.reset()
@@ -276,8 +296,8 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
             xg = env.x.double().cpu().numpy()
             for b in range(0, 64, 9):
                 u = np.clip(u_prev[b] + acts[b] * np.float32(0.1), 0, 1)
-                ref = oracle.rk_sc_guarded(x_prev[b], u, w[w_off[b] + k], p32, 900.0, 256, 4, 4)[0]
-                assert scaled_err(xg[b], ref) < tol, (dtype, k, b)
+                ref = oracle.rk_sc_guarded(x_prev[b], u, w[w_off[b] + k], p32, 900.0, n_sub, order, win)[0]
+                assert scaled_err(xg[b], ref) < tol, (dtype, scheme, k, b)
         env.close()
 
 
@@ -297,8 +317,13 @@ def test_config1_rule_based_day_against_fixture(golden):
     X, R, U, INFO, OBS = g["x"], g["reward"], g["u"], g["info"], g["obs"]
     keys = [str(k) for k in g["info_keys"]]
     ctrl = RuleBasedController()
-    for n_sub, tol in ((1024, 4e-6), (256, 8e-5)):       # 1024: tier-2b windows of 3.5 s (four sub-steps)
-        env = TomatoVecEnv(8, weather=g["weather"], params=g["p"], dtype="float64", n_sub=n_sub, season_length=1,
+    # (this module integrates UNVERIFIED, see the fixture at its top: the error is that of ONE attempt and is set by the tier-2b
+    # window's length in seconds whatever the scheme -- CPU checker, same tuples: 3.5 s 3.2e-6, 1.76 s 7.9e-7, 4.7 s 5.6e-6, 15 s 5.8e-5)
+    #   ls5 512 / window 1 (1.76 s)  the round-3 bound of 1e-6 for this day stays asserted
+    #   rk4 1024 (window 4 = 3.5 s)  also checks info and observations of every step against the fixture
+    #   ls5 parity preset (192 / 1)  and throughput preset (120 / 2), rk4 256
+    for scheme, n_sub, window, tol in (("ls5", 512, 1, 1e-6), ("rk4", 1024, 0, 4e-6), ("ls5", 192, 1, 7e-6), ("ls5", 120, 0, 8e-5), ("rk4", 256, 0, 8e-5)):
+        env = TomatoVecEnv(8, weather=g["weather"], params=g["p"], dtype="float64", scheme=scheme, n_sub=n_sub, window=window, season_length=1,
                            start_rows=[0], start_days=[0.0], auto_reset=False)
         obs = env.reset()
         np.testing.assert_allclose(obs[0], OBS[0], rtol=1e-6, atol=1e-5)
@@ -313,11 +338,11 @@ def test_config1_rule_based_day_against_fixture(golden):
             worst_x = max(worst_x, float(np.max(np.abs(env.x[0].cpu().numpy() - X[k + 1]) / sc)))
             worst_r = max(worst_r, abs(float(rew[0]) - R[k]))
             assert bool(done[0]) == (k == 96)                      # episode = N + 1 = 97 steps
-            if n_sub == 512:
+            if tol <= 4e-6:                                        # the tight configurations: info and observations of every step too
                 for j, key in enumerate(keys):
                     assert abs(info[INFO_KEYS.index(key), 0] - INFO[k][j]) < 5e-6 * max(1.0, abs(INFO[k][j])), key
                 np.testing.assert_allclose(obs[0], OBS[k + 1], rtol=2e-6, atol=2e-5)
-        print(f"config 1, n_sub={n_sub}: one-step state err {worst_x:.2e}, |d reward| {worst_r:.2e}, |d u| {worst_u:.2e}")
+        print(f"config 1, {scheme} n_sub={n_sub} window {window or 'scheme'}: one-step state err {worst_x:.2e}, |d reward| {worst_r:.2e}, |d u| {worst_u:.2e}")
         assert worst_u < 1e-9 and worst_x < tol and worst_r < 20 * tol
         env.close()
 
@@ -330,7 +355,7 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
     from gl_gym_amd.tomato_env import TomatoVecEnv
     w = golden("rollout_10day")["weather"]
     B = 96
-    env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=256, season_length=1, uncertainty_scale=0.2, seed=4242,
+    env = TomatoVecEnv(B, weather=w, dtype="float32", scheme="rk4", n_sub=256, season_length=1, uncertainty_scale=0.2, seed=4242,
                        auto_reset=False)
     env.reset()
     rng = np.random.default_rng(3)
@@ -368,7 +393,7 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
 
 
 def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
-    """BASELINE config 5 at ITS size (B = 65 536, fp32, the shipped scheme: RK4 n_sub 240 with stability control, guard and
+    """BASELINE config 5 at ITS size (B = 65 536, fp32, the shipped default scheme: the five-stage 2N scheme at n_sub 120 with stability control, guard and
     per-env crop blocks re-drawn every step): properties that do not depend on the size -- every drawn block within +-10 %
     (p144 derived), no failed integration over 40 steps, finite states, physical leaf mass -- and 24 environments picked across
     the batch checked for one step against the oracle's restatement of the SAME controlled scheme fed their 208-vectors."""
@@ -377,7 +402,7 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     w = golden("rollout_10day")["weather"]
     B = 65536
     env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=10, uncertainty_scale=0.2, seed=99, auto_reset=False)
-    assert env.n_sub == 240 and env.scheme == "rk4"
+    assert env.n_sub == 120 and env.scheme == "ls5" and env.window == 0
     env.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(17)
     for k in range(39):
@@ -396,7 +421,7 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     for j, b in enumerate(pick):
         p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
         u = np.clip(u_prev[j] + a[j] * np.float32(0.1), 0, 1)
-        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 240, 4, 4)
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 120, 5, 2)
         assert not failed
         worst = max(worst, scaled_err(xg[j], ref))
     m = env.metrics()
@@ -409,8 +434,9 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     env.close()
 
 
-@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 4), ("rk2", 2, 4), ("rk3", 3, 3)])
-def test_fp64_per_env_crop_blocks_in_every_scheme(golden, oracle, scheme, order, win):
+@pytest.mark.parametrize("scheme,order,win,preset", [("ls5", 5, 2, "throughput"), ("ls5", 5, 1, "parity"), ("rk4", 4, 4, "throughput"), ("rk2", 2, 4, "throughput"),
+                                                     ("rk3", 3, 3, "throughput")])
+def test_fp64_per_env_crop_blocks_in_every_scheme(golden, oracle, scheme, order, win, preset):
     """The fp64 kernels that take PER-ENVIRONMENT crop constants (a per-quad record in LDS; `step_kernel_quad<double, ..., CROP>` and
     `evalf_kernel_quad<double, ..., CROP>`, one instantiation per scheme) against the CPU checker's restatement fed each
     environment's own 208-vector: 48 environments with +-10 % crop noise, three env-steps from a spun-up state through glgym_step,
@@ -420,10 +446,11 @@ def test_fp64_per_env_crop_blocks_in_every_scheme(golden, oracle, scheme, order,
     from gl_gym_amd.tomato_env import TomatoVecEnv
     w = golden("rollout_10day")["weather"]
     B = 48
-    env = TomatoVecEnv(B, weather=w, dtype="float64", scheme=scheme, season_length=2, uncertainty_scale=0.2, seed=5, start_rows=[0, 130, 400],
+    env = TomatoVecEnv(B, weather=w, dtype="float64", scheme=scheme, preset=preset, season_length=2, uncertainty_scale=0.2, seed=5, start_rows=[0, 130, 400],
                        auto_reset=False)
     env.reset()
-    m = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme)
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme, preset=preset)
+    assert (m.n_sub, m.window) == (env.n_sub, env.window)
     m.set_verify("never")                                      # the action path below integrates guarded, unverified
     gen = torch.Generator(device=env.device); gen.manual_seed(23)
     w_off = env.w_off_t.cpu().numpy()
@@ -442,7 +469,7 @@ def test_fp64_per_env_crop_blocks_in_every_scheme(golden, oracle, scheme, order,
             assert not failed
             worst_step = max(worst_step, scaled_err(xg[b][None], ref[None]))
             worst_evalf = max(worst_evalf, scaled_err(np.asarray(Y[b])[None], ref[None]))
-    print(f"fp64 per-env crop blocks, {scheme}: glgym_step {worst_step:.1e}, glgym_evalF {worst_evalf:.1e} vs the checker's scheme")
+    print(f"fp64 per-env crop blocks, {scheme} {preset}: glgym_step {worst_step:.1e}, glgym_evalF {worst_evalf:.1e} vs the checker's scheme")
     assert worst_step < 1e-10 and worst_evalf < 1e-10
     assert np.std(crop[0] / env.p[128]) > 0.03                   # the blocks really differ between environments
     env.close(); m.close()
@@ -457,7 +484,7 @@ def test_stability_control_in_storm(golden, oracle):
     w = golden("rollout_10day")["weather"].copy()
     w[:, 4] = 19.5; w[:, 1] = 2.0; w[:, 0] = 0.0
     B = 64
-    env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=256, season_length=1, auto_reset=False)
+    env = TomatoVecEnv(B, weather=w, dtype="float32", scheme="rk4", n_sub=256, season_length=1, auto_reset=False)
     env.reset()
     p = env.p.astype(np.float64)
     ctrl = np.tile(np.array([0.9, 0.1, 0.0, 0.95, 0.5, 0.05]), (B, 1))
@@ -484,7 +511,7 @@ def test_run_time_configuration_dt300_no_forecast(golden):
     w900 = golden("rollout_10day")["weather"]
     w = np.repeat(w900, 3, axis=0)[:3000]                  # a 300-s grid (zero-order hold of the 900-s fixture rows)
     B = 32
-    env = TomatoVecEnv(B, weather=w, dtype="float64", dt=300.0, n_sub=86, season_length=0.02, pred_horizon=0,
+    env = TomatoVecEnv(B, weather=w, dtype="float64", dt=300.0, scheme="rk4", n_sub=86, season_length=0.02, pred_horizon=0,
                        start_rows=[0, 12], start_days=[0.0, 12 * 300 / 86400], seed=3, auto_reset=False)
     assert env.N == 5 and env.Np == 0 and env.obs_dim == 23
     obs0 = env.reset()
@@ -520,7 +547,7 @@ def test_custom_reward_prices_and_constraints(golden):
     w = golden("rollout_10day")["weather"]
     rp = dict(elec_price=0.21, heating_price=0.05, co2_price=0.12, fruit_price=2.4, dmfm=0.0627)
     cs = dict(co2_min=500., co2_max=1000., temp_min=17., temp_max=20., rh_min=60., rh_max=75.)
-    env = TomatoVecEnv(16, weather=w, dtype="float64", n_sub=256, season_length=1, reward_params=rp, constraints=cs,
+    env = TomatoVecEnv(16, weather=w, dtype="float64", scheme="rk4", n_sub=256, season_length=1, reward_params=rp, constraints=cs,
                        auto_reset=False)
     env.reset()
     orc = OracleTomatoEnv(weather=w, p=env.p, season_length=1, integrator="rk4", n_sub=256, train_years=[0],
@@ -556,7 +583,7 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     X, U, D, P, DX, XT = g["X"], g["U"], g["D14"], g["P"], g["DX"], g["X_tight300"]
     n = len(XT)
     for dtype, tol_rhs, tol_step in (("float64", 1e-11, 1.3e-5), ("float32", 2e-4, 3e-5)):
-        m = GreenLight(28, 6, 14, 208, 300.0, dtype=dtype, n_sub=256, variant="ode_pipe")
+        m = GreenLight(28, 6, 14, 208, 300.0, dtype=dtype, scheme="rk4", n_sub=256, variant="ode_pipe")
         for grp in (0, 1):                                    # even tuples: default p; odd: the MATLAB-comparison overrides
             idx = np.arange(grp, len(X), 2)
             if not np.array_equal(P[idx[0]], P[idx[-1]]):     # crop-noise tuples differ: one row at a time
@@ -572,11 +599,11 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
         assert err < tol_step
         m.close()
     # (2) default variant, 14-column rows
-    a = GreenLight(28, 6, 14, 208, 300.0, n_sub=256)
+    a = GreenLight(28, 6, 14, 208, 300.0, n_sub=256)             # (the default scheme, ls5)
     b = GreenLight(28, 6, 10, 208, 300.0, n_sub=256)
     np.testing.assert_array_equal(a.evalF_batch(X[:8], U[:8], D[:8]), b.evalF_batch(X[:8], U[:8], D[:8, :10]))
     with pytest.raises(Exception):
-        GreenLight(28, 6, 10, 208, 300.0, variant="ode_pipe")          # needs the measured-pipe columns
+        GreenLight(28, 6, 10, 208, 300.0, scheme="rk4", variant="ode_pipe")          # needs the measured-pipe columns
     a.close(); b.close()
     # (3) env: 14-column weather table, controls held, pipe tracking on most rows
     w10 = golden("rollout_10day")["weather"][:200]
@@ -586,9 +613,9 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     w14[::13, 10] = 0.0
     p = P[1]
     env = TomatoVecEnv(4, weather=w14, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
-                       n_sub=256, model_variant="ode_pipe", auto_reset=False)
+                       scheme="rk4", n_sub=256, model_variant="ode_pipe", auto_reset=False)
     ref_env = TomatoVecEnv(4, weather=w10, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
-                           n_sub=256, auto_reset=False)
+                           scheme="rk4", n_sub=256, auto_reset=False)
     np.testing.assert_array_equal(env.reset(), ref_env.reset())           # obs / reset read the 14-wide rows correctly
     x = env.x[0].double().cpu().numpy()
     p64 = np.asarray(env.p, dtype=np.float64)
@@ -609,8 +636,8 @@ def test_rk2_scheme_matches_oracle_restatement(golden, oracle):
     g = golden("step_tight")
     X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
     for dtype, tol_o, tol_t in (("float64", 1e-9, 3e-5), ("float32", 3e-5, 4e-5)):
-        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk2")
-        assert m.n_sub == 336                  # the scheme's default nominal count
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk2", preset="throughput")
+        assert m.n_sub == 336                  # the scheme's nominal count (throughput preset)
         m.set_n_sub(360)
         got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
         ref = np.array([oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, 360, 2, 4)[0] for i in range(len(X))])
@@ -629,8 +656,8 @@ def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
     g = golden("step_tight")
     X, U, D, P, XT = g["X"], g["U"], g["D"], g["P"].astype(np.float64), g["X_tight"]
     for dtype, tol_o, tol_t in (("float64", 1e-9, 3e-5), ("float32", 3e-5, 4e-5)):          # measured 2.7e-5 in fp64
-        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk3")
-        assert m.n_sub == 270                  # the scheme's default nominal count
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="rk3", preset="throughput")
+        assert m.n_sub == 270                  # the scheme's nominal count (throughput preset)
         got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(len(X))])
         ref = np.array([oracle.rk_sc_guarded(X[i], U[i], D[i], P[i], 900.0, 270, 3, 3)[0] for i in range(len(X))])
         print(f"rk3 {dtype}: vs oracle scheme {scaled_err(got, ref):.2e}, vs tight {scaled_err(got, XT):.2e}")
@@ -639,11 +666,12 @@ def test_rk3_scheme_matches_oracle_restatement(golden, oracle):
         m.set_n_sub(268)                       # n_sub is rounded up to a multiple of the 3-sub-step window
         np.testing.assert_array_equal(np.array(m.evalF(X[0], U[0], D[0], P[0])), got[0])
         m.close()
-    assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3").n_sub == 90 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2").n_sub == 336
+    assert GreenLight(28, 6, 10, 208, 300.0, scheme="rk3", preset="throughput").n_sub == 90 and GreenLight(28, 6, 10, 208, 900.0, scheme="rk2", preset="throughput").n_sub == 336
 
 
-@pytest.mark.parametrize("scheme,order,win", [("rk4", 4, 4), ("rk2", 2, 4), ("rk3", 3, 3)])
-def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win):
+@pytest.mark.parametrize("scheme,order,win,preset", [("ls5", 5, 2, "throughput"), ("ls5", 5, 1, "parity"), ("rk4", 4, 4, "throughput"), ("rk2", 2, 4, "throughput"),
+                                                     ("rk3", 3, 3, "throughput")])
+def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, scheme, order, win, preset):
     """The fp64 kernels sit at the register limit and hipcc 7.2 has miscompiled them before (round 4: builds
     with the default parameter block compiled in computed wrong slow states -- traced to the max-ilp scheduler flag, since removed): every env-step of a short
     rollout must agree with the oracle's restatement of the same scheme to rounding level, through glgym_step AND glgym_evalF (two
@@ -654,9 +682,10 @@ def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, sche
     g = golden("rollout_3day_synth")
     A, W, XR = g["actions"], g["weather"], g["X"]
     p = golden("params_default")["p"].astype(np.float64)
-    env = TomatoVecEnv(64, weather=W, dtype="float64", scheme=scheme, season_length=3, auto_reset=False)
+    env = TomatoVecEnv(64, weather=W, dtype="float64", scheme=scheme, preset=preset, season_length=3, auto_reset=False)
     env.reset()
-    m = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme)
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme, preset=preset)
+    assert (m.n_sub, m.window) == (env.n_sub, env.window) and (env.window or win) == win
     u = np.zeros(6)
     for k in range(16):
         x_prev = env.x[0].double().cpu().numpy().copy()
@@ -670,16 +699,17 @@ def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, sche
 
 
 def test_default_n_sub_scales_with_dt(golden, oracle):
-    """Without an explicit n_sub the nominal sub-step stays 3.75 s for any dt (80 sub-steps at the dt = 300 s of the
-    reference's experiments/run_time.py, 480 at 1 800 s); accuracy against plain RK4 with 8 192 sub-steps."""
+    """Without an explicit n_sub the nominal sub-step keeps its length for any dt (throughput preset of the default scheme: 7.5 s -- 40
+    sub-steps at the dt = 300 s of the reference's experiments/run_time.py, 240 at 1 800 s; the parity preset GreenLight() defaults
+    to: 4.7 s -- 64 / 384); accuracy against plain RK4 with 8 192 sub-steps."""
     from gl_gym_amd import GreenLight
     g = golden("step_tight")
     X, U, D, P = g["X"], g["U"], g["D"], g["P"].astype(np.float64)
     scale = 1e-3 * np.abs(X).max(axis=0)
-    for dt, n_expect in ((300.0, 80), (1800.0, 480)):
+    for dt, preset, n_expect in ((300.0, "throughput", 40), (1800.0, "throughput", 240), (300.0, "parity", 64), (1800.0, "parity", 384)):
         for dtype in ("float64", "float32"):
-            m = GreenLight(28, 6, 10, 208, dt, dtype=dtype)
-            assert m.n_sub == n_expect
+            m = GreenLight(28, 6, 10, 208, dt, dtype=dtype, preset=preset)
+            assert m.n_sub == n_expect and m.scheme == "ls5"
             for i in (0, 7, 19, 33):
                 got = np.array(m.evalF(X[i], U[i], D[i], P[i]))
                 ref = oracle.rk4_split(X[i], U[i], D[i], P[i], dt, 8192)
@@ -687,9 +717,9 @@ def test_default_n_sub_scales_with_dt(golden, oracle):
             m.close()
 
 
-@pytest.mark.parametrize("scheme", ["rk4", "rk2", "rk3"])
+@pytest.mark.parametrize("scheme", ["ls5", "rk4", "rk2", "rk3"])
 def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
-    """GLGYM_OCC=2 (read per launch) makes float32 default-parameter launches take the `__launch_bounds__(64, 2)` build of
+    """glgym_set_occupancy(h, 2) makes float32 default-parameter launches take the `__launch_bounds__(64, 2)` build of
     step_kernel (256 registers, the rest spilled to scratch).  Same source, other register allocation: its results must
     equal those of the one-wave build environment by environment, over several steps with observations, auto-reset bookkeeping
     and metrics.  Both batches are beyond the quad kernel's range (B > 16 384) so that both run one lane per environment; the
@@ -705,6 +735,7 @@ def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
                          auto_reset=False)
     large = TomatoVecEnv(Bl, weather=w, dtype="float32", scheme=scheme, season_length=1, start_rows=starts, seed=5,
                          auto_reset=False)
+    large.set_occupancy(2)                   # handle state (round 5; GLGYM_OCC is only its initial value, read at glgym_create)
     small.reset(); large.reset()
     # the large batch = 64 copies of the small one (same start rows, states and actions per copy)
     rep = Bl // Bs
@@ -714,13 +745,8 @@ def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
     worst = 0.0
     for k in range(4):
         a = torch.rand(Bs, 6, generator=g, device=small.device) * 2 - 1
-        os.environ.pop("GLGYM_OCC", None)
         o_s, r_s, d_s, i_s = small.step_tensor(a)
-        os.environ["GLGYM_OCC"] = "2"
-        try:
-            o_l, r_l, d_l, i_l = large.step_tensor(a.repeat(rep, 1))
-        finally:
-            os.environ.pop("GLGYM_OCC", None)
+        o_l, r_l, d_l, i_l = large.step_tensor(a.repeat(rep, 1))
         # column-scaled differences (conftest.scaled_err's metric): rounding-level, the two builds order a few float32
         # operations differently; measured 2e-7 ... 1e-6, against 1e-5 ... 2e-5 of either build to the float64 kernel
         # (reward and the profit entries of info are differences that pass through zero: scaled by the column maximum)
@@ -758,7 +784,7 @@ def test_bench_workload_at_full_batch_against_oracle_and_fine_truth(oracle):
     w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
     starts = np.arange(0, 35040 - 5760 - 60, 96)
     env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=60, pred_horizon=0.5, seed=666, start_rows=starts, auto_reset=True)
-    assert env.n_sub == 240 and env.scheme == "rk4"
+    assert env.n_sub == 120 and env.scheme == "ls5" and env.window == 0      # bench.py's `value` configuration
     env.reset_tensor()
     dev = env.device
     env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)).to(env.tdtype))
@@ -776,7 +802,7 @@ def test_bench_workload_at_full_batch_against_oracle_and_fine_truth(oracle):
         u = env.u[pick].double().cpu().numpy()                                         # the control the kernel applied
         x_gpu = env.x[pick].double().cpu().numpy()
         flags = env.step_flags_t.cpu().numpy()[pick]
-        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 240, 4, 4, want_flags=True), range(64)))
+        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 120, 5, 2, want_flags=True), range(64)))
         for j in range(64):
             assert not ref[j][3] and not (flags[j] & 128)
             worst_one = max(worst_one, scaled_err(x_gpu[j][None], ref[j][0][None]))

@@ -12,7 +12,17 @@ from conftest import scaled_err
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("rk4", 240), ("rk2", 336), ("rk3", 270)]            # the schemes' default nominal sub-step counts
+def no_floor_err(got, ref, abs_floor=2e-4):
+    """conftest.scaled_err over the entries the fixtures' floor rule does not cover (a temperature -- columns 2..21 -- within
+    1e4 x abs_floor of 0 C and off by less than abs_floor is the metric's floor, not a disagreement: tests/test_jump_fixture.py judge)"""
+    sc = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max(axis=0, keepdims=True))
+    sc[sc == 0] = 1.0
+    e = np.abs(got - ref) / sc
+    floor = (np.abs(got - ref) < abs_floor) & (np.arange(ref.shape[1])[None, :] < 22) & (np.abs(ref) < 1e4 * abs_floor)
+    return float(np.max(np.where(floor, 0.0, e)))
+
+
+SCHEMES = [("ls5", 120), ("rk4", 240), ("rk2", 336), ("rk3", 270)]            # the schemes' nominal sub-step counts (throughput preset)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -57,7 +67,7 @@ def test_storm_step_maps_through_step_kernel(golden, oracle, scheme, n_sub, dtyp
     assert m["n_ode_fail"] == 0 and not done.any()
     assert m["n_refined_substeps"] > 0                           # lanes in the storm took more than n_sub sub-steps
     if dtype == "float64":                                       # the oracle's restatement takes the same sub-steps
-        order, win = {"rk4": (4, 4), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
+        order, win = {"ls5": (5, 2), "rk4": (4, 4), "rk2": (2, 4), "rk3": (3, 3)}[scheme]
         ref = [oracle.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, n_sub, order, win, verify=True)
                for i in range(B)]        # step_raw_control integrates verified (glgym_set_verify: AUTO)
         assert m["n_refined_substeps"] == sum(r_[2] for r_ in ref)
@@ -81,16 +91,16 @@ def test_pinned_wet_screen_is_resolved_or_flagged_never_wrong(golden, oracle):
         x[7] = x[2] - 1e-7                                           # ... and 1e-7 K below the air temperature
         x[15] = 1.4 * 610.78 * np.exp(17.2694 * x[7] / (x[7] + 238.3))    # air far above the screen's dew point
         truth = oracle.rk4(x, u, d, p, 900.0, 32768)
-        for dtype in ("float64", "float32"):
-            m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=240)
+        for dtype, scheme, n_sub in (("float64", "ls5", 120), ("float32", "ls5", 120), ("float64", "rk4", 240), ("float32", "rk4", 240)):
+            m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
             try:
                 got = np.array(m.evalF(x, u, d, p))
             except GlgymOdeError:
                 got = None
             if got is not None:
                 err = float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), scale)))
-                print(f"pinned screen tuple {i} {dtype}: {err:.2e}")
-                assert err < 1e-4, (i, dtype, err)
+                print(f"pinned screen tuple {i} {dtype} {scheme}: {err:.2e}")
+                assert err < 1e-4, (i, dtype, scheme, err)
             m.close()
 
 
@@ -105,8 +115,8 @@ def test_ragged_batch_and_mixed_lanes_are_independent(golden):
     D = np.concatenate([g["D"][:40], t["D"][:37]])
     order = np.random.default_rng(0).permutation(len(X))          # interleave storm and nominal tuples: 77 lanes = 64 + 13
     X, U, D = X[order], U[order], D[order]
-    for dtype in ("float64", "float32"):
-        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, n_sub=240)
+    for dtype, scheme, n_sub in (("float64", "ls5", 120), ("float32", "ls5", 120), ("float64", "rk4", 240), ("float32", "rk4", 240)):
+        m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
         batch = m.evalF_batch(X, U, D)
         p = golden("params_default")["p"].astype(np.float64)
         for i in (0, 5, 40, 63, 64, 76):
@@ -122,7 +132,7 @@ def test_ode_pipe_tracking_at_dt_900_is_refined_not_unstable(golden, oracle):
     g = golden("pipe_kat")
     X, U, D14, P = g["X"], g["U"], g["D14"], g["P"]
     track = np.nonzero((D14[:, 10] >= 1) & (D14[:, 12] <= 0))[0][:6]
-    m = GreenLight(28, 6, 14, 208, 900.0, dtype="float64", variant="ode_pipe", n_sub=240)
+    m = GreenLight(28, 6, 14, 208, 900.0, dtype="float64", variant="ode_pipe", scheme="rk4", n_sub=240)
     scale = 1e-3 * np.abs(X).max(axis=0)
     for i in track:
         got = np.array(m.evalF(X[i], U[i], D14[i], P[i]))
@@ -133,7 +143,8 @@ def test_ode_pipe_tracking_at_dt_900_is_refined_not_unstable(golden, oracle):
     m.close()
 
 
-def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
+@pytest.mark.parametrize("scheme,n_sub", [("ls5", 120), ("rk4", 240)])
+def test_four_lanes_per_environment_equals_one_lane_per_environment(golden, scheme, n_sub):
     """The north-star layout (gl_model_quad.hpp: a quad of lanes per environment, DPP inside the quad; taken for fp32 batches up to
     16 384) against the one-lane-per-environment kernel on the same inputs: storm and raw-jump tuples (refined lanes, ladder
     attempts, verified mode), a batch that is not a multiple of 16, through glgym_step with raw controls and with actions.  Same
@@ -147,11 +158,10 @@ def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
     B = len(X)                                                   # 200 = 12 full quads-of-16 + 8
     w = np.repeat(D, 4, axis=0)
     out = {}
-    old = os.environ.get("GLGYM_LAYOUT")
-    try:
+    if True:
         for layout in ("one", "quad"):
-            os.environ["GLGYM_LAYOUT"] = layout
-            env = TomatoVecEnv(B, weather=w, dtype="float32", n_sub=240, season_length=0.02, pred_horizon=0, auto_reset=False)
+            env = TomatoVecEnv(B, weather=w, dtype="float32", scheme=scheme, n_sub=n_sub, season_length=0.02, pred_horizon=0, auto_reset=False)
+            env.set_layout(layout)                # handle state (glgym_set_layout; round 5)
             env.reset()
             env.w_off_t.copy_(torch.arange(B, dtype=torch.int32, device=env.device) * 4)
             env.x.copy_(torch.as_tensor(X, dtype=env.tdtype, device=env.device))
@@ -164,21 +174,20 @@ def test_four_lanes_per_environment_equals_one_lane_per_environment(golden):
             obs2, r2, done2, _ = env.step(np.zeros((B, 6), np.float32))                      # action path: guarded, unverified
             out[layout] = (x_raw, m_raw, r.copy(), env.x.double().cpu().numpy().copy(), env.metrics(), r2.copy(), done.copy())
             env.close()
-    finally:
-        if old is None:
-            os.environ.pop("GLGYM_LAYOUT", None)
-        else:
-            os.environ["GLGYM_LAYOUT"] = old
     a, b = out["one"], out["quad"]
     e_raw, e_act = scaled_err(b[0], a[0]), scaled_err(b[3], a[3])
-    print(f"quad vs one lane per env (fp32, {B} storm / jump tuples): raw-control step {e_raw:.1e}, action step {e_act:.1e}; "
+    print(f"quad vs one lane per env (fp32 {scheme}, {B} storm / jump tuples): raw-control step {e_raw:.1e}, action step {e_act:.1e}; "
           f"vs truth: one {scaled_err(a[0], XT):.1e}, quad {scaled_err(b[0], XT):.1e}; extra attempts {a[1]['n_guard_retries']:.0f} / "
           f"{b[1]['n_guard_retries']:.0f}, refined {a[1]['n_refined_substeps']:.0f} / {b[1]['n_refined_substeps']:.0f}")
     # (fp32 rounding through up to 1e4 refined sub-steps of a pinned wet surface differs between the layouts' operation orders: the
     # layouts are compared with the fixtures' floor rule -- a temperature within 2 C of 0 C may differ by 2e-4 K -- and both are
-    # judged against the tight truth below)
+    # judged against the tight truth below.  Outside the floor rule the two fp32 layouts agree to 3e-4 scaled: 2.5e-4 measured in
+    # round 4; the 2e-3 that round allowed is gone)
     from test_jump_fixture import judge
-    assert judge(b[0], a[0], 2e-4)[0] == 0 and judge(b[3], a[3], 2e-4)[0] == 0 and e_raw < 2e-3 and e_act < 2e-3
+    assert judge(b[0], a[0], 2e-4)[0] == 0 and judge(b[3], a[3], 2e-4)[0] == 0
+    e_raw_nf, e_act_nf = no_floor_err(b[0], a[0]), no_floor_err(b[3], a[3])
+    print(f"   outside the floor rule: raw-control step {e_raw_nf:.1e}, action step {e_act_nf:.1e}")
+    assert e_raw_nf < 3e-4 and e_act_nf < 3e-4
     assert np.max(np.abs(a[2] - b[2])) < 1e-5 and np.max(np.abs(a[5] - b[5])) < 1e-5 and np.array_equal(a[6], b[6])
     for k in ("n_ode_fail", "n_done", "n_env_steps"):
         assert a[1][k] == b[1][k] and a[4][k] == b[4][k], k
@@ -199,6 +208,7 @@ def test_fp64_large_ragged_batch_against_the_cpu_checker(golden, oracle):
     B = 40003
     rng = np.random.default_rng(3)
     env = TomatoVecEnv(B, weather=w, dtype="float64", season_length=2, start_rows=[0, 96, 300, 480], seed=11, auto_reset=False)
+    assert (env.scheme, env.preset, env.n_sub, env.window) == ("ls5", "parity", 192, 1)     # what an fp64 handle gets by default (round 5)
     env.reset()
     p = env.p.astype(np.float64)
     pick = np.concatenate([np.arange(16), np.arange(B - 16, B), rng.choice(np.arange(16, B - 16), 64, replace=False)])
@@ -212,7 +222,7 @@ def test_fp64_large_ragged_batch_against_the_cpu_checker(golden, oracle):
         x_gpu = env.x[pick].double().cpu().numpy()
         flags = env.step_flags_t.cpu().numpy()[pick]
         for j in range(len(pick)):
-            ref = oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, env.n_sub, 4, 4, want_flags=True)
+            ref = oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, env.n_sub, 5, env.window, want_flags=True)
             assert not ref[3] and not (flags[j] & 128)
             worst = max(worst, scaled_err(x_gpu[j][None], ref[0][None]))
             worst_flags += int((flags[j] & 0xffff) != (ref[4] & 0xffff))

@@ -19,18 +19,18 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_one_step_stress_rates_stay_at_the_measured_level():
     sys.path.insert(0, str(ROOT / "tools"))
     import gpu_stress
-    res = gpu_stress.run_stress(16384, 11, schemes=("rk4",), dtypes=("float64", "float32"))
-    for dtype in ("float64", "float32"):
-        r = res[("rk4", dtype)]
+    res = gpu_stress.run_stress(16384, 11, schemes=("ls5", "rk4"), dtypes=("float64", "float32"))
+    for scheme, dtype in (("ls5", "float64"), ("ls5", "float32"), ("rk4", "float64"), ("rk4", "float32")):
+        r = res[(scheme, dtype)]
         n4 = r["n_kind"][4]
         assert r["n"] > 15000 and n4 > 2500
         # kinds 0-3: nothing beyond the metric floor, no failed integration
-        assert sum(r["real"][:4]) == 0 and sum(r["gross"][:4]) == 0 and sum(r["failed"][:4]) == 0, (dtype, r)
+        assert sum(r["real"][:4]) == 0 and sum(r["gross"][:4]) == 0 and sum(r["failed"][:4]) == 0, (scheme, dtype, r)
         # the review's recipe: gross <= 3e-4, failed <= 1e-3, above-the-bar <= 2.5e-3 per tuple (+1: one seed's granularity)
-        assert r["gross"][4] <= 3e-4 * n4 + 1, (dtype, r)
-        assert r["failed"][4] <= 1e-3 * n4 + 1, (dtype, r)
-        assert r["real"][4] <= 2.5e-3 * n4 + 1, (dtype, r)
-        assert r["q999"] < 1e-4, (dtype, r)
+        assert r["gross"][4] <= 3e-4 * n4 + 1, (scheme, dtype, r)
+        assert r["failed"][4] <= 1e-3 * n4 + 1, (scheme, dtype, r)
+        assert r["real"][4] <= 2.5e-3 * n4 + 1, (scheme, dtype, r)
+        assert r["q999"] < 1e-4, (scheme, dtype, r)
 
 
 def test_step_flags_say_how_an_env_step_was_accepted():
@@ -56,8 +56,10 @@ def test_step_flags_say_how_an_env_step_was_accepted():
     fl = env.step_flags_t.cpu().numpy()
     assert not (fl & L.SF_FAILED).any() and not done.any()
     assert (((fl >> 8) & 7) >= 1).all()                                    # verified: at least n_sub and 2 n_sub
-    ref = np.array([O.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, env.n_sub, 4, 4, verify=True, want_flags=True)[4]
+    assert (env.scheme, env.n_sub, env.window) == ("ls5", 192, 1)          # an fp64 handle's default: the parity preset
+    ref = np.array([O.rk_sc_guarded(X[i], U[i], D[i], env.p.astype(np.float64), 900.0, env.n_sub, 5, env.window, verify=True, want_flags=True)[4]
                     for i in range(B)])
+    assert (fl >= 0).all()                                                 # bit 31 is never set (the count saturates at 32 767)
     assert np.array_equal(fl & 0xffff, ref & 0xffff), np.nonzero((fl & 0xffff) != (ref & 0xffff))
     assert np.abs((fl >> 16) - (ref >> 16)).max() <= 2                     # sub-step counts (a ceil() may flip on a last bit)
     n_flagged_accept = int(((fl & L.SF_ACCEPT_AGREE_FLAGGED) != 0).sum())

@@ -38,27 +38,31 @@ def test_fixture_is_what_it_says(golden):
     assert sce(g["X_bdf"], g["X_tight"]).max() < 1e-2
 
 
-def test_oracle_verified_guard_against_the_jump_truth(golden, oracle):
+import pytest
+
+
+@pytest.mark.parametrize("n_sub,order,win", [(120, 5, 2), (240, 4, 4)])
+def test_oracle_verified_guard_against_the_jump_truth(golden, oracle, n_sub, order, win):
     g = golden("step_tight_jump")
     p = golden("params_default")["p"].astype(np.float64)
     X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
 
     def run(i):
-        return oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, 240, 4, 4, verify=True)
+        return oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n_sub, order, win, verify=True)
     with ThreadPoolExecutor(8) as ex:
         R = list(ex.map(run, range(len(X))))
     got = np.array([r[0] for r in R])
     assert not any(r[3] for r in R)                                                   # no failed integration
     wrong, floor = judge(got, XT)
-    print(f"oracle RK4-240 verified on {len(X)} jump tuples: above 1e-4: {wrong} (+ {floor} at the metric floor), "
+    print(f"oracle order {order} n_sub {n_sub} verified on {len(X)} jump tuples: above 1e-4: {wrong} (+ {floor} at the metric floor), "
           f"max {sce(got, XT).max():.1e}, attempts beyond the first: {sum(r[1] for r in R)}")
     assert wrong == 0 and floor <= 3
     # the review's tuples A and B under the UNVERIFIED guard (the action path's integration): round 2 capped the refinement at
     # 16x, went unstable on the pinned cover and returned the wrong branch with failed = 0; now the sub-step follows the rate
     # bound down to 1/64 of the nominal one, the attempt is 'heavy' (>= 3x the nominal sub-steps) and gets verified by 2x
     for i in (0, 1):
-        y, retries, refined, failed = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, 240, 4, 4)
-        assert not failed and retries >= 1 and refined > 3 * 240 and judge(y[None], XT[i][None])[0] == 0
+        y, retries, refined, failed = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n_sub, order, win)
+        assert not failed and retries >= 1 and refined > 3 * n_sub and judge(y[None], XT[i][None])[0] == 0
 
 
 def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
@@ -68,14 +72,15 @@ def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
     p = golden("params_default")["p"].astype(np.float64)
     X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
     for i in list(range(0, 15)) + [40, 100, 300]:
-        for (n, o, w) in ((240, 4, 4), (270, 3, 3)):
+        for (n, o, w) in ((120, 5, 2), (240, 4, 4), (270, 3, 3)):
             a = hostmath.step_guarded(X[i], U[i], D[i], p, False, 900.0, n, o, w, verify=True)
             b = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n, o, w, verify=True)
             assert a[1] == b[1] and a[3] == b[3] and not a[3], (i, n, a[1:], b[1:])
             assert sce(a[0], b[0]).max() < 1e-7, (i, n, sce(a[0], b[0]).max())      # kinks amplify rounding: 2e-8 seen
-        y32 = hostmath.step_guarded(X[i], U[i], D[i], p, True, 900.0, 240, 4, 4, verify=True)
-        wrong, floor = judge(y32[0][None], XT[i][None], 2e-4)
-        assert not y32[3] and wrong == 0, (i, sce(y32[0], XT[i]).max())
+        for (n, o, w) in ((120, 5, 2), (240, 4, 4)):
+            y32 = hostmath.step_guarded(X[i], U[i], D[i], p, True, 900.0, n, o, w, verify=True)
+            wrong, floor = judge(y32[0][None], XT[i][None], 2e-4)
+            assert not y32[3] and wrong == 0, (i, n, sce(y32[0], XT[i]).max())
 
 
 def test_c_bdf_stand_in_for_cvodes(golden, oracle):

@@ -13,7 +13,7 @@ from gl_gym_amd import GreenLight
 from gl_gym_amd.utils import synthetic_weather, init_state
 
 
-def run_stress(N=32768, seed=7, schemes=("rk4", "rk3", "rk2"), dtypes=("float64", "float32"), argv=()):
+def run_stress(N=32768, seed=7, schemes=("ls5", "rk4", "rk3", "rk2"), dtypes=("float64", "float32"), argv=()):
     """-> {(scheme, dtype): {"n": tuples with truth, "n_kind": per kind, "real": per kind (> 1e-4 beyond the metric floor), "gross": per kind
     (> 1e-2), "failed": per kind, "q999": 99.9 % quantile}}; prints the tool's report lines."""
     sys_argv = list(argv)
@@ -54,8 +54,8 @@ def run_stress(N=32768, seed=7, schemes=("rk4", "rk3", "rk2"), dtypes=("float64"
     spun = ~np.isnan(XS).any(axis=1)
     print(f"spin-up (1 800 s from the reset state, unverified guard): {int((~spun).sum())} of {N} rows reported as failed integrations (by kind {[int((~spun & (kind == k)).sum()) for k in range(5)]}); dropped")
     XS, U, D, kind = XS[spun], U[spun], D[spun], kind[spun]; N = len(XS)
-    fine = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=2560); fine.set_verify("never"); T1 = raw_evalF(fine, XS, U, D); fine.close()
-    finer = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", n_sub=5120); finer.set_verify("never"); T2 = raw_evalF(finer, XS, U, D); finer.close()
+    fine = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme="rk4", n_sub=2560); fine.set_verify("never"); T1 = raw_evalF(fine, XS, U, D); fine.close()
+    finer = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme="rk4", n_sub=5120); finer.set_verify("never"); T2 = raw_evalF(finer, XS, U, D); finer.close()
     sce = lambda a, b: np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * COLMAX)
     ok = np.isfinite(T2).all(axis=1) & np.isfinite(T1).all(axis=1) & (sce(np.nan_to_num(T1), np.nan_to_num(T2)).max(axis=1) < 2e-7)
     print(f"truth runs (fp64 kernel, n_sub 2 560 / 5 120, unverified guard): {int(np.isnan(T1).any(axis=1).sum())} / {int(np.isnan(T2).any(axis=1).sum())} rows reported as failed integrations")
@@ -66,7 +66,7 @@ def run_stress(N=32768, seed=7, schemes=("rk4", "rk3", "rk2"), dtypes=("float64"
         print(f"dumped {int(k4.sum())} review-recipe tuples"); return results
     for scheme in schemes:
         for dtype in dtypes:
-            m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme)
+            m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, preset="throughput")     # the schemes' nominal counts
             if "never" in sys_argv:
                 m.set_verify("never")
             Y = raw_evalF(m, XS[ok], U[ok], D[ok]); rc = 0
