@@ -431,6 +431,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
     LsCoef<T> lc;                 // ORDER 5: the pair's y component by the exponential 2N formulas (gl_model.hpp ls_coefs), in registers
+    T ls_Nprev = T(0), ls_hprev = T(0);       // ORDER 5, cover lane: N_w at the start of the previous sub-step and its length (0: none yet)
     const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
     const T gam = m.iCapCov * m.cCovCond, cw = cov ? T(0.5) : T(0);
     QVec<T> y, xs, k, acc;
@@ -517,9 +518,15 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         }
         if (it == n_win) break;
         T hs = M::min(S * M::rcp(lam), hnom);
+        const T hs_stab = hs;                                  // what stability alone allows in this window (rk_delta)
+        // movement limiter; ORDER 5: its allowance grows with the head-room the window's rate bound leaves below the stability limit
+        T move_allow = T(SC_MOVE);
+        if (ORDER == 5) move_allow = T(SC_MOVE) * M::min(M::max(S * M::rcp(lam * hnom), T(1)), T(SC_MOVE_HMAX));
+        bool limited0;
         {
             const T mv = gq_max(gq_fast_max(true_rates(k, y), gq_tol<T>(role).mov));
-            hs = (mv * hs > T(SC_MOVE)) ? T(SC_MOVE) * M::rcp(mv) : hs;
+            limited0 = mv * hs > move_allow;
+            hs = limited0 ? move_allow * M::rcp(mv) : hs;
         }
         const T hmin = hnom * T(1.0 / SC_MAX_REFINE);
         const bool capped = !(hs >= hmin);
@@ -527,7 +534,10 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         n_cap += capped ? 1 : 0;
         capped_prev = capped;
         T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
-        const T h = hw * M::rcp(n_rem), h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+        T h = hw * M::rcp(n_rem);
+        // ORDER 5: a limiter-bound window re-partitions its remainder sub-step by sub-step (rk_delta); uniform inside the quad
+        const bool adaptive = (ORDER == 5) && limited0 && !capped;
+        T t_rem = hw;
         if (h != h_last) {
             if (ORDER == 5) ls_coefs<T>(cov ? T(2) * gam : T(0), h, lc); else etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
         }
@@ -536,6 +546,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         // two "others" (tCan24, tCanSum | tIntLamp, time), its ETD sibling on the pair's y component (classical coefficients off the
         // cover lane), the cover lane's x assembled from tTop, sigma and w (rk_delta), constant rate for the rest
         auto sub_step = [&]() {
+            const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
             const T w0 = y.p.y, n1 = k.p.y;
             const bool full01 = lane0 || role == 3;
             auto fill = [&](T c, T dW) {
@@ -548,6 +559,11 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                 // component by the exponential form with per-lane coefficients -- a = 2 gam on the cover lane; a = 0 elsewhere, for
                 // which E = 1, dphi = h dc and the formulas ARE the plain 2N scheme: one instruction stream for the four lanes
                 const T F0 = n1 - (cov ? T(2) * gam : T(0)) * w0;
+                // linear predictor of the cover lane's forcing (rk_delta): slope from the previous sub-step's start value; none elsewhere
+                // (a = 0: the plain 2N scheme needs none)
+                const T slope = (cov && h <= T(2.0001) * ls_hprev) ? (n1 - ls_Nprev) * M::rcp(ls_hprev) : T(0);
+                ls_Nprev = n1; ls_hprev = h;
+                const T slope_ia = slope * M::rcp(T(2) * gam);
                 T vv = T(0), dv = T(0);
 #pragma unroll
                 for (int stg = 0; stg < 5; ++stg) {
@@ -556,10 +572,10 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                     acc.p.x = (stg == 0) ? k.p.x : Ai * acc.p.x + k.p.x;
                     for (int i = 0; i < 6; ++i) { acc.sh[i] = (stg == 0) ? k.sh[i] : Ai * acc.sh[i] + k.sh[i]; del.sh[i] += Bh * acc.sh[i]; }
                     acc.o[0] = (stg == 0) ? k.o[0] : Ai * acc.o[0] + k.o[0]; acc.o[1] = (stg == 0) ? k.o[1] : Ai * acc.o[1] + k.o[1];
-                    dv = (stg == 0) ? T(0) : Ai * dv + h * (k.p.y - n1);
+                    dv = (stg == 0) ? T(0) : Ai * dv + h * ((k.p.y - n1) - slope * (T(Ls5<T>::c(stg)) * h));
                     const T vnext = lc.E[stg] * (vv + Bi * dv);
                     dv = lc.E[stg] * dv;
-                    const T dW = lc.dphi[stg] * F0 + (vnext - vv);
+                    const T dW = lc.dphi[stg] * F0 + (h * T(Ls5<T>::c(stg + 1) - Ls5<T>::c(stg)) - lc.dphi[stg]) * slope_ia + (vnext - vv);
                     vv = vnext;
                     del.p = gq_mk<T>(del.p.x + Bh * acc.p.x - cw * dW, del.p.y + dW);
                     del.o[0] += full01 ? Bh * acc.o[0] : T(0);
@@ -630,10 +646,27 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             ++n_steps;
         };
         sub_step();
+        t_rem -= h;
         for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
             state_now();
             GQ_FENCE(); gq_stage<T, false, PIPE>(role, y, K, s, m, q, k, nullptr);
+            if (ORDER == 5 && GL_WAVE_ANY(adaptive)) {
+                // the limiter again with this sub-step's first stage; the rest of the window re-partitioned (rk_delta, decision for decision)
+                const T mvj = gq_max(gq_fast_max(true_rates(k, y), gq_tol<T>(role).mov));
+                T hsj = (mvj * hs_stab > move_allow) ? move_allow * M::rcp(mvj) : hs_stab;
+                hsj = !(hsj >= hmin) ? hmin : hsj;
+                T nn = M::max(T(1), ceil_pos(t_rem * M::rcp(hsj) - T(1e-3)));
+                T hj = t_rem * M::rcp(nn);
+                const bool grow = hj > T(2.0001) * h;
+                hj = grow ? T(2) * h : hj;
+                nn = (grow && nn < T(2)) ? T(2) : nn;
+                h = adaptive ? hj : h;
+                n_rem = adaptive ? nn : n_rem;
+                if (h != h_last) ls_coefs<T>(cov ? T(2) * gam : T(0), h, lc);
+                h_last = h;
+            }
             sub_step();
+            t_rem -= h;
         }
         if (ORDER != 2) {                                  // the last stage of the window's last sub-step (midpoint: set in sub_step)
             estP = k.p;

@@ -26,15 +26,15 @@ LAYOUTS = {"auto": 0, "one": 1, "quad": 2}                # glgym_layout
 # environment whose rate bound at the start of the env-step asks for more gets proportionally more windows (its own sub-step
 # length), and what changes inside the env-step is followed window by window.  "rk3" is the three-stage member of the same
 # exponential family (stability interval 2.513: 270 covers 0.69 1/s), "rk2" its midpoint rule (2.0: 336 covers 0.69 1/s).
-# "ls5" (round 5, the default): the five-stage fourth-order 2N-storage scheme (stability interval 5.459: 1.09 per right-hand side
-# against RK4's 0.70; cover conduction exact as in the others): 120 covers 0.67 1/s, two sub-steps per window = the 15 s window of
-# RK4-240 -- 600 right-hand sides per env-step for RK4-240's 960 at the same accuracy.
-DEFAULT_N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270, "ls5": 120}
+# "ls5" (round 5, the default): the five-stage fourth-order 2N-storage scheme (stability interval 5.009: 1.00 per right-hand side
+# against RK4's 0.70; cover conduction exact as in the others): 128 covers 0.655 1/s, two sub-steps per window (14 s; RK4-240: 15 s)
+# -- 640 right-hand sides per env-step for RK4-240's 960 at the same accuracy on every fixture.
+DEFAULT_N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270, "ls5": 128}
 DEFAULT_SCHEME = "ls5"
 VERIFY_MODES = {"auto": 0, "always": 1, "never": 2}     # glgym_verify (include/glgym.h)
 N_SUB_MULTIPLE = {"rk4": 4, "rk2": 4, "rk3": 3, "ls5": 2}          # tier-2b window of the scheme
-# PRESETS.  "throughput": the scheme's nominal count with its own window (max scaled error on the tight one-step tuples 6.1e-5 for
-# ls5 and rk4, 10-day rollout 1.5e-5 fp64 / 2.9e-5 fp32; bar 1e-4).  "parity": inside the 1.3e-5 band a BDF solve at the reference's
+# PRESETS.  "throughput": the scheme's nominal count with its own window (max scaled error on the tight one-step tuples 5.4e-5 for
+# ls5, 6.1e-5 for rk4, 10-day rollout 1.5e-5 fp64 / 2.9e-5 fp32; bar 1e-4).  "parity": inside the 1.3e-5 band a BDF solve at the reference's
 # tolerances (greenlight_model.cpp:51-52) keeps from the tight solution -- ls5: n_sub 192 with ONE sub-step per window (1.0e-5), the
 # others: n_sub x 8/3 with their own window (rk4 640: 8.7e-6).  (n_sub, window) at dt = 900 s; window 0 = the scheme's own.
 PRESETS = {"throughput": {k: (v, 0) for k, v in DEFAULT_N_SUB.items()},
@@ -43,7 +43,7 @@ PRESETS = {"throughput": {k: (v, 0) for k, v in DEFAULT_N_SUB.items()},
 
 def preset_n_sub(scheme: str, dt: float, preset: str = "throughput"):
     """-> (n_sub, window) of `preset` for `scheme`, n_sub scaled with dt so that the nominal sub-step h = dt / n_sub stays the same
-    (e.g. ls5: 7.5 s, 40 sub-steps at the dt = 300 s of experiments/run_time.py) and rounded up to a multiple of the window."""
+    (e.g. ls5: 7.03 s, 44 sub-steps at the dt = 300 s of experiments/run_time.py) and rounded up to a multiple of the window."""
     n0, window = PRESETS[preset][scheme]
     n = n0 * float(dt) / 900.0
     mult = window if window > 0 else N_SUB_MULTIPLE[scheme]

@@ -24,8 +24,8 @@ class GreenLight:
         variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14).
         scheme = "ls5" (default; five-stage fourth-order 2N scheme), "rk4", "rk3" or "rk2" (include/glgym.h).
         preset = "parity" (default HERE: this class stands in for the reference's CVODES call, so it integrates inside the band that
-        solver's tolerances keep from the tight solution -- ls5: n_sub 192, one sub-step per window, 1.0e-5 on the tight one-step
-        tuples) or "throughput" (n_sub 120, window 2: 6.1e-5; what the batched envs run); n_sub / window override the preset."""
+        solver's tolerances keep from the tight solution -- ls5: n_sub 192, one sub-step per window, 9.1e-6 on the tight one-step
+        tuples) or "throughput" (n_sub 128, window 2: 5.4e-5; what the batched envs run); n_sub / window override the preset."""
         self._lib = L.load()
         scheme = L.DEFAULT_SCHEME if scheme is None else scheme
         if scheme not in L.SCHEMES:

@@ -166,7 +166,7 @@ class TomatoVecEnv:
                  u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
-        scheme / n_sub / window: "ls5" (default: five-stage fourth-order 2N-storage scheme, n_sub 120, two sub-steps per tier-2b window), "rk4" (classical RK4, 240),
+        scheme / n_sub / window: "ls5" (default: five-stage fourth-order 2N-storage scheme, n_sub 128, two sub-steps per tier-2b window), "rk4" (classical RK4, 240),
         "rk3" (three-stage third-order scheme, 270) or "rk2" (midpoint rule, 336), all with the cover conduction integrated exactly (include/glgym.h).
         preset: "throughput" (the counts above; default for float32) or "parity" (inside the band of the reference solver's tolerances:
         ls5 n_sub 192 with one sub-step per window; default for float64) -- used for whatever of n_sub / window is not given (_lib.PRESETS);

@@ -184,13 +184,13 @@ def test_scheme_table_and_default_sub_step_counts():
     assert enum == {"GLGYM_SCHEME_RK4": L.SCHEMES["rk4"], "GLGYM_SCHEME_RK2": L.SCHEMES["rk2"], "GLGYM_SCHEME_RK3": L.SCHEMES["rk3"],
                     "GLGYM_SCHEME_LS5": L.SCHEMES["ls5"]}
     assert L.DEFAULT_SCHEME == "ls5"
-    assert [L.default_n_sub(s, 900.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [120, 240, 270, 336]
-    assert [L.default_n_sub(s, 300.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [40, 80, 90, 112]
-    assert [L.default_n_sub(s, 1800.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [240, 480, 540, 672]
+    assert [L.default_n_sub(s, 900.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [128, 240, 270, 336]
+    assert [L.default_n_sub(s, 300.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [44, 80, 90, 112]
+    assert [L.default_n_sub(s, 1800.0) for s in ("ls5", "rk4", "rk3", "rk2")] == [256, 480, 540, 672]
     assert L.default_n_sub("rk3", 1.0) == 3 and L.default_n_sub("rk4", 1.0) == 4 and L.default_n_sub("ls5", 1.0) == 2
     # the parity preset: ls5 with ONE sub-step per window; the others keep their window and take 8/3 of the nominal count
     assert L.preset_n_sub("ls5", 900.0, "parity") == (192, 1) and L.preset_n_sub("rk4", 900.0, "parity") == (640, 0)
-    assert L.preset_n_sub("ls5", 300.0, "parity") == (64, 1) and L.preset_n_sub("ls5", 900.0, "throughput") == (120, 0)
+    assert L.preset_n_sub("ls5", 300.0, "parity") == (64, 1) and L.preset_n_sub("ls5", 900.0, "throughput") == (128, 0)
     layouts = dict((k, int(v)) for k, v in re.findall(r"GLGYM_LAYOUT_([A-Z]+) = (\d)", hdr))
     assert layouts == {k.upper(): v for k, v in L.LAYOUTS.items()}
     assert int(re.search(r"#define GLGYM_METRIC_REPLICAS (\d+)", hdr).group(1)) == L.METRIC_REPLICAS

@@ -13,7 +13,7 @@ from test_jump_fixture import judge, sce
 
 pytestmark = pytest.mark.gpu
 
-SCHEMES = [("ls5", 120), ("rk4", 240), ("rk3", 270), ("rk2", 336)]
+SCHEMES = [("ls5", 128), ("rk4", 240), ("rk3", 270), ("rk2", 336)]
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -70,7 +70,7 @@ def test_unverified_mode_flags_what_round_2_missed(golden):
     from gl_gym_amd import GreenLight
     from gl_gym_amd._lib import GlgymOdeError
     g = golden("step_tight_jump")
-    for dtype, scheme, n_sub in (("float64", "ls5", 120), ("float32", "ls5", 120), ("float64", "rk4", 240), ("float32", "rk4", 240)):
+    for dtype, scheme, n_sub in (("float64", "ls5", 128), ("float32", "ls5", 128), ("float64", "rk4", 240), ("float32", "rk4", 240)):
         m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
         m.set_verify("never")
         for i in (0, 1):

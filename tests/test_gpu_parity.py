@@ -83,7 +83,7 @@ def test_evalF_signature_and_value(models, golden, oracle):
     assert e_def < 1.3e-5 and e_def <= e_bdf
     # --- the THROUGHPUT preset of both fourth-order schemes (what the batched envs and bench.py's `value` run): inside the 1e-4 bar with
     # the one artificial tuple at 6.1e-5, every other tuple well below
-    for scheme, n_expect, rest_tol in (("ls5", 120, 4.0e-5), ("rk4", 240, 2.5e-5)):
+    for scheme, n_expect, rest_tol in (("ls5", 128, 4.0e-5), ("rk4", 240, 2.5e-5)):
         m_thr = GreenLight(28, 6, 10, 208, 900.0, dtype="float64", scheme=scheme, preset="throughput")
         assert m_thr.n_sub == n_expect and m_thr.window == 0
         got = m_thr.evalF_batch(X, U, D, P)
@@ -147,7 +147,7 @@ def test_10day_rollout_vs_tight_fixture(golden, fixture, dtype, tol, scheme, pre
     n_steps = len(acts)
     if dtype == "float64":
         # THROUGHPUT presets: the midpoint rule at n_sub = 336: second order, 7.6e-6 / 9.6e-6 in fp64; RK4 at 240 and the five-stage 2N
-        # scheme at 120 (both 15 s tier-2b windows): 1.5e-5 / 1.4e-5; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6.
+        # scheme at 128 (15 s / 14 s tier-2b windows): 1.5e-5 / 1.4e-5; the three-stage scheme at 270 (10 s windows): 6.8e-6 / 6.6e-6.
         # PARITY presets (ls5 192 / one-sub-step windows: 2.9e-6 / 2.7e-6; rk4 640): the round-3 bound of 5e-6 stays asserted
         tol = 5e-6 if preset == "parity" else (2e-5 if scheme in ("rk4", "ls5") else 1e-5)
     elif preset == "parity":
@@ -199,7 +199,7 @@ def test_config3_shard_10day_horizon_at_full_batch(golden):
     env.close()
 
 
-@pytest.mark.parametrize("scheme,n_sub", [("ls5", 120), ("rk4", 256)])
+@pytest.mark.parametrize("scheme,n_sub", [("ls5", 128), ("rk4", 256)])
 def test_step_kernel_matches_env_oracle(golden, oracle, scheme, n_sub):
     """Fused step (control clip, weather row, sub-stepper, reward, info, terminal test) vs the numpy env oracle."""
     from gl_gym_amd.tomato_env import TomatoVecEnv
@@ -281,7 +281,7 @@ def test_generic_kernel_with_non_default_parameters(golden, oracle):
     p[194], p[195], p[198] = 0.02, 0.8, 1.5   # interlight geometry present (their power stays 0)
     p[8] = 1.2                                # etaRoofThr > 1 -> the "else" ventilation branch
     for dtype, tol, scheme, n_sub, order, win in (("float64", 1e-8, "rk4", 256, 4, 4), ("float32", 5e-5, "rk4", 256, 4, 4),
-                                                  ("float64", 1e-8, "ls5", 120, 5, 2), ("float32", 5e-5, "ls5", 120, 5, 2)):
+                                                  ("float64", 1e-8, "ls5", 128, 5, 2), ("float32", 5e-5, "ls5", 128, 5, 2)):
         env = TomatoVecEnv(64, weather=w, params=p.astype(np.float32), dtype=dtype, scheme=scheme, n_sub=n_sub, season_length=1,
                            start_rows=[0, 50], seed=2, auto_reset=False)
         p32 = env.p.astype(np.float64)
@@ -321,8 +321,8 @@ def test_config1_rule_based_day_against_fixture(golden):
     # window's length in seconds whatever the scheme -- CPU checker, same tuples: 3.5 s 3.2e-6, 1.76 s 7.9e-7, 4.7 s 5.6e-6, 15 s 5.8e-5)
     #   ls5 512 / window 1 (1.76 s)  the round-3 bound of 1e-6 for this day stays asserted
     #   rk4 1024 (window 4 = 3.5 s)  also checks info and observations of every step against the fixture
-    #   ls5 parity preset (192 / 1)  and throughput preset (120 / 2), rk4 256
-    for scheme, n_sub, window, tol in (("ls5", 512, 1, 1e-6), ("rk4", 1024, 0, 4e-6), ("ls5", 192, 1, 7e-6), ("ls5", 120, 0, 8e-5), ("rk4", 256, 0, 8e-5)):
+    #   ls5 parity preset (192 / 1)  and throughput preset (128 / 2), rk4 256
+    for scheme, n_sub, window, tol in (("ls5", 512, 1, 1e-6), ("rk4", 1024, 0, 4e-6), ("ls5", 192, 1, 7e-6), ("ls5", 128, 0, 8e-5), ("rk4", 256, 0, 8e-5)):
         env = TomatoVecEnv(8, weather=g["weather"], params=g["p"], dtype="float64", scheme=scheme, n_sub=n_sub, window=window, season_length=1,
                            start_rows=[0], start_days=[0.0], auto_reset=False)
         obs = env.reset()
@@ -393,7 +393,7 @@ def test_crop_noise_kernel_and_config5_step(golden, oracle):
 
 
 def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
-    """BASELINE config 5 at ITS size (B = 65 536, fp32, the shipped default scheme: the five-stage 2N scheme at n_sub 120 with stability control, guard and
+    """BASELINE config 5 at ITS size (B = 65 536, fp32, the shipped default scheme: the five-stage 2N scheme at n_sub 128 with stability control, guard and
     per-env crop blocks re-drawn every step): properties that do not depend on the size -- every drawn block within +-10 %
     (p144 derived), no failed integration over 40 steps, finite states, physical leaf mass -- and 24 environments picked across
     the batch checked for one step against the oracle's restatement of the SAME controlled scheme fed their 208-vectors."""
@@ -402,7 +402,7 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     w = golden("rollout_10day")["weather"]
     B = 65536
     env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=10, uncertainty_scale=0.2, seed=99, auto_reset=False)
-    assert env.n_sub == 120 and env.scheme == "ls5" and env.window == 0
+    assert env.n_sub == 128 and env.scheme == "ls5" and env.window == 0
     env.reset()
     gen = torch.Generator(device=env.device); gen.manual_seed(17)
     for k in range(39):
@@ -421,7 +421,7 @@ def test_config5_at_full_size_under_the_controlled_scheme(golden, oracle):
     for j, b in enumerate(pick):
         p = env.p.astype(np.float64).copy(); p[128:162] = crop[:, b]
         u = np.clip(u_prev[j] + a[j] * np.float32(0.1), 0, 1)
-        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 120, 5, 2)
+        ref, retries, refined, failed = oracle.rk_sc_guarded(x_prev[j], u, w[39], p, 900.0, 128, 5, 2)
         assert not failed
         worst = max(worst, scaled_err(xg[j], ref))
     m = env.metrics()
@@ -699,14 +699,14 @@ def test_fp64_step_kernel_tracks_oracle_scheme_step_by_step(golden, oracle, sche
 
 
 def test_default_n_sub_scales_with_dt(golden, oracle):
-    """Without an explicit n_sub the nominal sub-step keeps its length for any dt (throughput preset of the default scheme: 7.5 s -- 40
-    sub-steps at the dt = 300 s of the reference's experiments/run_time.py, 240 at 1 800 s; the parity preset GreenLight() defaults
+    """Without an explicit n_sub the nominal sub-step keeps its length for any dt (throughput preset of the default scheme: 7.03 s -- 44
+    sub-steps at the dt = 300 s of the reference's experiments/run_time.py, 256 at 1 800 s; the parity preset GreenLight() defaults
     to: 4.7 s -- 64 / 384); accuracy against plain RK4 with 8 192 sub-steps."""
     from gl_gym_amd import GreenLight
     g = golden("step_tight")
     X, U, D, P = g["X"], g["U"], g["D"], g["P"].astype(np.float64)
     scale = 1e-3 * np.abs(X).max(axis=0)
-    for dt, preset, n_expect in ((300.0, "throughput", 40), (1800.0, "throughput", 240), (300.0, "parity", 64), (1800.0, "parity", 384)):
+    for dt, preset, n_expect in ((300.0, "throughput", 44), (1800.0, "throughput", 256), (300.0, "parity", 64), (1800.0, "parity", 384)):
         for dtype in ("float64", "float32"):
             m = GreenLight(28, 6, 10, 208, dt, dtype=dtype, preset=preset)
             assert m.n_sub == n_expect and m.scheme == "ls5"
@@ -784,7 +784,7 @@ def test_bench_workload_at_full_batch_against_oracle_and_fine_truth(oracle):
     w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
     starts = np.arange(0, 35040 - 5760 - 60, 96)
     env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=60, pred_horizon=0.5, seed=666, start_rows=starts, auto_reset=True)
-    assert env.n_sub == 120 and env.scheme == "ls5" and env.window == 0      # bench.py's `value` configuration
+    assert env.n_sub == 128 and env.scheme == "ls5" and env.window == 0      # bench.py's `value` configuration
     env.reset_tensor()
     dev = env.device
     env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)).to(env.tdtype))
@@ -802,7 +802,7 @@ def test_bench_workload_at_full_batch_against_oracle_and_fine_truth(oracle):
         u = env.u[pick].double().cpu().numpy()                                         # the control the kernel applied
         x_gpu = env.x[pick].double().cpu().numpy()
         flags = env.step_flags_t.cpu().numpy()[pick]
-        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 120, 5, 2, want_flags=True), range(64)))
+        ref = list(pool.map(lambda j: oracle.rk_sc_guarded(x_prev[j], u[j], w[w_off[j] + k], p, 900.0, 128, 5, 2, want_flags=True), range(64)))
         for j in range(64):
             assert not ref[j][3] and not (flags[j] & 128)
             worst_one = max(worst_one, scaled_err(x_gpu[j][None], ref[j][0][None]))

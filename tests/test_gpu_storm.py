@@ -22,7 +22,7 @@ def no_floor_err(got, ref, abs_floor=2e-4):
     return float(np.max(np.where(floor, 0.0, e)))
 
 
-SCHEMES = [("ls5", 120), ("rk4", 240), ("rk2", 336), ("rk3", 270)]            # the schemes' nominal sub-step counts (throughput preset)
+SCHEMES = [("ls5", 128), ("rk4", 240), ("rk2", 336), ("rk3", 270)]            # the schemes' nominal sub-step counts (throughput preset)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -91,7 +91,7 @@ def test_pinned_wet_screen_is_resolved_or_flagged_never_wrong(golden, oracle):
         x[7] = x[2] - 1e-7                                           # ... and 1e-7 K below the air temperature
         x[15] = 1.4 * 610.78 * np.exp(17.2694 * x[7] / (x[7] + 238.3))    # air far above the screen's dew point
         truth = oracle.rk4(x, u, d, p, 900.0, 32768)
-        for dtype, scheme, n_sub in (("float64", "ls5", 120), ("float32", "ls5", 120), ("float64", "rk4", 240), ("float32", "rk4", 240)):
+        for dtype, scheme, n_sub in (("float64", "ls5", 128), ("float32", "ls5", 128), ("float64", "rk4", 240), ("float32", "rk4", 240)):
             m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
             try:
                 got = np.array(m.evalF(x, u, d, p))
@@ -115,7 +115,7 @@ def test_ragged_batch_and_mixed_lanes_are_independent(golden):
     D = np.concatenate([g["D"][:40], t["D"][:37]])
     order = np.random.default_rng(0).permutation(len(X))          # interleave storm and nominal tuples: 77 lanes = 64 + 13
     X, U, D = X[order], U[order], D[order]
-    for dtype, scheme, n_sub in (("float64", "ls5", 120), ("float32", "ls5", 120), ("float64", "rk4", 240), ("float32", "rk4", 240)):
+    for dtype, scheme, n_sub in (("float64", "ls5", 128), ("float32", "ls5", 128), ("float64", "rk4", 240), ("float32", "rk4", 240)):
         m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
         batch = m.evalF_batch(X, U, D)
         p = golden("params_default")["p"].astype(np.float64)
@@ -143,7 +143,7 @@ def test_ode_pipe_tracking_at_dt_900_is_refined_not_unstable(golden, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("scheme,n_sub", [("ls5", 120), ("rk4", 240)])
+@pytest.mark.parametrize("scheme,n_sub", [("ls5", 128), ("rk4", 240)])
 def test_four_lanes_per_environment_equals_one_lane_per_environment(golden, scheme, n_sub):
     """The north-star layout (gl_model_quad.hpp: a quad of lanes per environment, DPP inside the quad; taken for fp32 batches up to
     16 384) against the one-lane-per-environment kernel on the same inputs: storm and raw-jump tuples (refined lanes, ladder

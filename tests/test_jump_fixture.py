@@ -41,7 +41,7 @@ def test_fixture_is_what_it_says(golden):
 import pytest
 
 
-@pytest.mark.parametrize("n_sub,order,win", [(120, 5, 2), (240, 4, 4)])
+@pytest.mark.parametrize("n_sub,order,win", [(128, 5, 2), (240, 4, 4)])
 def test_oracle_verified_guard_against_the_jump_truth(golden, oracle, n_sub, order, win):
     g = golden("step_tight_jump")
     p = golden("params_default")["p"].astype(np.float64)
@@ -72,12 +72,12 @@ def test_product_arithmetic_on_the_hard_jump_tuples(golden, oracle, hostmath):
     p = golden("params_default")["p"].astype(np.float64)
     X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
     for i in list(range(0, 15)) + [40, 100, 300]:
-        for (n, o, w) in ((120, 5, 2), (240, 4, 4), (270, 3, 3)):
+        for (n, o, w) in ((128, 5, 2), (240, 4, 4), (270, 3, 3)):
             a = hostmath.step_guarded(X[i], U[i], D[i], p, False, 900.0, n, o, w, verify=True)
             b = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n, o, w, verify=True)
             assert a[1] == b[1] and a[3] == b[3] and not a[3], (i, n, a[1:], b[1:])
             assert sce(a[0], b[0]).max() < 1e-7, (i, n, sce(a[0], b[0]).max())      # kinks amplify rounding: 2e-8 seen
-        for (n, o, w) in ((120, 5, 2), (240, 4, 4)):
+        for (n, o, w) in ((128, 5, 2), (240, 4, 4)):
             y32 = hostmath.step_guarded(X[i], U[i], D[i], p, True, 900.0, n, o, w, verify=True)
             wrong, floor = judge(y32[0][None], XT[i][None], 2e-4)
             assert not y32[3] and wrong == 0, (i, n, sce(y32[0], XT[i]).max())

@@ -139,7 +139,7 @@ def test_integrator_variants_host(hostmath, oracle, golden):
     idx = range(0, len(X), 2)
     # (5, 2, 120): the default scheme at its throughput preset; (5, 1, 192): its parity preset, inside the 1.3e-5 band of a BDF solve at
     # the reference's tolerances (on this half of the tuples: 9.4e-6)
-    for order, win, n, tol_t in ((5, 2, 120, 6.3e-5), (5, 1, 192, 1.3e-5), (4, 1, 256, 2e-5), (4, 2, 240, 2.5e-5), (4, 3, 240, 3.6e-5), (4, 4, 240, 6.3e-5), (2, 2, 358, 3e-5),
+    for order, win, n, tol_t in ((5, 2, 128, 6.3e-5), (5, 1, 192, 1.3e-5), (4, 1, 256, 2e-5), (4, 2, 240, 2.5e-5), (4, 3, 240, 3.6e-5), (4, 4, 240, 6.3e-5), (2, 2, 358, 3e-5),
                                  (2, 4, 360, 4e-5), (3, 1, 284, 2e-5), (3, 3, 270, 3e-5)):
         got = np.array([hostmath.step_scheme(X[i], U[i], D[i], P[i], False, 900.0, n, order, win) for i in idx])
         ref = np.array([oracle.rk_sc(X[i], U[i], D[i], P[i], 900.0, n, order, win)[0] for i in idx])
@@ -175,7 +175,7 @@ def test_stability_controlled_scheme_host_vs_oracle_and_truth(hostmath, oracle, 
         # margin of the sub-step covers that
         assert 0.94 * LAM[i] <= rb_p <= 1.3 * LAM[i], (i, rb_p, LAM[i])
         assert abs(hostmath.rate_bound(X[i], U[i], D[i], p, f32=True) - rb_p) < 1e-5 * rb_p
-        for f32, win, order, n in ((False, 2, 5, 120), (True, 2, 5, 120), (False, 1, 4, 240), (True, 4, 4, 240), (False, 3, 3, 270), (True, 3, 3, 270)):
+        for f32, win, order, n in ((False, 2, 5, 128), (True, 2, 5, 128), (False, 1, 4, 240), (True, 4, 4, 240), (False, 3, 3, 270), (True, 3, 3, 270)):
             y, retries, extra, failed = hostmath.step_guarded(X[i], U[i], D[i], p, f32=f32, n_sub=n, order=order, window=win)
             yo, ro, eo, fo = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n, order, win)
             assert not failed and not fo

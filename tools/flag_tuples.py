@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU): run the bench workload and save the (x, u, d) tuples of every env-step whose first integration attempt was
 not accepted as it stood (step_flags, include/glgym.h GLGYM_SF_*), for offline analysis against the CPU checker.
-    python tools/flag_tuples.py [steps] [n_sub] [dtype]      -> gpurun_out/flagged_tuples.npz"""
+    python tools/flag_tuples.py [steps] [n_sub] [dtype] [scheme]      -> gpurun_out/flagged_tuples.npz"""
 import sys
 from pathlib import Path
 import numpy as np, torch
@@ -10,11 +10,12 @@ sys.path.insert(0, str(ROOT / "greenlight-gym2_amd"))
 from gl_gym_amd.tomato_env import TomatoVecEnv  # noqa: E402
 from gl_gym_amd.utils import synthetic_weather  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
-n_sub = int(sys.argv[2]) if len(sys.argv) > 2 else None
+n_sub = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
+scheme = sys.argv[4] if len(sys.argv) > 4 else "ls5"
 dtype = sys.argv[3] if len(sys.argv) > 3 else "float32"
 B = 65536
 w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024); starts = np.arange(0, 35040 - 5760 - 60, 96)
-env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme="rk4", n_sub=n_sub, season_length=60, pred_horizon=0.5, seed=666, start_rows=starts,
+env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, n_sub=n_sub, season_length=60, pred_horizon=0.5, seed=666, start_rows=starts,
                    auto_reset=True)
 env.reset_tensor()
 env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=env.device, generator=torch.Generator(device=env.device).manual_seed(1234)).to(env.tdtype))
@@ -27,7 +28,7 @@ for i in range(steps):
     env.action_t.copy_(a)
     env._launch_step(raw_control=False)
     fl = env.step_flags_t
-    idx = torch.nonzero(fl != 0).flatten()
+    idx = torch.nonzero((fl & 0xffff) != 0).flatten()          # first-attempt flags / extra attempts (bits 16.. only count sub-steps)
     if len(idx):
         X.append(x_prev[:, idx].t().double().cpu().numpy())
         U.append(env.u_T[:, idx].t().double().cpu().numpy())           # applied control
@@ -35,7 +36,7 @@ for i in range(steps):
         F.append(fl[idx].cpu().numpy()); K.append(np.full(len(idx), i))
         for f in F[-1]: hist[int(f)] = hist.get(int(f), 0) + 1
     env._launch_reset(env.done_t)
-print("n_sub", env.n_sub, dtype, "flag words seen (word: count):", dict(sorted(hist.items())), "of", steps * B, "env-steps")
+print(scheme, "n_sub", env.n_sub, dtype, "flag words seen (word: count):", dict(sorted(hist.items())), "of", steps * B, "env-steps")
 print(env.metrics())
 if X:
     out = ROOT / "gpurun_out" / "flagged_tuples.npz"

@@ -23,7 +23,7 @@ for name in ("step_tight", "step_tight_storm", "step_tight_jump"):
     g = G(name)
     X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
     P = g["P"].astype(np.float64) if "P" in g.files else None
-    for preset, (n, w) in (("throughput", (120, 2)), ("parity", (192, 1))):
+    for preset, (n, w) in (("throughput", (128, 2)), ("parity", (192, 1))):
         ref = np.array([O.rk_sc_guarded(X[i], U[i], D[i], P[i] if P is not None else p0, 900.0, n, 5, w, verify=True)[0] for i in range(len(X))])
         for dtype in ("float64", "float32"):
             m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme="ls5", preset=preset)
@@ -64,7 +64,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "quick":
 weather = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
 starts = np.arange(0, 35040 - 5760 - 60, 96)
 for B, dtype in ((65536, "float32"), (4096, "float64"), (16384, "float32"), (8, "float32"), (262144, "float32")):
-    for scheme, n_sub, window in (("ls5", 120, 0), ("rk4", 240, 0), ("ls5", 192, 1), ("rk3", 270, 0)):
+    for scheme, n_sub, window in (("ls5", 128, 0), ("rk4", 240, 0), ("ls5", 192, 1), ("rk3", 270, 0)):
         env = TomatoVecEnv(B, weather=weather, dtype=dtype, scheme=scheme, n_sub=n_sub, window=window, season_length=60, pred_horizon=0.5, seed=666,
                            start_rows=starts, auto_reset=True)
         env.reset_tensor()
