@@ -1672,6 +1672,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WINR), hmin = hnom * T(1.0 / SC_MAX_REFINE);
     int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
+    T winc[NX];                     // ORDER 5: the fast states' increments of the current window (added to del at its end)
     // the integrator works in the coordinates of rhs_fast<WETDIFF>: slots 5, 7, 20 = tTop - tCovIn, tAir - tThScr, tAir - tBlScr;
     // with COVEXP slot 6 = w = tCovIn - tCovE
     T z0[NX];
@@ -1772,14 +1773,14 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // third of the limit may move 3 K per sub-step, a lane at the limit 1 K as before.  On the bench workload the limiter then
         // acts in 1 % of the env-steps instead of 20 % (those were lanes with rates of 0.15-0.3 1/s whose vapour pressure or CO2
         // moved fast: nothing to go stale); at one wave per SIMD the launch waits for its slowest lane.
-        auto fast_move = [&](const T* kk) {
+        auto fast_move = [&](const T* kk, T w_at) {
             T mv = T(0);
 #pragma unroll
             for (int j = 0; j < SC_NFAST; ++j)
                 if (j != 7) {
                     T kj = kk[sc_fast(j)];
-                    if (COVEXP && sc_fast(j) == 5) kj = kk[5] - T(0.5) * kk[6] + gamCov * y[6];              // d(tTop - tCovIn)/dt
-                    if (COVEXP && sc_fast(j) == 6) kj = (kk[3] - kk[5]) - T(0.5) * kk[6] + gamCov * y[6];     // d(tCovE)/dt
+                    if (COVEXP && sc_fast(j) == 5) kj = kk[5] - T(0.5) * kk[6] + gamCov * w_at;              // d(tTop - tCovIn)/dt
+                    if (COVEXP && sc_fast(j) == 6) kj = (kk[3] - kk[5]) - T(0.5) * kk[6] + gamCov * w_at;     // d(tCovE)/dt
                     mv = M::max(mv, M::abs(kj) * T(sc_itol(j)));
                 }
             return mv;
@@ -1788,7 +1789,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         if (ORDER == 5) move_allow = T(SC_MOVE) * M::min(M::max(S * M::rcp(lam * hnom), T(1)), T(SC_MOVE_HMAX));
         bool limited0;
         {
-            const T mv = fast_move(k);
+            const T mv = fast_move(k, y[6]);
             limited0 = mv * hs > move_allow;
             hs = limited0 ? move_allow * M::rcp(mv) : hs;
         }
@@ -1806,6 +1807,18 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // whether the code runs at all.
         const bool adaptive = (ORDER == 5) && limited0 && !capped;
         T t_rem = hw;
+        // ORDER 5: the fast states' increments of this WINDOW are accumulated apart (winc; stage input = y + winc with y = z0 + del of
+        // the window's start) and reach del once, at the window's end.  The 2N scheme adds five stage increments per sub-step where
+        // RK4 adds one, and on a deep-pinned wet surface (1e4 sub-steps of 0.02 s per env-step) those roundings are what the result
+        // is made of: added to del one by one they cost the fp32 kernel four gross tuples of 2 552 in the saddle-node corner
+        // (tests/test_gpu_stress.py) where RK4 has one.  Within a window the accumulator is ~50x smaller than del, so is each
+        // rounding -- and the instruction count per stage is that of the direct form (one add for the stage input, one FMA for the
+        // accumulator; z0 and del rest during the sub-steps).
+        T w_now = y[6];                                            // w at the start of the sub-step about to be taken
+        if (ORDER == 5) {
+#pragma unroll
+            for (int p = 0; p < GL_NPAIR_FAST; ++p) RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(winc, r.sp(T(0))); });
+        }
         if (COVEXP && h != h_ec) {
             if (ORDER == 5) ls_coefs<T>(T(2) * gamCov, h, lc); else etd_coefs<T>(T(2) * gamCov, h, ec);
             h_ec = h;
@@ -1814,9 +1827,9 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         auto sub_step = [&]() {
             const T h2 = T(0.5) * h;
             if (ORDER == 5) {
-                // the five-stage 2N scheme: acc holds dy / h (dy' <- A_i dy' + k, del <- del + (B_i h) dy'); the stage input is z0 + del.
+                // the five-stage 2N scheme: acc holds dy / h (dy' <- A_i dy' + k, winc <- winc + (B_i h) dy'); the stage input is y + winc.
                 // Slot 6 (w) by the exponential form above, slot 5 (tTop - tCovIn) assembled from the classical part k[5] and w's increments
-                const T w0 = y[6], N0 = k[6];
+                const T w0 = w_now, N0 = k[6];
                 const T F0 = N0 - (T(2) * gamCov) * w0;                  // dw/dt at the start of the sub-step
                 // linear predictor of the forcing: slope from the previous sub-step's start value, only when this sub-step is at most
                 // twice as long as that one (a slope measured over a refined sub-step must not be carried over a nominal one)
@@ -1824,27 +1837,28 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 ls_Nprev = N0; ls_hprev = h;
                 const T slope_ia = slope * M::rcp(T(2) * gamCov);       // slope / a: d2phi_st slope = (h dc_st - dphi_st) slope / a
                 T vv = T(0), dv = T(0);
-#if defined(GL_LS5_ROLL)
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
                 for (int stg = 0; stg < 5; ++stg) {
-                    if (stg > 0) { state_now(); rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k); }
+                    if (stg > 0) {
+#pragma unroll
+                        for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                            RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.ld(winc)); });
+                        rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);
+                    }
                     const T Ai = T(Ls5<T>::A(stg)), Bi = T(Ls5<T>::B(stg)), Bh = Bi * h;
 #pragma unroll
                     for (int p = 0; p < GL_NPAIR_FAST; ++p)
                         if (p != 3)
                             RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) {
-                                r.st(acc, stg == 0 ? r.ld(k) : r.sp(Ai) * r.ld(acc) + r.ld(k)); r.st(del, r.ld(del) + r.sp(Bh) * r.ld(acc)); });
+                                r.st(acc, stg == 0 ? r.ld(k) : r.sp(Ai) * r.ld(acc) + r.ld(k)); r.st(winc, r.ld(winc) + r.sp(Bh) * r.ld(acc)); });
                     acc[5] = (stg == 0) ? k[5] : Ai * acc[5] + k[5];
                     dv = (stg == 0) ? T(0) : Ai * dv + h * ((k[6] - N0) - slope * (T(Ls5<T>::c(stg)) * h));
                     const T vnext = lc.E[stg] * (vv + Bi * dv);
                     dv = lc.E[stg] * dv;
                     const T dW = lc.dphi[stg] * F0 + (h * T(Ls5<T>::c(stg + 1) - Ls5<T>::c(stg)) - lc.dphi[stg]) * slope_ia + (vnext - vv);
                     vv = vnext;
-                    del[6] += dW;
-                    del[5] += Bh * acc[5] - T(0.5) * dW;
+                    winc[6] += dW;
+                    winc[5] += Bh * acc[5] - T(0.5) * dW;
                 }
 #pragma unroll
                 for (int p = GL_NPAIR_FAST; p < GL_NPAIR; ++p)          // constant-rate states
@@ -1968,11 +1982,19 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
         for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
         for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
-            state_now();
-            rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);                // same tier 2b
+            if (ORDER == 5) {
+#pragma unroll
+                for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                    RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(xs, r.ld(y) + r.ld(winc)); });
+                w_now = xs[6];
+                rhs_stage<T, PIPE, false, COVEXP>(xs, q, s, m, cr, k);           // same tier 2b
+            } else {
+                state_now();
+                rhs_stage<T, PIPE, false, COVEXP>(y, q, s, m, cr, k);            // same tier 2b
+            }
             if (ORDER == 5 && GL_WAVE_ANY(adaptive)) {
                 // the limiter again, with this sub-step's first stage; the rest of the window re-partitioned (rk_sc_impl restates it)
-                const T mvj = fast_move(k);
+                const T mvj = fast_move(k, w_now);
                 T hsj = (mvj * hs_stab > move_allow) ? move_allow * M::rcp(mvj) : hs_stab;
                 hsj = !(hsj >= hmin) ? hmin : hsj;
                 T nn = M::max(T(1), ceil_pos(t_rem * M::rcp(hsj) - T(1e-3)));
@@ -1994,6 +2016,11 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             for (int j = 0; j < SC_NFAST; ++j) est[j] = (ORDER != 2) ? k[sc_fast(j)] : est[j] + T(2.0) * k[sc_fast(j)];
         }
         // ---- window end: increment of the window's RK part (harvest excluded), harvest flow
+        if (ORDER == 5) {
+#pragma unroll
+            for (int p = 0; p < GL_NPAIR_FAST; ++p)
+                RkVec<T>::pair(gl_pair_a(p), gl_pair_b(p), [&](auto r) { r.st(del, r.ld(del) + r.ld(winc)); });
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dwin[gl_slow_slot(i)];

@@ -92,14 +92,16 @@ template <class T> struct QVec { P2<T> p; T sh[6]; T o[4]; };
 template <class T> struct LaneK {
     P2<T> cA, nA, cA2, nA2, sgA;   // exchange with node A: c |sg dA + eps|^n dA; the "2" set applies where dA < 0 (the floor's two regimes)
     P2<T> cB;                      // second exchange (to the top compartment): the two screens
-    P2<T> src, iCap, wetC, mAir, mTop, trK;
+    P2<T> src, iCap, wetC, mAir;
+    T mTopX, trKx;                 // x components of the "exchanges with the top compartment" mask and of the transpiration coefficient (y: always 0)
     P2<T> firX[4], firY[4];        // C[own x|y][lane s .x] and C[own x|y][lane s .y]
     P2<T> cSky;
     P2<T> iC;                      // interlight long-wave coefficients of the pair (zero power in the reference; geometry may be present)
     T ro[4];                       // rates of the lane's constant-rate states (tier 2b)
     // ETD coefficients of the pair's y component for the sub-step in use (rk_delta_quad; part of this record so that the fp64
-    // build keeps them in LDS with the rest of it): cover lane a = 2 cCovCond / capCov, every other lane a = 0 = classical RK4
-    EtdCoef<T> ec;
+    // build keeps them in LDS with the rest of it): cover lane a = 2 cCovCond / capCov, every other lane a = 0 = the classical scheme.
+    // RK4 / three-stage / midpoint: ec; the five-stage 2N scheme: lc (same storage)
+    union { EtdCoef<T> ec; LsCoef<T> lc; };
 };
 
 template <class T>
@@ -128,8 +130,8 @@ __device__ __forceinline__ void gq_make_lane(int role, const StepCoef<T>& s, con
     K.iCap = gq_mk<T>(pk(q.iCapCan, m.iCapFlr, m.iCapThScr, m.iCapCov), pk(m.iCapPipe, m.iCapLamp, m.iCapBlScr, m.iCapCov));
     K.wetC = gq_mk<T>(pk(z, z, L64, L64), pk(z, z, L64, z));
     K.mAir = gq_mk<T>(pk(one, one, one, z), pk(one, one, one, z));
-    K.mTop = gq_mk<T>(pk(z, z, z, one), z);
-    K.trK = gq_mk<T>(pk(q.mvCanK, z, z, z), z);
+    K.mTopX = pk(z, z, z, one);
+    K.trKx = pk(q.mvCanK, z, z, z);
     K.iC = gq_mk<T>(pk(q.iCan, q.iFlr, q.iThScr, q.iCovIn), pk(q.iPipe, q.iLamp, q.iBlScr, z));
     K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
     K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
@@ -184,9 +186,9 @@ __device__ __forceinline__ void gq_make_lane_step(int role, const StepCoef<T>& s
     K.iCap = gq_mk<T>(LS.iCapx, pk(m.iCapPipe, m.iCapLamp, m.iCapBlScr, m.iCapCov));
     K.wetC = gq_mk<T>(pk(z, z, L64, L64), pk(z, z, L64, z));
     K.mAir = gq_mk<T>(pk(one, one, one, z), pk(one, one, one, z));
-    K.mTop = gq_mk<T>(pk(z, z, z, one), z);
+    K.mTopX = pk(z, z, z, one);
     K.src = gq_mk<T>(z, pk(s.hBoilPipe, s.lampNet, z, s.sunCovE));
-    K.trK = gq_mk<T>(z, z);
+    K.trKx = z;
     K.iC = gq_mk<T>(z, z);
 }
 template <class T>
@@ -205,7 +207,7 @@ __device__ __forceinline__ void gq_make_lane_win(int role, const StepCoef<T>& s,
     K.cA2 = gq_mk<T>(lane0 ? q.hCanAirK : K.cA2.x, K.cA2.y);
     K.iCap = gq_mk<T>(lane0 ? q.iCapCan : LS.iCapx, K.iCap.y);
     K.src = gq_mk<T>(pk(q.swCan + q.rGroPipeCan, q.swFlr - q.hFlrSo1, z, z), K.src.y);
-    K.trK = gq_mk<T>(lane0 ? q.mvCanK : z, z);
+    K.trKx = lane0 ? q.mvCanK : z;
     if (m.intLampActive) K.iC = gq_mk<T>(pk(q.iCan, q.iFlr, q.iThScr, q.iCovIn), pk(q.iPipe, q.iLamp, q.iBlScr, z));
     K.ro[0] = pk(z, q.dSo3, q.dBuf, z); K.ro[1] = pk(z, q.dSo4, q.dLeaf, z);
     K.ro[2] = pk(q.dSo1, q.dSo5, q.dStem, z); K.ro[3] = pk(q.dSo2, q.dGro, q.dFruit, z);
@@ -280,17 +282,18 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T co2Dev = m.etaMgPpm * co2Air - T(200);
     const T rfCo2 = M::min(T(1.5), one + s.cEvap3 * (co2Dev * co2Dev));
     const T rfVp = M::min(T(5.8), one + s.cEvap4 * (vpd * vpd));
-    const T mvCan = vpd * K.trK.x * M::rcpn(m.rB + s.rSK * rfCo2 * rfVp);
+    const T mvCan = vpd * K.trKx * M::rcpn(m.rB + s.rSK * rfCo2 * rfVp);
     // ---- the pair's balances
     const T L = m.latent;
     const P2<T> net = K.src + fir + fluxA + gq_sp<T>(L) * mv - fluxB + gq_mk<T>(-(L * mvCan), T(0));
     const P2<T> dTp = K.iCap * net;
     // ---- sums the air / top balances need
-    const P2<T> fa = fluxA * K.mAir, ft = fluxA * K.mTop, ma = mv * K.mAir, mt = mv * K.mTop;
+    const P2<T> fa = fluxA * K.mAir, ma = mv * K.mAir;
+    const T ftx = fluxA.x * K.mTopX, mtx = mv.x * K.mTopX;       // (the y components of that mask are 0 on every lane)
     const T sHeatAir = gq_sum(-(fa.x + fa.y));
-    const T sHeatTop = gq_sum((fluxB.x + fluxB.y) - (ft.x + ft.y));
+    const T sHeatTop = gq_sum((fluxB.x + fluxB.y) - ftx);
     const T sVapAir = gq_sum(mvCan - (ma.x + ma.y));
-    const T sVapTop = gq_sum(-(mt.x + mt.y));
+    const T sVapTop = gq_sum(-mtx);
     const T tCan = gq_bcast<0>(Tp.x);
     // ---- air side (identical in the four lanes): ventilation, screen air flux, air streams (rhs_fast)
     const T dTOut = tAir - s.tOut;
@@ -430,7 +433,6 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     T hw = dt / T(n_win), hnom = hw / T(WINR);
     int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
     const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
-    LsCoef<T> lc;                 // ORDER 5: the pair's y component by the exponential 2N formulas (gl_model.hpp ls_coefs), in registers
     T ls_Nprev = T(0), ls_hprev = T(0);       // ORDER 5, cover lane: N_w at the start of the previous sub-step and its length (0: none yet)
     const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
     const T gam = m.iCapCov * m.cCovCond, cw = cov ? T(0.5) : T(0);
@@ -454,6 +456,13 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     auto harvest = [&](T hh) {
         const T a = harvest_flow(z0.o[1] + del.o[1], cr.cLeafMax, hh), b = harvest_flow(z0.o[3] + del.o[3], cr.cFruitMax, hh);
         del.o[1] += crop ? a : T(0); del.o[3] += crop ? b : T(0);
+    };
+    QVec<T> winc;                 // ORDER 5: the window's increments (see the sub-step loop)
+    T w_now = T(0);               // ORDER 5: the pair's y component at the start of the sub-step about to be taken
+    auto stage_in = [&]() {       // ORDER 5: xs = y + winc (y = z0 + del of the window's start)
+        xs.p = y.p + winc.p;
+        for (int i = 0; i < 6; ++i) xs.sh[i] = y.sh[i] + winc.sh[i];
+        xs.o[0] = y.o[0] + winc.o[0]; xs.o[1] = y.o[1] + winc.o[1]; xs.o[2] = y.o[2]; xs.o[3] = y.o[3];
     };
     auto state_now = [&]() { y.p = z0.p + del.p; for (int i = 0; i < 6; ++i) y.sh[i] = z0.sh[i] + del.sh[i]; for (int j = 0; j < 4; ++j) y.o[j] = z0.o[j] + del.o[j]; };
     // the cover lane's derivatives of (tTop - tCovIn, tCovE) from the integrator's (classical part of slot 5, N_w): rk_delta's movement limiter
@@ -539,7 +548,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         const bool adaptive = (ORDER == 5) && limited0 && !capped;
         T t_rem = hw;
         if (h != h_last) {
-            if (ORDER == 5) ls_coefs<T>(cov ? T(2) * gam : T(0), h, lc); else etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
+            if (ORDER == 5) ls_coefs<T>(cov ? T(2) * gam : T(0), h, K.lc); else etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
         }
         h_last = h;
         // one sub-step from (y, k = f(y)): the classical scheme on the pair's x component, the shared states and lane 0's / lane 3's first
@@ -547,7 +556,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         // cover lane), the cover lane's x assembled from tTop, sigma and w (rk_delta), constant rate for the rest
         auto sub_step = [&]() {
             const T h2 = T(0.5) * h, h6 = h * T(1.0 / 6.0);
-            const T w0 = y.p.y, n1 = k.p.y;
+            const T w0 = (ORDER == 5) ? w_now : y.p.y, n1 = k.p.y;
             const bool full01 = lane0 || role == 3;
             auto fill = [&](T c, T dW) {
                 xs.p = gq_mk<T>(y.p.x + c * k.p.x - cw * dW, w0 + dW);
@@ -567,21 +576,21 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                 T vv = T(0), dv = T(0);
 #pragma unroll
                 for (int stg = 0; stg < 5; ++stg) {
-                    if (stg > 0) { state_now(); GQ_FENCE(); gq_stage<T, false, PIPE>(role, y, K, s, m, q, k, nullptr); }
+                    if (stg > 0) { stage_in(); GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr); }
                     const T Ai = T(Ls5<T>::A(stg)), Bi = T(Ls5<T>::B(stg)), Bh = Bi * h;
                     acc.p.x = (stg == 0) ? k.p.x : Ai * acc.p.x + k.p.x;
-                    for (int i = 0; i < 6; ++i) { acc.sh[i] = (stg == 0) ? k.sh[i] : Ai * acc.sh[i] + k.sh[i]; del.sh[i] += Bh * acc.sh[i]; }
+                    for (int i = 0; i < 6; ++i) { acc.sh[i] = (stg == 0) ? k.sh[i] : Ai * acc.sh[i] + k.sh[i]; winc.sh[i] += Bh * acc.sh[i]; }
                     acc.o[0] = (stg == 0) ? k.o[0] : Ai * acc.o[0] + k.o[0]; acc.o[1] = (stg == 0) ? k.o[1] : Ai * acc.o[1] + k.o[1];
                     dv = (stg == 0) ? T(0) : Ai * dv + h * ((k.p.y - n1) - slope * (T(Ls5<T>::c(stg)) * h));
-                    const T vnext = lc.E[stg] * (vv + Bi * dv);
-                    dv = lc.E[stg] * dv;
-                    const T dW = lc.dphi[stg] * F0 + (h * T(Ls5<T>::c(stg + 1) - Ls5<T>::c(stg)) - lc.dphi[stg]) * slope_ia + (vnext - vv);
+                    const T vnext = K.lc.E[stg] * (vv + Bi * dv);
+                    dv = K.lc.E[stg] * dv;
+                    const T dW = K.lc.dphi[stg] * F0 + (h * T(Ls5<T>::c(stg + 1) - Ls5<T>::c(stg)) - K.lc.dphi[stg]) * slope_ia + (vnext - vv);
                     vv = vnext;
-                    del.p = gq_mk<T>(del.p.x + Bh * acc.p.x - cw * dW, del.p.y + dW);
-                    del.o[0] += full01 ? Bh * acc.o[0] : T(0);
-                    del.o[1] += full01 ? Bh * acc.o[1] : T(0);
+                    winc.p = gq_mk<T>(winc.p.x + (Bh * acc.p.x - cw * dW), winc.p.y + dW);
+                    winc.o[0] += full01 ? Bh * acc.o[0] : T(0);
+                    winc.o[1] += full01 ? Bh * acc.o[1] : T(0);
                 }
-                del.o[0] += full01 ? T(0) : h * k.o[0];
+                del.o[0] += full01 ? T(0) : h * k.o[0];          // constant-rate "others" of lanes 1 / 2: straight into del
                 del.o[1] += full01 ? T(0) : h * k.o[1];
             } else if (ORDER == 4) {
                 T dWa, accW;
@@ -645,14 +654,24 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             del.o[2] += h * k.o[2]; del.o[3] += h * k.o[3];
             ++n_steps;
         };
+        // ORDER 5: the window's increments of the pair, the shared states and (lanes 0 / 3) the first two "others" are accumulated apart
+        // and reach del at the window's end; the stage input is y + winc (rk_delta: rounding)
+        if (ORDER == 5) { winc.p = gq_sp<T>(T(0)); for (int i = 0; i < 6; ++i) winc.sh[i] = T(0); winc.o[0] = T(0); winc.o[1] = T(0); }
+        w_now = y.p.y;
         sub_step();
         t_rem -= h;
         for (n_rem -= T(1); n_rem >= T(0.5); n_rem -= T(1)) {
-            state_now();
-            GQ_FENCE(); gq_stage<T, false, PIPE>(role, y, K, s, m, q, k, nullptr);
+            if (ORDER == 5) {
+                stage_in();
+                w_now = xs.p.y;
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, xs, K, s, m, q, k, nullptr);
+            } else {
+                state_now();
+                GQ_FENCE(); gq_stage<T, false, PIPE>(role, y, K, s, m, q, k, nullptr);
+            }
             if (ORDER == 5 && GL_WAVE_ANY(adaptive)) {
                 // the limiter again with this sub-step's first stage; the rest of the window re-partitioned (rk_delta, decision for decision)
-                const T mvj = gq_max(gq_fast_max(true_rates(k, y), gq_tol<T>(role).mov));
+                const T mvj = gq_max(gq_fast_max(true_rates(k, xs), gq_tol<T>(role).mov));
                 T hsj = (mvj * hs_stab > move_allow) ? move_allow * M::rcp(mvj) : hs_stab;
                 hsj = !(hsj >= hmin) ? hmin : hsj;
                 T nn = M::max(T(1), ceil_pos(t_rem * M::rcp(hsj) - T(1e-3)));
@@ -662,7 +681,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
                 nn = (grow && nn < T(2)) ? T(2) : nn;
                 h = adaptive ? hj : h;
                 n_rem = adaptive ? nn : n_rem;
-                if (h != h_last) ls_coefs<T>(cov ? T(2) * gam : T(0), h, lc);
+                if (h != h_last) ls_coefs<T>(cov ? T(2) * gam : T(0), h, K.lc);
                 h_last = h;
             }
             sub_step();
@@ -673,6 +692,11 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             for (int i = 0; i < 6; ++i) estS[i] = k.sh[i];
         }
         // ---- window end
+        if (ORDER == 5) {
+            del.p = del.p + winc.p;
+            for (int i = 0; i < 6; ++i) del.sh[i] += winc.sh[i];
+            del.o[0] += winc.o[0]; del.o[1] += winc.o[1];
+        }
         {
             T end7[7];
             slow7(del, end7);

@@ -96,17 +96,22 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     right-hand sides than RK4 at RK4-like accuracy (the error of both is set by the slow tier's window, not by the order); the
  *     slow sub-expressions and the harvest flow are shared by three nominal sub-steps (n_sub is rounded up to a multiple of 3).
  *     (Rounds 2-3 shipped Bogacki-Shampine 3(2) with the conduction in its right-hand side at n_sub 354 under this name.)
- *   GLGYM_SCHEME_LS5 (round 5): a FIVE-stage FOURTH-order explicit Runge-Kutta scheme in Williamson's 2N-storage form (two registers per
- *     state: dy <- A_i dy + h f(y), y <- y + B_i dy).  The 2N five-stage fourth-order family has one free parameter, the z^5 coefficient
- *     of its stability polynomial; Carpenter-Kennedy's published member (1/200) has a real-axis stability interval of 4.657, the member
- *     used here (0.0044) 5.4588 with |R| <= 0.5 at its working point: 1.09 per right-hand side against RK4's 0.70.  The cover conduction is
- *     integrated exactly here too (Lawson's transformation applied to the deviation of the forcing from its value at the start of the
- *     sub-step: exact for a frozen forcing, no stage history).  Use n_sub 120 (7.5 s sub-steps: rates up to 0.67 1/s); the slow
- *     sub-expressions and the harvest flow are shared by TWO nominal sub-steps (15 s, the window RK4-240 runs with): 600 right-hand sides
- *     + 60 windows per env-step where RK4 takes 960 + 60, at RK4's accuracy on every fixture (tight one-step tuples 6.1e-5, 10-day
- *     rollout 1.5e-5 in fp64 -- the same figures as GLGYM_SCHEME_RK4 at 240).  PARITY preset: n_sub 192 with glgym_set_window(h, 1):
- *     1.0e-5 on the tight one-step tuples, inside the 1.3e-5 band of a BDF solve at the reference's tolerances, at 960 right-hand sides
- *     + 192 windows (RK4 needs n_sub 640: 2 560 + 160).  oracle/studies/lsrk_study.py, DESIGN.md section 2.7. */
+ *   GLGYM_SCHEME_LS5 (round 5; the Python layer's default): a FIVE-stage FOURTH-order explicit Runge-Kutta scheme in Williamson's 2N-storage
+ *     form (two registers per state: dy <- A_i dy + h f(y), y <- y + B_i dy).  The 2N five-stage fourth-order family has one free
+ *     parameter, the z^5 coefficient of its stability polynomial; Carpenter-Kennedy's published member (1/200) has a real-axis stability
+ *     interval of 4.657, the member used here (0.0047) 5.009 with |R| <= 0.28 at its working point: 1.00 per right-hand side against
+ *     RK4's 0.70.  (Members with a longer interval settle on spurious quasi-steady states of the strongly ventilated top compartment
+ *     beyond h lambda ~ 4.1; this one shows none up to its limit.)  The cover conduction is integrated exactly here too (Lawson's
+ *     transformation applied to the deviation of the forcing from a linear predictor: exact for a linearly varying forcing, no stage
+ *     history).  Use n_sub 128 (7.03 s sub-steps: rates up to 0.655 1/s); the slow sub-expressions and the harvest flow are shared by TWO
+ *     nominal sub-steps (14 s; RK4-240: 15 s): 640 right-hand sides + 64 windows per env-step where RK4 takes 960 + 60, at RK4's accuracy
+ *     or better on every fixture (tight one-step tuples 5.4e-5, 10-day rollout 1.3e-5 in fp64; RK4 at 240: 6.1e-5 / 1.5e-5) and on the wide
+ *     random stress (43 of 5 954 one-step maps above 1e-4 against RK4-240's 49).  Its stability control differs from the other schemes' in
+ *     two measured points: the movement limiter's allowance grows with the head-room the window's rate bound leaves below the stability
+ *     limit, and a window the limiter does bind re-partitions its remainder sub-step by sub-step (the initial layer of an env-step decays
+ *     within seconds).  PARITY preset: n_sub 192 with glgym_set_window(h, 1): 9.1e-6 on the tight one-step tuples, inside the 1.3e-5 band
+ *     of a BDF solve at the reference's tolerances, at 960 right-hand sides + 192 windows (RK4 needs n_sub 640: 2 560 + 160).
+ *     oracle/studies/lsrk_study.py, stress_ls5.py; DESIGN.md section 2.7. */
 typedef enum { GLGYM_SCHEME_RK4 = 0, GLGYM_SCHEME_RK2 = 1, GLGYM_SCHEME_RK3 = 2, GLGYM_SCHEME_LS5 = 3 } glgym_scheme;
 
 /* Step-doubling VERIFIED integration: no attempt is accepted on its own -- the result is the finer of two agreeing attempts (at
