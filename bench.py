@@ -93,7 +93,7 @@ N_SUB = {"rk4": 240, "rk2": 336, "rk3": 270, "ls5": 128}
 PARITY_CFG = {"ls5": (192, 1), "rk4": (640, 0), "rk3": (720, 0), "rk2": (896, 0)}      # (n_sub, window): gl_gym_amd/_lib.py PRESETS["parity"]
 
 
-def cpu_baseline(n_sub: int, budget_s: float = 8.0):
+def cpu_baseline(n_sub: int, budget_s: float = 8.0, order: int = 4, window: int = 4):
     """The CPU path beside the GPU number, on a bounded sample of the bench workload's env-steps (ODE step only), timed on THIS
     box's host cores.  Four figures:
       cpu_baseline                 the reference-like integrator: variable-order BDF + modified Newton + reused finite-difference
@@ -101,7 +101,8 @@ def cpu_baseline(n_sub: int, budget_s: float = 8.0):
                                    tolerances of greenlight_model.cpp:46-63; CasADi / CVODES themselves are absent), ONE core --
                                    how the reference runs an env;
       cpu_baseline_all_cores       the same on every core granted to this container (threads over env slices);
-      cpu_baseline_same_scheme     the kernels' own arithmetic as a plain-C fp64 port (RK4, n_sub sub-steps), one core;
+      cpu_baseline_same_scheme     the kernels' own scheme as a plain-C fp64 port (the checker's rk_sc_guarded at the bench's
+                                   scheme / n_sub / window), one core;
       cpu_baseline_same_scheme_all_cores."""
     import os
     from concurrent.futures import ThreadPoolExecutor
@@ -118,7 +119,7 @@ def cpu_baseline(n_sub: int, budget_s: float = 8.0):
     D = w[rows]
     # spun-up states (one env-step from the reset state under the same inputs): at the reset state every exchange law sits on
     # its kink, which is not what a running env looks like
-    X = O.rk4_batch(np.array([init_state(w[r]) * (1 + 1e-3 * rng.standard_normal(28)) for r in rows]), U, D, p, 900.0, n_sub)
+    X = O.rk4_batch(np.array([init_state(w[r]) * (1 + 1e-3 * rng.standard_normal(28)) for r in rows]), U, D, p, 900.0, 256)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:        # a container may be granted fewer CPUs than it can see (cgroup v2 quota)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -153,13 +154,16 @@ def cpu_baseline(n_sub: int, budget_s: float = 8.0):
                "rhs_evaluations_per_env_step": evals / done,
                "sample": f"{done} env-steps on {cores} threads (= CPUs granted to this container) in {el:.1f} s"}
 
-    def rk(k):
-        O.rk4_batch(X[:64], U[:64], D[:64], p, 900.0, n_sub)
-    done, _, el = timed(rk, 64, 1, budget_s / 2)
-    rk_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "algorithm": "the kernels' own scheme family: RK4, fixed sub-steps", "rhs_evaluations_per_env_step": 4 * n_sub,
-              "sample": f"{done} env-steps (fp64 C oracle, RK4 n_sub={n_sub}, ODE step only) in {el:.1f} s"}
-    done, _, el = timed(rk, 64, cores, budget_s / 2)
-    rk_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port", "rhs_evaluations_per_env_step": 4 * n_sub,
+    def rk(k):      # the checker's restatement of the kernels' own integration (stability control, guard ladder), tuple by tuple
+        for i in range(16):
+            O.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, n_sub, order, window)
+    stages = {4: 4, 5: 5, 3: 3, 2: 2}[order]
+    alg = "the kernels' own scheme (order code %d, n_sub %d, window %d: stability-controlled sub-stepper + guard)" % (order, n_sub, window)
+    done, _, el = timed(rk, 16, 1, budget_s / 2)
+    rk_one = {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "algorithm": alg, "rhs_evaluations_per_env_step": stages * n_sub,
+              "sample": f"{done} env-steps (fp64 C oracle, n_sub={n_sub}, ODE step only) in {el:.1f} s"}
+    done, _, el = timed(rk, 16, cores, budget_s / 2)
+    rk_all = {"value": done / el, "unit": "env-steps/s", "cores": cores, "kind": "port", "rhs_evaluations_per_env_step": stages * n_sub,
               "sample": f"{done} env-steps on {cores} threads in {el:.1f} s"}
     return {"cpu_baseline": bdf_one, "cpu_baseline_all_cores": bdf_all, "cpu_baseline_same_scheme": rk_one,
             "cpu_baseline_same_scheme_all_cores": rk_all}
@@ -507,8 +511,8 @@ def main():
                        "deviation": "config text says 4 RK4 sub-steps; that is unstable for this stiff ODE (classical floor 224); n_sub is "
                                     "the nominal count of the stability-controlled sub-stepper, and the default scheme is a five-stage "
                                     "fourth-order Runge-Kutta method rather than the classical four-stage one (same order, same accuracy "
-                                    "on every fixture, 600 instead of 960 right-hand sides; classical RK4 timed in other_scheme) (DESIGN.md 2)",
-                       "scheme": ("five-stage FOURTH-order explicit Runge-Kutta scheme in 2N-storage form (stability interval 5.459 = 1.09 per "
+                                    "on every fixture, 640 instead of 960 right-hand sides; classical RK4 timed in other_scheme) (DESIGN.md 2)",
+                       "scheme": ("five-stage FOURTH-order explicit Runge-Kutta scheme in 2N-storage form (stability interval 5.009 = 1.00 per "
                                   "right-hand side; classical RK4: 0.70)" if args.scheme == "ls5" else args.scheme.upper()) +
                                  " with the cover pair's conduction integrated exactly, "
                                  "stability-controlled per environment (rate bound -> the environment's own number of windows, "
@@ -545,7 +549,8 @@ def main():
             "episodes_finished": agg["episodes_finished"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline(N_SUB["rk4"]))
+            out.update(cpu_baseline(args.n_sub, order={"rk4": 4, "ls5": 5, "rk3": 3, "rk2": 2}[args.scheme],
+                                    window=args.window or {"rk4": 4, "ls5": 2, "rk3": 3, "rk2": 4}[args.scheme]))
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:

@@ -2007,9 +2007,6 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 h_last = h;
                 if (h != h_ec) { ls_coefs<T>(T(2) * gamCov, h, lc); h_ec = h; }
             }
-#if defined(GL_TRACE_H)
-            fprintf(stderr, "P it %d h %.17g t_rem %.17g n_rem %g\n", it, (double)h, (double)t_rem, (double)n_rem);
-#endif
             sub_step();
             t_rem -= h;
 #pragma unroll

@@ -163,13 +163,15 @@ class TomatoVecEnv:
                  model_variant: str = "ode", scheme: Optional[str] = None, window: Optional[int] = None,
                  preset: Optional[str] = None,
                  observation_modules: Optional[Sequence[str]] = None, u_min: Optional[Sequence[float]] = None,
-                 u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1):
+                 u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1, integration_info: bool = True):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
         scheme / n_sub / window: "ls5" (default: five-stage fourth-order 2N-storage scheme, n_sub 128, two sub-steps per tier-2b window), "rk4" (classical RK4, 240),
         "rk3" (three-stage third-order scheme, 270) or "rk2" (midpoint rule, 336), all with the cover conduction integrated exactly (include/glgym.h).
         preset: "throughput" (the counts above; default for float32) or "parity" (inside the band of the reference solver's tolerances:
         ls5 n_sub 192 with one sub-step per window; default for float64) -- used for whatever of n_sub / window is not given (_lib.PRESETS);
+        integration_info: put the per-env GLGYM_SF_* word of each step into infos[i]["integration"] (one more B x 4-byte D2H copy
+        per host-side step; False: not copied, key absent -- the device tensor `step_flags_t` is always written);
         weather: [rows, nd] with nd = 10, or 14 when the rows carry the measured pipe columns
         (experiments/gl_predefined_controls.py:95, 107).  model_variant = "ode" | "ode_pipe" (ode.hpp:126-263, nd >= 14)."""
         torch = _torch()
@@ -215,6 +217,7 @@ class TomatoVecEnv:
         self.uncertainty_scale = float(uncertainty_scale)
         self.auto_reset = auto_reset
         self.lazy_infos = (int(num_envs) > 4096) if lazy_infos is None else bool(lazy_infos)
+        self.integration_info = bool(integration_info)
         self.seed_value = int(seed)
 
         self.p = np.asarray(init_default_params(L.NP) if params is None else params, dtype=np.float32)
@@ -441,14 +444,16 @@ class TomatoVecEnv:
         term = None
         if self.auto_reset and dones.any():
             term = self.term_obs_t.cpu().numpy() if term_obs is None else term_obs
-        flags = self.step_flags_t.cpu().numpy()
+        flags = self.step_flags_t.cpu().numpy() if self.integration_info else None
         if self.lazy_infos:
             infos = LazyInfos(L.INFO_KEYS, rows, ctrl, dones, term, flags)
         else:
             infos = [dict(zip(L.INFO_KEYS, row), controls=c) for row, c in zip(rows.tolist(), ctrl)]
-            for d, f in zip(infos, flags.tolist()):
+            for d in infos:
                 d["TimeLimit.truncated"] = False
-                d["integration"] = f          # GLGYM_SF_* word: 0 = first attempt accepted as it stood
+            if flags is not None:
+                for d, f in zip(infos, flags.tolist()):
+                    d["integration"] = f      # GLGYM_SF_* word: 0 = first attempt accepted as it stood
             if term is not None:
                 for b in np.nonzero(dones)[0]:
                     infos[b]["terminal_observation"] = term[b]

@@ -1286,7 +1286,6 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                 h = hj; h_last = h;
                 n = r + nn;                       /* the loop ends when the remaining partition is used up */
             }
-            if (getenv("SC_TRACE_H")) fprintf(stderr, "O it %d r %d h %.17g t_rem %.17g n %d\n", it, r, h, t_rem, n);
             t_rem -= h;
             if (order == 5) {
                 ls5_substep(x, k1, ym, u, d, p, pipe, h, est, est_ar, est_w);

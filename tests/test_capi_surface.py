@@ -174,6 +174,29 @@ def test_quad_kernel_isa_keeps_its_spill_free_inner_loops(device_asm):
                 assert depth < 3, (name, line.strip())
 
 
+def test_recorded_pmc_constants_belong_to_the_shipped_isa(device_asm):
+    """bench.py prices its roofline block with rocprofv3 counters recorded once per variant (profiles/rNN_pmc_constants.json; it
+    cannot collect counters itself).  Each record carries the static fingerprint of the kernel it was taken on -- total instructions,
+    vector and packed instructions of the sub-step loop (tools/pk_share.py) -- and this test recompiles the device code: a kernel
+    change without re-recording the counters (tools/profile_r05.sh) fails here instead of shipping a stale `roofline.frac`."""
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    from pk_share import loop_stats
+    sys.path.insert(0, str(ROOT))
+    import bench
+    newest = bench.PMC_FILES[0]
+    d = json.loads(newest.read_text())
+    assert "f32_ls5" in d and "f64_ls5_quad" in d, sorted(d)          # the default workload and config 2 are priced
+    for variant, rec in d.items():
+        assert "isa_fragment" in rec, variant
+        now = loop_stats(device_asm, rec["isa_fragment"])
+        assert now is not None, (variant, rec["isa_fragment"])
+        for k in ("isa_instr_total", "isa_valu_in_loop", "isa_pk_in_loop"):
+            assert now[k] == rec[k], (variant, k, now[k], rec[k], "re-record the counters: tools/profile_r05.sh")
+        assert bench.load_pmc(variant) is rec or bench.load_pmc(variant) == rec      # ... and it is this file bench.py reads
+
+
 def test_scheme_table_and_default_sub_step_counts():
     """Host-side scheme constants agree with include/glgym.h, and the nominal sub-step keeps its length when dt changes
     (multiples of the scheme's tier-2b window: RK4 -> 4, three-stage scheme -> 3, midpoint -> 4)."""
