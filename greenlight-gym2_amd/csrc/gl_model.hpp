@@ -74,42 +74,43 @@ template <class T> GL_HD T ceil_pos(T v) { return T(::ceil(v)); }
 __device__ __forceinline__ double gl_rcp_f64(double v)
 {
     const double x0 = __builtin_amdgcn_rcp(v);              // v_rcp_f64: ~2^-26
-    double e = __builtin_fma(-v, x0, 1.0), x = __builtin_fma(x0, e, x0);
-    e = __builtin_fma(-v, x, 1.0); x = __builtin_fma(x, e, x);
+    const double e = __builtin_fma(-v, x0, 1.0);            // 1 / v = x0 / (1 - e) = x0 (1 + e + e^2 + e^3 ...): cubic step, e^3 ~ 2^-78
+    const double x = __builtin_fma(x0, __builtin_fma(e, e, e), x0);
     return __builtin_isfinite(x) ? x : x0;                  // 1/inf = 0, 1/0 = inf: the refinement would make them NaN
 }
-// the same two Newton steps without the 1/0, 1/inf repair: for arguments that are finite and non-zero by construction
-// (temperatures in kelvin, densities, resistances) -- three instructions less per call, eleven calls per fp64 stage
+// the same cubic step without the 1/0, 1/inf repair: for arguments that are finite and non-zero by construction
+// (temperatures in kelvin, densities, resistances) -- three instructions less per call, seventeen calls per lane and fp64 stage
+// (round 5: one cubic step, three FMAs, in place of two Newton steps, four)
 __device__ __forceinline__ double gl_rcpn_f64(double v)
 {
     const double x0 = __builtin_amdgcn_rcp(v);
-    double e = __builtin_fma(-v, x0, 1.0), x = __builtin_fma(x0, e, x0);
-    e = __builtin_fma(-v, x, 1.0);
-    return __builtin_fma(x, e, x);
+    const double e = __builtin_fma(-v, x0, 1.0);
+    return __builtin_fma(x0, __builtin_fma(e, e, e), x0);
 }
-// sqrt(v), v > 0 and normal: v_rsq_f64 (2^-26), one coupled Goldschmidt step (g -> sqrt v, h -> 1 / (2 sqrt v)), one residual
-// correction: <= 1 ulp in 8 instructions (ocml's sqrt adds scaling for subnormal / huge arguments that do not occur here)
+// sqrt(v), v > 0 and normal: y = v_rsq_f64 (2^-26), g = v y, e = 1 - g y; sqrt v = g (1 - e)^(-1/2) = g (1 + e/2 + 3/8 e^2 + O(e^3)):
+// <= 1 ulp in 6 instructions (ocml's sqrt adds scaling for subnormal / huge arguments that do not occur here)
 __device__ __forceinline__ double gl_sqrtn_f64(double v)
 {
     const double y = __builtin_amdgcn_rsq(v);
-    double g = v * y, h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, v);
-    return __builtin_fma(d, h, g);
+    const double g = v * y;
+    const double e = __builtin_fma(-g, y, 1.0);
+    const double t = __builtin_fma(e, 0.375, 0.5) * e;
+    return __builtin_fma(g, t, g);
 }
 __device__ __forceinline__ double gl_exp_f64(double v)
 {
     const double n = __builtin_rint(v * 1.4426950408889634);
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, v);
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);          // |r| <= 0.3466
-    double p = 1.0 / 6227020800.0;                                  // Taylor to r^13: remainder < 5e-18
-    p = __builtin_fma(p, r, 1.0 / 479001600.0); p = __builtin_fma(p, r, 1.0 / 39916800.0);
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);   p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);     p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);       p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);        p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);               p = __builtin_fma(p, r, 1.0);
+    // degree-11 near-minimax polynomial on |r| <= ln 2 / 2 (Chebyshev interpolant computed in 80-bit arithmetic,
+    // tools/minimax_coeffs.py): truncation 4.2e-18 relative -- two FMAs (and two 64-bit literals) less than the Taylor
+    // polynomial to r^13 it replaces (round 5; seven calls per lane and stage in the four-lanes-per-environment kernel)
+    double p = 2.51037402717273133e-08;
+    p = __builtin_fma(p, r, 2.76330770766344563e-07); p = __builtin_fma(p, r, 2.75572561042502470e-06);
+    p = __builtin_fma(p, r, 2.48014841668440023e-05); p = __builtin_fma(p, r, 1.98412698821587752e-04);
+    p = __builtin_fma(p, r, 1.38888889537468695e-03); p = __builtin_fma(p, r, 8.33333333331519842e-03);
+    p = __builtin_fma(p, r, 4.16666666664813265e-02); p = __builtin_fma(p, r, 1.66666666666667185e-01);
+    p = __builtin_fma(p, r, 5.00000000000001998e-01); p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)n);
 }
@@ -120,10 +121,12 @@ __device__ __forceinline__ double gl_log_f64(double v)
     const bool lo = m < 0.70710678118654752;
     m = lo ? m + m : m; e = lo ? e - 1 : e;                         // [sqrt(1/2), sqrt(2))
     const double s = (m - 1.0) * gl_rcpn_f64(m + 1.0), z = s * s;  // |s| <= 0.1716 (m + 1 in [1.7, 2.42]: no repair needed)
-    double p = 1.0 / 21.0;                                          // atanh series to s^21: remainder < 1e-17
-    p = __builtin_fma(p, z, 1.0 / 19.0); p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, 1.0 / 7.0);  p = __builtin_fma(p, z, 1.0 / 5.0);  p = __builtin_fma(p, z, 1.0 / 3.0);
+    // (atanh(s) / s - 1) / z = 1/3 + z/5 + ... on z in [0, 0.02944]: degree-6 near-minimax polynomial (tools/minimax_coeffs.py;
+    // 5.9e-18 relative to ln m) in place of the series to s^21 -- three FMAs less
+    double p = 7.31091077671264522e-02;
+    p = __builtin_fma(p, z, 7.66558143896194366e-02); p = __builtin_fma(p, z, 9.09145594034031224e-02);
+    p = __builtin_fma(p, z, 1.11111053385651942e-01); p = __builtin_fma(p, z, 1.42857143153403782e-01);
+    p = __builtin_fma(p, z, 1.99999999999383143e-01); p = __builtin_fma(p, z, 3.33333333333333703e-01);
     const double t = s * z * p;                                     // ln m = 2 (s + t)
     const double fe = (double)e;
     return __builtin_fma(fe, 6.93147180369123816490e-01, __builtin_fma(fe, 1.90821492927058770002e-10, 2.0 * t) + 2.0 * s);
