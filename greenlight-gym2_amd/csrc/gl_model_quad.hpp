@@ -764,5 +764,76 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
     return extra;
 }
 
+// The verified ladder with TWO rungs at a time (round 5; glgym_evalF at small batches, where lanes are free and the call is a latency
+// chain): two quads per row, `half` 0 / 1, integrate the same row with n_sub << (2 round + half) sub-steps side by side -- attempts
+// (0, 1) in the first round, (2, 3) in the second -- exchange their results across the quads (ds_bpermute, once per round) and both
+// replay rk4_delta_guarded_quad's decisions on them in its order: the accepted attempt, `failed` and the returned state are those
+// of the sequential ladder bit for bit (each attempt is a pure function of (z0, n)); what differs is the elapsed time -- the 2 n
+// attempt's instead of n + 2 n -- and that attempt 3 is integrated speculatively when attempt 2 is needed.  Verified mode only
+// (no attempt is accepted on its own; unverified integrations accept a clean first attempt and have nothing to run beside it).
+// *mine: this quad holds the accepted attempt in `del` (the quad that writes the row).
+template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
+__device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K,
+                                                            const ModelConst<T>& m, const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del,
+                                                            int* failed, int* mine, int win_rt = 0)
+{
+    static_assert(SC_ATTEMPTS == 4, "two rounds of two attempts");
+    const int WINR = win_rt > 0 ? win_rt : WIN;
+    const QTol<T> tol = gq_tol<T>(role);
+    // The ladder's state is carried as INTEGERS in vector registers (0 / 1), updated by selects, with an opaque barrier per round: as
+    // `bool`s assigned under `break`s the compiler turned them into lane masks in spilled scalar registers whose loop-carried merge read
+    // a slot no path had written (hipcc 7.2, the fp32 RK4 / three-stage builds: the row-0 lane of the accepted quad sometimes did not
+    // write, depending on what earlier kernels had left in that register -- tools/README.md "pair ladder").
+    int done = 0, ok = 0, have_prev = 0, winner = 0;
+    QVec<T> prev;
+    prev.p = gq_sp<T>(T(0));
+    for (int i = 0; i < 6; ++i) prev.sh[i] = T(0);
+    for (int round = 0; round < SC_ATTEMPTS / 2; ++round) {
+        if (done != 0) break;                              // uniform over the two quads of a row
+        const int n = n_sub << (2 * round + half);
+        ScStat<T> st;
+        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
+        const int n_nom = ((n + WINR - 1) / WINR) * WINR;
+        T chk = (del.p.x + del.p.y) * T(0);
+        for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
+        for (int j = 0; j < 4; ++j) chk += del.o[j] * T(0);
+        const int nonfinite = gq_or((chk == T(0)) ? 0 : 1);
+        // bit 0: complete; bit 1: no flag; bit 2: not heavy
+        int code = (((nonfinite == 0) && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE))) ? 1 : 0) | ((st.flags == 0) ? 2 : 0) |
+                   ((st.n_steps < SC_HEAVY * n_nom) ? 4 : 0);
+        asm volatile("" : "+v"(code));
+        QVec<T> now, oth;
+        gq_phys_pair<T>(role, del, now.p);
+        for (int i = 0; i < 6; ++i) now.sh[i] = del.sh[i];
+        const int ocode = __shfl_xor(code, 4);
+        oth.p = gq_mk<T>(__shfl_xor(now.p.x, 4), __shfl_xor(now.p.y, 4));
+        for (int i = 0; i < 6; ++i) oth.sh[i] = __shfl_xor(now.sh[i], 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {                   // attempt 2 round + hh, in the sequential ladder's order; no early exit:
+            const int act = done ^ 1;                      // a decided row keeps its state through the selects below
+            const int own = (hh == half) ? 1 : 0;
+            const int c = own ? code : ocode;
+            QVec<T> cur, dif;
+            cur.p = gq_mk<T>(own ? now.p.x : oth.p.x, own ? now.p.y : oth.p.y);
+            for (int i = 0; i < 6; ++i) cur.sh[i] = own ? now.sh[i] : oth.sh[i];
+            dif.p = cur.p - prev.p;
+            for (int i = 0; i < 6; ++i) dif.sh[i] = cur.sh[i] - prev.sh[i];
+            const T worst = gq_max(gq_fast_max(dif, tol.est));
+            const int complete = c & 1, last = (2 * round + hh == SC_ATTEMPTS - 1) ? 1 : 0;
+            const int agree = complete & have_prev & ((worst <= T(SC_AGREE)) ? 1 : 0);
+            const int ok_n = agree | (last & complete & ((c >> 1) & 1));
+            ok = act ? ok_n : ok;
+            winner = act ? hh : winner;
+            have_prev = act ? complete : have_prev;
+            prev.p = gq_mk<T>(act ? cur.p.x : prev.p.x, act ? cur.p.y : prev.p.y);
+            for (int i = 0; i < 6; ++i) prev.sh[i] = act ? cur.sh[i] : prev.sh[i];
+            done = act ? (ok_n | last) : done;
+            asm volatile("" : "+v"(done), "+v"(ok), "+v"(winner), "+v"(have_prev));
+        }
+    }
+    *failed = ok ^ 1;
+    *mine = (half == winner) ? 1 : 0;
+}
+
 }  // namespace glm
 #endif

@@ -495,7 +495,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
 // ---------------------------------------------------------------------------------------------------
 // reference-compatible step map, four lanes per row (what fp64 handles run: row-major double I/O, per-row crop blocks)
 // ---------------------------------------------------------------------------------------------------
-template <class T, int SCH, bool PIPE, bool CROP>
+// PAIR (round 5): two quads per row, the verified ladder two rungs at a time (gl_model_quad.hpp rk4_delta_guarded_quad_pair) -- what
+// glgym_evalF launches in verified mode while the batch leaves lanes free; bit-identical results, two thirds of the latency
+template <class T, int SCH, bool PIPE, bool CROP, bool PAIR = false>
 __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const double* u, const double* d, const double* crop, int B, T dt,
                                                           int n_sub, T gasR, T tCanMin, ModelConst<T> m_arg, double* x_next, int nd,
                                                           int* n_failed, int verify, int pipe, int window)
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const
         __syncthreads();
     }
     const ModelConst<T>& m = LDSM ? sh_m[0] : m_arg;
-    const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3, b = gl >> 2;
+    const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3, b = PAIR ? gl >> 3 : gl >> 2, half = PAIR ? (gl >> 2) & 1 : 0;
     const bool live = b < B;
     const int bb = live ? b : B - 1;
     T uu[NU], dd[7];
@@ -561,17 +563,25 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const
     z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x,
                     role == 2 ? x0.sh[2] - x0.p.y : role == 3 ? x0.p.x - x0.p.y : x0.p.y);
     bool bad;
-    int extra_steps, first_flags = 0;
-    rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, dt, n_sub, del, &bad, &extra_steps, verify != 0,
-                                                                                  &first_flags, window);
+    int mine = 1;                        // (an integer on purpose: rk4_delta_guarded_quad_pair)
+    if (PAIR) {
+        int bad_i;
+        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, half, z0, s, K, m, cr, dt, n_sub, del, &bad_i, &mine, window);
+        asm volatile("" : "+v"(bad_i), "+v"(mine));
+        bad = bad_i != 0;
+    } else {
+        int extra_steps, first_flags = 0;
+        rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, dt, n_sub, del, &bad, &extra_steps, verify != 0,
+                                                                                      &first_flags, window);
+    }
     // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE
     P2<T> dP;
     gq_phys_pair<T>(role, del, dP);
     asm volatile("" ::: "memory");
     int gl2 = blockIdx.x * WAVE + threadIdx.x;
     asm volatile("" : "+v"(gl2));
-    const int role2 = gl2 & 3, b2 = gl2 >> 2;
-    if (b2 < B) {
+    const int role2 = gl2 & 3, b2 = PAIR ? gl2 >> 3 : gl2 >> 2;
+    if (b2 < B && mine != 0) {
         const double nan = __builtin_nan("");
         auto X2 = [&](int i) { return x[(size_t)b2 * NX + i]; };
         auto W = [&](int i, T dv) { x_next[(size_t)b2 * NX + i] = bad ? nan : X2(i) + (double)dv; };
@@ -1228,6 +1238,7 @@ struct glgym_handle_s {
     int window = 0;                     // glgym_set_window: 0 = the scheme's own
     int layout = GLGYM_LAYOUT_AUTO;     // glgym_set_layout (fp32); initial value from GLGYM_LAYOUT at glgym_create
     int occupancy = 1;                  // glgym_set_occupancy (one-lane fp32 kernel); initial value from GLGYM_OCC at glgym_create
+    int ladder_parallel = 1;            // glgym_set_ladder_parallel: verified glgym_evalF calls may run two rungs of the ladder side by side
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
     float du = 0.1f, u_min[NU] = {0, 0, 0, 0, 0, 0}, u_max[NU] = {1, 1, 1, 1, 1, 1};   // glgym_set_control_limits
     int obs_modules[6] = {0, 1, 2, 3, 4, 5};   // observation modules in output order (glgym_set_obs_modules)
@@ -1397,6 +1408,13 @@ int glgym_set_occupancy(glgym_handle h, int waves_per_simd)
     return GLGYM_OK;
 }
 
+int glgym_set_ladder_parallel(glgym_handle h, int on)
+{
+    if (!h || (on != 0 && on != 1)) { g_err = "glgym_set_ladder_parallel: 0 or 1"; return GLGYM_EINVAL; }
+    h->ladder_parallel = on;
+    return GLGYM_OK;
+}
+
 int glgym_set_control_limits(glgym_handle h, const double* u_min, const double* u_max, double delta_u_max)
 {
     if (!h || !u_min || !u_max || !(delta_u_max >= 0)) { g_err = "glgym_set_control_limits: bad arguments"; return GLGYM_EINVAL; }
@@ -1458,15 +1476,29 @@ static void launch_evalf_sch(glgym_handle h, const ModelConst<T>& m, const doubl
                              const double* dd, const double* dcrop, int B, double* dout, dim3 grid, dim3 block)
 {
     const int verify = h->verify_mode != GLGYM_VERIFY_NEVER;
+    // verified calls on batches that leave lanes free run the ladder two rungs at a time, two quads per row (evalf_kernel_quad<PAIR>):
+    // up to one wavefront per SIMD of the device (8 lanes per row); beyond that the sequential ladder does the same work on fewer lanes
+    const bool pair = verify && h->ladder_parallel && !dcrop && (size_t)8 * B <= (size_t)WAVE * h->n_simd &&
+                      (sizeof(T) == 8 || h->layout != GLGYM_LAYOUT_ONE);
     if constexpr (sizeof(T) == 8) {      // fp64: four lanes per row (no one-lane fp64 integrator exists any more)
-        const dim3 qgrid((4 * B + WAVE - 1) / WAVE);
+        const dim3 qgrid((4 * B + WAVE - 1) / WAVE), pgrid((8 * B + WAVE - 1) / WAVE);
         const int pipe = h->variant == GLGYM_ODE_PIPE ? 1 : 0;
-        if (dcrop) hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, true>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+        if (pair) hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, false, true>), pgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                                     T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe, h->window);
+        else if (dcrop) hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, true>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                                       T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe, h->window);
         else hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, true, false>), qgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                                 T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, pipe, h->window);
     } else {
-        if (dcrop) hipLaunchKernelGGL((evalf_kernel<T, true, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+        const dim3 pgrid((8 * B + WAVE - 1) / WAVE);
+        if (pair) hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, false, false, true>), pgrid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
+                                     T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, 0, h->window);
+        // fp32 rows without their own parameter block take the four-lanes-per-row kernel where glgym_step does (up to one round of
+        // quad wavefronts: 16 384 rows on MI355X; glgym_set_layout overrides)
+        else if (!dcrop && (h->layout == GLGYM_LAYOUT_QUAD || (h->layout == GLGYM_LAYOUT_AUTO && B <= 4 * h->n_simd * 4)))
+            hipLaunchKernelGGL((evalf_kernel_quad<T, SCH, false, false, false>), dim3((4 * B + WAVE - 1) / WAVE), block, 0, (hipStream_t)0, dx, du, dd, dcrop, B,
+                               T(h->dt), h->n_sub, T(p_used[39]), T(p_used[162]), m, dout, h->nd, h->fail_dev, verify, 0, h->window);
+        else if (dcrop) hipLaunchKernelGGL((evalf_kernel<T, true, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                                       T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify, h->window);
         else hipLaunchKernelGGL((evalf_kernel<T, false, false, SCH>), grid, block, 0, (hipStream_t)0, dx, du, dd, dcrop, B, T(h->dt), h->n_sub,
                                 T(p_used[39]), T(p_used[162]), m, dout, 0, h->nd, h->fail_dev, verify, h->window);
@@ -1551,6 +1583,7 @@ static int evalf_impl(glgym_handle h, const double* x, const double* u, const do
         HIPCHK(hipMemcpy(dcrop, crop.data(), crop.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemset(h->fail_dev, 0, sizeof(int)));
+    HIPCHK(hipMemset(dout, 0xFF, (size_t)B * NX * sizeof(double)));      // a row no lane writes reads back as NaN, not as the previous call's
     if (h->dtype == GLGYM_F32) {
         ModelConst<float> m = h->mf;
         if (p) make_model_const<float>(p_used, m);

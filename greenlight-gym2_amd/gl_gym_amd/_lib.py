@@ -148,6 +148,7 @@ PROTOTYPES = {
     "glgym_set_window": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_occupancy": (C.c_int, [C.c_void_p, C.c_int]),
+    "glgym_set_ladder_parallel": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_last_error": (C.c_char_p, []),
     "glgym_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _DP, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_void_p)]),

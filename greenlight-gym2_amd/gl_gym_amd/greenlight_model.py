@@ -68,6 +68,16 @@ class GreenLight:
         (include/glgym.h, glgym_verify)."""
         L.check(self._lib.glgym_set_verify(self._h, L.VERIFY_MODES[mode]), "glgym_set_verify")
 
+    def set_ladder_parallel(self, on: bool):
+        """Verified evalF calls on small batches run two rungs of the step-doubling ladder side by side (default; include/glgym.h
+        glgym_set_ladder_parallel): identical results, two thirds of the latency.  False: always the sequential ladder."""
+        L.check(self._lib.glgym_set_ladder_parallel(self._h, int(bool(on))), "glgym_set_ladder_parallel")
+
+    def set_layout(self, layout: str):
+        """Kernel layout of fp32 handles ("auto" | "one" | "quad"; include/glgym.h glgym_set_layout): evalF rows without their own
+        parameter block run four lanes per row up to 16 384 rows, one lane per row beyond; fp64 has one layout."""
+        L.check(self._lib.glgym_set_layout(self._h, L.LAYOUTS[layout]), "glgym_set_layout")
+
     def _as(self, a, n, B):
         a = np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1)
         if a.shape[1] != n:

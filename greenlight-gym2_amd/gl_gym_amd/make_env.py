@@ -82,7 +82,7 @@ def tomato_vec_env_from_config(n_envs: int, reward_function: str, observation_mo
                                base_env_params: Optional[Dict[str, Any]] = None, uncertainty_scale: float = 0.0,
                                seed: int = 0, **device_kw):
     """``TomatoEnv(**env_specific_params, base_env_params=env_base_params)`` for n_envs environments at once.
-    device_kw: dtype, n_sub, device, auto_reset, lazy_infos, model_variant (TomatoVecEnv keyword arguments);
+    device_kw: dtype, scheme, preset, n_sub, window, device, auto_reset, lazy_infos, model_variant (TomatoVecEnv keyword arguments);
     weather_on_device=True builds the weather table with the device pipeline (weather_device.py)."""
     from .tomato_env import TomatoVecEnv
     base = dict(base_env_params or {})

@@ -64,6 +64,39 @@ def test_jump_step_maps_through_step_kernel(golden, scheme, n_sub, dtype):
     env.close()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme,n_sub", [("ls5", 128), ("rk4", 240)])
+def test_two_rungs_at_a_time_equals_the_sequential_ladder(golden, scheme, n_sub, dtype):
+    """Verified evalF calls on small batches integrate n_sub and 2 n_sub (then 4 n_sub and 8 n_sub) side by side on two lane groups per
+    row (include/glgym.h glgym_set_ladder_parallel): the accepted attempt and the state must be the sequential ladder's BIT FOR BIT
+    -- on the fixture whose tuples need the ladder most (every row takes two attempts, some three or four)."""
+    from gl_gym_amd import GreenLight
+    g = golden("step_tight_jump")
+    X, U, D, XT = g["X"], g["U"], g["D"], g["X_tight"]
+    m = GreenLight(28, 6, 10, 208, 900.0, dtype=dtype, scheme=scheme, n_sub=n_sub)
+    par = m.evalF_batch(X, U, D)
+    m.set_ladder_parallel(False)
+    seq = m.evalF_batch(X, U, D)
+    assert np.array_equal(par, seq), (scheme, dtype, float(np.nanmax(np.abs(par - seq))))
+    one_row = m.evalF_batch(X[5:6], U[5:6], D[5:6])           # ... and a row's result does not depend on the batch around it
+    m.set_ladder_parallel(True)
+    assert np.array_equal(m.evalF_batch(X[5:6], U[5:6], D[5:6]), one_row) and np.array_equal(one_row[0], seq[5])
+    # row by row (one wavefront, 56 of its lanes idle), other kernels in between: the first build of this path left the row-0 lane of
+    # the accepted lane group unwritten depending on what earlier kernels had left in a register (hipcc 7.2; gl_model_quad.hpp)
+    other = GreenLight(28, 6, 10, 208, 900.0, dtype="float64" if dtype == "float32" else "float32", scheme=scheme, n_sub=n_sub)
+    for i in range(0, 96, 2):
+        other.evalF_batch(X[i:i + 3], U[i:i + 3], D[i:i + 3])
+        got = m.evalF_batch(X[i:i + 1], U[i:i + 1], D[i:i + 1])[0]
+        assert np.array_equal(got, seq[i]), (scheme, dtype, i, np.nonzero(got != seq[i])[0])
+    other.close()
+    if dtype == "float32":                                     # the one-lane fp32 evalF kernel (what batches beyond 16 384 rows run)
+        m.set_layout("one")
+        one = m.evalF_batch(X, U, D)
+        wrong, floor = judge(one, XT, 2e-4)
+        assert wrong == 0 and floor <= 6, (scheme, wrong, floor)
+    m.close()
+
+
 def test_unverified_mode_flags_what_round_2_missed(golden):
     """GLGYM_VERIFY_NEVER = the action path's integration (guard only).  On the review's tuples A and B the branch invariant now
     sends the env-step up the ladder: right, or failed -- not silently wrong."""

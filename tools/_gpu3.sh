@@ -1,0 +1,8 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+python -m pytest tests -m gpu -x -q -k "fp64 or float64 or f64 or fuzz or rhs or kat" 2>&1 | tail -5
+for i in 1 2; do python bench.py --dtype f64 --batch 4096 --steps 300 --warmup 50 --no-cpu-baseline --no-alt-scheme --no-parity-config 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('config2', d['value'], d['ms_per_step'], d['parity']['max_scaled_err_10day'], d['roofline'].get('frac'))"; done
+python bench.py --dtype f64 --batch 4096 --steps 200 --warmup 50 --no-cpu-baseline --no-alt-scheme 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('config2 parity_config', json.dumps(d['parity_config'])[:400])"
+python bench.py --dtype f64 --batch 8 --steps 300 --warmup 50 --no-cpu-baseline --no-alt-scheme --no-parity-config --no-parity 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('f64 B8', d['value'], d['ms_per_step'])"
+python bench.py --scheme rk4 --steps 500 --warmup 100 --no-cpu-baseline --no-alt-scheme 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('rk4', d['value'], d['ms_per_step'], d['parity']['max_scaled_err_10day'], d['roofline'].get('frac')); print('rk4 parity_config', json.dumps(d['parity_config'])[:400])"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU): run the bench workload and save the (x, u, d) tuples of every env-step whose first integration attempt was
 not accepted as it stood (step_flags, include/glgym.h GLGYM_SF_*), for offline analysis against the CPU checker.
-    python tools/flag_tuples.py [steps] [n_sub] [dtype] [scheme]      -> gpurun_out/flagged_tuples.npz"""
+    python tools/flag_tuples.py [steps] [n_sub] [dtype] [scheme]      -> gpurun_out/flagged_tuples.npz
+GLGYM_TOOL_HEAVY=k: also the env-steps that took at least k sub-steps beyond n_sub (the launch waits for its slowest lane)."""
 import sys
 from pathlib import Path
 import numpy as np, torch
@@ -29,13 +30,17 @@ for i in range(steps):
     env.action_t.copy_(a)
     env._launch_step(raw_control=False)
     fl = env.step_flags_t
-    idx = torch.nonzero((fl & 0xffff) != 0).flatten()          # first-attempt flags / extra attempts (bits 16.. only count sub-steps)
+    heavy_min = int(os.environ.get("GLGYM_TOOL_HEAVY", "0"))   # > 0: also capture env-steps with at least that many sub-steps beyond n_sub
+    sel = (fl & 0xffff) != 0                                   # first-attempt flags / extra attempts (bits 16.. only count sub-steps)
+    if heavy_min > 0:
+        sel = sel | ((fl >> 16) >= heavy_min)
+    idx = torch.nonzero(sel).flatten()
     if len(idx):
         X.append(x_prev[:, idx].t().double().cpu().numpy())
         U.append(env.u_T[:, idx].t().double().cpu().numpy())           # applied control
         D.append(env.weather_t[(off[idx] + ts[idx]).long()].double().cpu().numpy())
         F.append(fl[idx].cpu().numpy()); K.append(np.full(len(idx), i))
-        for f in F[-1]: hist[int(f)] = hist.get(int(f), 0) + 1
+        for f in F[-1]: hist[int(f) & 0xffff] = hist.get(int(f) & 0xffff, 0) + 1
     env._launch_reset(env.done_t)
 print(scheme, "n_sub", env.n_sub, dtype, "flag words seen (word: count):", dict(sorted(hist.items())), "of", steps * B, "env-steps")
 print(env.metrics())
