@@ -765,11 +765,11 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
 }
 
 // The verified ladder with TWO rungs at a time (round 5; glgym_evalF at small batches, where lanes are free and the call is a latency
-// chain): two quads per row, `half` 0 / 1, integrate the same row with n_sub << (2 round + half) sub-steps side by side -- attempts
-// (0, 1) in the first round, (2, 3) in the second -- exchange their results across the quads (ds_bpermute, once per round) and both
-// replay rk4_delta_guarded_quad's decisions on them in its order: the accepted attempt, `failed` and the returned state are those
+// chain): two quads per row, `half` 0 / 1, integrate the same row with n_sub and 2 n_sub sub-steps side by side (attempts 0 and 1),
+// exchange their results across the quads (ds_bpermute) and both replay rk4_delta_guarded_quad's decisions on them in its order; the
+// rare later attempts (4 n_sub, 8 n_sub) run on lane group 0 alone.  The accepted attempt, `failed` and the returned state are those
 // of the sequential ladder bit for bit (each attempt is a pure function of (z0, n)); what differs is the elapsed time -- the 2 n
-// attempt's instead of n + 2 n -- and that attempt 3 is integrated speculatively when attempt 2 is needed.  Verified mode only
+// attempt's instead of n + 2 n.  Verified mode only
 // (no attempt is accepted on its own; unverified integrations accept a clean first attempt and have nothing to run beside it).
 // *mine: this quad holds the accepted attempt in `del` (the quad that writes the row).
 template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
@@ -788,11 +788,16 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
     QVec<T> prev;
     prev.p = gq_sp<T>(T(0));
     for (int i = 0; i < 6; ++i) prev.sh[i] = T(0);
-    for (int round = 0; round < SC_ATTEMPTS / 2; ++round) {
+    // round 0: attempts 0 and 1 side by side; rounds 1, 2 (rare): attempt round + 1 on lane group 0 alone, the other group waits --
+    // integrating attempt 3 speculatively beside attempt 2 would cost a row that needs three attempts 2 + 8 = 10 n where the sequential
+    // ladder takes 1 + 2 + 4 = 7 n; this way it is 2 + 4 = 6 n (four attempts: 14 n against 15 n)
+    for (int round = 0; round < SC_ATTEMPTS - 1; ++round) {
         if (done != 0) break;                              // uniform over the two quads of a row
-        const int n = n_sub << (2 * round + half);
+        const int att_mine = (round == 0) ? half : round + 1;
+        const int n = n_sub << att_mine;
         ScStat<T> st;
-        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
+        st.flags = 0; st.n_steps = 0;
+        if (round == 0 || half == 0) rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
         const int n_nom = ((n + WINR - 1) / WINR) * WINR;
         T chk = (del.p.x + del.p.y) * T(0);
         for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
@@ -809,9 +814,10 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
         oth.p = gq_mk<T>(__shfl_xor(now.p.x, 4), __shfl_xor(now.p.y, 4));
         for (int i = 0; i < 6; ++i) oth.sh[i] = __shfl_xor(now.sh[i], 4);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {                   // attempt 2 round + hh, in the sequential ladder's order; no early exit:
-            const int act = done ^ 1;                      // a decided row keeps its state through the selects below
-            const int own = (hh == half) ? 1 : 0;
+        for (int hh = 0; hh < 2; ++hh) {                   // the attempts of this round in the sequential ladder's order; no early exit:
+            const int act = (done ^ 1) & ((round == 0 || hh == 0) ? 1 : 0);      // a decided row keeps its state through the selects below
+            const int holder = (round == 0) ? hh : 0, att = (round == 0) ? hh : round + 1;
+            const int own = (holder == half) ? 1 : 0;
             const int c = own ? code : ocode;
             QVec<T> cur, dif;
             cur.p = gq_mk<T>(own ? now.p.x : oth.p.x, own ? now.p.y : oth.p.y);
@@ -819,11 +825,11 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
             dif.p = cur.p - prev.p;
             for (int i = 0; i < 6; ++i) dif.sh[i] = cur.sh[i] - prev.sh[i];
             const T worst = gq_max(gq_fast_max(dif, tol.est));
-            const int complete = c & 1, last = (2 * round + hh == SC_ATTEMPTS - 1) ? 1 : 0;
+            const int complete = c & 1, last = (att == SC_ATTEMPTS - 1) ? 1 : 0;
             const int agree = complete & have_prev & ((worst <= T(SC_AGREE)) ? 1 : 0);
             const int ok_n = agree | (last & complete & ((c >> 1) & 1));
             ok = act ? ok_n : ok;
-            winner = act ? hh : winner;
+            winner = act ? holder : winner;
             have_prev = act ? complete : have_prev;
             prev.p = gq_mk<T>(act ? cur.p.x : prev.p.x, act ? cur.p.y : prev.p.y);
             for (int i = 0; i < 6; ++i) prev.sh[i] = act ? cur.sh[i] : prev.sh[i];
