@@ -1658,6 +1658,21 @@ template <class T> GL_HD void ls_coefs(T a, T h, LsCoef<T>& c)
 // changes inside the env-step is still followed window by window.
 #define SC_PRE_MARGIN 1.02
 #define SC_PRE_MAX 2.0
+// Round 5: that decision is taken at EVERY window, with the window's own (full) rate bound -- the window LENGTH follows the bound:
+//   sc = SC_PRE_MARGIN lam hnom_nominal / S   <= 1: the nominal window;
+//   <= SC_PRE_MAX: a window of hw_nominal / sc seconds (WIN sub-steps at the bound);
+//   beyond (a wet surface pinned at tens per second -- a burst -- or a persistently fast lane): SC_BURST_STEPS sub-steps at the bound,
+//   at least hw_nominal / SC_BURST_DIV and at most hw_nominal / SC_PRE_MAX seconds: the bound is looked at again after 1-2 s instead of
+//   being frozen for the nominal 14 (one environment per launch of the bench workload took 128 sub-steps of 0.11 s through a window
+//   whose transient was over after the first second);
+// the rest of the env-step is divided into equal windows of at most that length.  No window is longer than the nominal one.  The pre-pass
+// (smooth slopes at x0, once) is gone; a lane 6 % over the limit INSIDE the env-step no longer pays 50 % (3 sub-steps per window for 2).
+// The refinement cap hnom_nominal / SC_MAX_REFINE, the harm gate and the look-ahead of the pinned analysis keep the NOMINAL sub-step.
+// The exact harvest flow stays half a window ahead of the windows (the one just taken: the next one's length is not known yet).
+// Slowest lanes of the bench workload (396 env-steps with >= 40 extra sub-steps of 2.6e7): 269 -> 61 us extra on average; every
+// fixture unchanged (oracle/studies/lsrk_study_result.txt, fourth batch).  oracle/gl_oracle.c rk_sc_impl (gl_sc_varwin) restates it.
+#define SC_BURST_STEPS 8.0
+#define SC_BURST_DIV 8.0
 
 // win_rt > 0 overrides the compile-time window WIN at run time (glgym_set_window: e.g. ls5 with one sub-step per window = the parity preset)
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
@@ -1670,10 +1685,13 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     const int WINR = win_rt > 0 ? win_rt : WIN;
     const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
     const T est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
-    // the environment's windows: nominal count now, its own after the pre-pass (it == -1) below
-    int n_win = (n_sub + WINR - 1) / WINR;
-    T hw = dt / T(n_win), hw2 = T(0.5) * hw, hnom = hw / T(WINR), hmin = hnom * T(1.0 / SC_MAX_REFINE);
-    int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
+    // the nominal windows; the window about to be taken gets its own length from its rate bound (hw, hnom: see SC_PRE_MARGIN above)
+    const int n_win = (n_sub + WINR - 1) / WINR;
+    const T hw_nom = dt / T(n_win), hnom_nom = hw_nom / T(WINR), hmin = hnom_nom * T(1.0 / SC_MAX_REFINE);
+    T hw = hw_nom, hnom = hnom_nom;
+    const T t_grace = T((int)::ceil(SC_GRACE_S / (double)hw_nom)) * hw_nom + T(0.01) * hw_nom;
+    T t_now = T(0), t_harv = T(0.5) * hw_nom;       // elapsed time; how far the exact harvest flow has been applied
+    int n_left = 0;                                 // the equal windows the rest of the env-step was divided into when the last one was chosen
     T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
     T winc[NX];                     // ORDER 5: the fast states' increments of the current window (added to del at its end)
     // the integrator works in the coordinates of rhs_fast<WETDIFF>: slots 5, 7, 20 = tTop - tCovIn, tAir - tThScr, tAir - tBlScr;
@@ -1707,10 +1725,16 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     };
     int side_prev = 0;
     bool capped_prev = false;
-    // it == -1: the pre-pass (rate bound at x0 -> this environment's number of windows);  0 .. n_win - 1: the windows;
-    // it == n_win: one closing evaluation at the final state (the error estimate of the last sub-step and the branch invariant
+    // Strang splitting: half a window of the exact harvest flow, RK on everything else, half a window again.  The flow is a
+    // one-parameter group, so the trailing half of one window and the leading half of the next are ONE call:
+    //   H(hw/2) [RK.. H(hw)]^(n-1) RK.. H(hw/2)     (equal windows; in general the flow is kept half the window just taken ahead)
+    del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, T(0.5) * hw_nom);
+    del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, T(0.5) * hw_nom);
+    // the windows, then one closing evaluation at the final state (the error estimate of the last sub-step and the branch invariant
     // of the last window)
-    for (int it = -1;; ++it) {
+    for (int it = 0;; ++it) {
+        const T t_left = dt - t_now;
+        const bool closing = it > 0 && n_left <= 1;
         // A rate beyond SC_MAX_REFINE x the nominal one is followed at the finest sub-step (the seconds before a cold, wet
         // surface crosses the air temperature); one that PERSISTS is unresolvable at this n_sub: the guard retries finer
         flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
@@ -1722,24 +1746,9 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) { xs[i] = y[i] + T(0.5) * dprev[gl_slow_slot(i)]; dwin[gl_slow_slot(i)] = del[i]; }
         slow_coef<T>(xs, s, m, cr, q);
-        T lam = (it < 0) ? T(0) : hnom;                           // in: nominal sub-step (0: smooth slopes only); out: the rate bound
+        T lam = hnom_nom;                                         // in: the nominal sub-step (harm gate, look-ahead); out: the rate bound
         int side = capped_prev ? 1 : 0;                           // in: was the window just taken capped?  out: the side bits
         rhs_stage<T, PIPE, true, COVEXP>(y, q, s, m, cr, k, &lam, &side);
-        if (it < 0) {
-            const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
-            if (sc > T(1)) {                                      // (a NaN rate leaves the nominal count)
-                n_win = (int)ceil_pos(T(n_win) * sc - T(1e-9));
-                hw = dt / T(n_win); hw2 = T(0.5) * hw; hnom = hw / T(WINR); hmin = hnom * T(1.0 / SC_MAX_REFINE);
-                n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
-                h_last = hnom;
-            }
-            // Strang splitting: half a window of the exact harvest flow, RK on everything else, half a window again.  The flow
-            // is a one-parameter group, so the trailing half of one window and the leading half of the next are ONE call:
-            //   H(hw/2) [RK.. H(hw)]^(n-1) RK.. H(hw/2)
-            del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hw2);
-            del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hw2);
-            continue;
-        }
         // branch invariant (rhs_fast<RATES>): a wet surface that was below its air node at the last look and now sits above
         // it inside the bistable regime with positive drive has jumped branches -- acted on only where the sub-step could not
         // follow the rate bound (the window just taken was capped at SC_MAX_REFINE): a crossing inside a RESOLVED window is
@@ -1757,10 +1766,20 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 const T wj = ((ORDER == 4 || ORDER == 3) && sc_fast(j) == 6) ? T(sc_itol(j)) * ec.w3 : T(sc_itol(j));
                 worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * wj);
             }
-            const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
+            const T tolmul = (t_now <= t_grace) ? T(SC_GRACE_MUL) : T(1);
             flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
         }
-        if (it >= n_win) break;
+        if (closing) break;
+        {   // ---- this window's length from its rate bound (SC_PRE_MARGIN above)
+            const T sc = T(SC_PRE_MARGIN) * lam * hnom_nom * M::rcp(S);
+            T hw_t = hw_nom;                                      // (a NaN rate leaves the nominal window)
+            if (sc > T(1) && sc <= T(SC_PRE_MAX)) hw_t = hw_nom * M::rcp(sc);
+            else if (sc > T(SC_PRE_MAX))
+                hw_t = M::min(hw_nom * T(1.0 / SC_PRE_MAX), M::max(hw_nom * T(1.0 / SC_BURST_DIV), T(SC_BURST_STEPS / SC_PRE_MARGIN) * S * M::rcp(lam)));
+            const T nl = M::max(T(1), ceil_pos(t_left * M::rcp(hw_t) - T(1e-3)));
+            n_left = (int)nl;
+            hw = t_left * M::rcp(nl); hnom = hw / T(WINR);
+        }
         // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
         T hs = M::min(S * M::rcp(lam), hnom);
         const T hs_stab = hs;                                     // what stability alone allows in this window
@@ -2024,7 +2043,10 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dwin[gl_slow_slot(i)];
-        const T hh = (it == n_win - 1) ? hw2 : hw;
+        t_now = (n_left <= 1) ? dt : t_now + hw;
+        const T target = M::min(dt, t_now + T(0.5) * hw);
+        const T hh = M::max(T(0), target - t_harv);
+        t_harv = M::max(t_harv, target);
         del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
     }

@@ -428,10 +428,13 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     static_assert(ORDER == 5 || ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER");
     using M = Math<T>;
     const int WINR = win_rt > 0 ? win_rt : WIN;               // run-time window (glgym_set_window), rk_delta
-    // the quad's windows: nominal count now, its own after the pre-pass (it == -1; rk_delta)
-    int n_win = (n_sub + WINR - 1) / WINR;
-    T hw = dt / T(n_win), hnom = hw / T(WINR);
-    int n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
+    // the nominal windows; each window gets its own length from its rate bound (rk_delta, SC_PRE_MARGIN)
+    const int n_win = (n_sub + WINR - 1) / WINR;
+    const T hw_nom = dt / T(n_win), hnom_nom = hw_nom / T(WINR);
+    T hw = hw_nom, hnom = hnom_nom;
+    const T t_grace = T((int)::ceil(SC_GRACE_S / (double)hw_nom)) * hw_nom + T(0.01) * hw_nom;
+    T t_now = T(0), t_harv = T(0.5) * hw_nom;
+    int n_left = 0;
     const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
     T ls_Nprev = T(0), ls_hprev = T(0);       // ORDER 5, cover lane: N_w at the start of the previous sub-step and its length (0: none yet)
     const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
@@ -448,7 +451,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     for (int j = 0; j < 7; ++j) { dprev[j] = T(0); dwin[j] = T(0); }
     int n_steps = 0, flags = 0, side_prev = 0;
     bool capped_prev = false;
-    int n_cap = 0;                // windows taken at the refinement cap
+    T t_cap = T(0);               // time spent in windows taken at the refinement cap
     T h_last = T(-1);             // length of the last sub-step taken = the one K.ec holds the coefficients of
     // the pair's y component by the ETD formulas of rk_delta: the cover lane with a = 2 gam, every other lane with a = 0, for which the
     // coefficients are those of classical RK4 -- one instruction stream for the four lanes
@@ -475,8 +478,11 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     SlowCoef<T> q;
     LaneStep<T> LS;
     if (!LDSQ) gq_make_lane_step<T>(role, s, m, K, LS);
-    for (int it = -1; it <= n_win; ++it) {
-        flags |= (T(n_cap) * hw > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
+    harvest(T(0.5) * hw_nom);                                  // leading half of the exact harvest flow (rk_delta)
+    for (int it = 0;; ++it) {
+        const T t_left = dt - t_now;
+        const bool closing = it > 0 && n_left <= 1;
+        flags |= (t_cap > T(SC_CAP_S)) ? SC_FLAG_CAP : 0;
         if (flags & SC_FLAG_CAP) break;
         // ---- window start: tier 2b at the predicted window midpoint; every lane evaluates it from the gathered inputs
         state_now();
@@ -502,19 +508,8 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         QRates<T> R;
         GQ_FENCE(); gq_stage<T, true, PIPE>(role, y, K, s, m, q, k, &R);
         int side = capped_prev ? 1 : 0;
-        T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, (it < 0) ? T(0) : hnom, &side);
+        T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, hnom_nom, &side);
         if (PIPE) lam = (s.pipeTrack != T(0)) ? M::max(lam, T(1)) : lam;      // dxdt(9) = tPipeSet - x9: rate 1 1/s (rhs_fast<RATES, PIPE>)
-        if (it < 0) {
-            // pre-pass (rk_delta): the environment's own number of windows from the rate bound at x0, then the leading harvest half step
-            const T sc = M::min(T(SC_PRE_MARGIN) * lam * hnom * M::rcp(S), T(SC_PRE_MAX));
-            if (sc > T(1)) {
-                n_win = (int)ceil_pos(T(n_win) * sc - T(1e-9));
-                hw = dt / T(n_win); hnom = hw / T(WINR);
-                n_grace = (int)::ceil(SC_GRACE_S / (double)hw);
-            }
-            harvest(T(0.5) * hw);
-            continue;
-        }
         flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
         side_prev = side;
         if (it > 0) {
@@ -522,10 +517,20 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             dif.p = estP - k.p;
             for (int i = 0; i < 6; ++i) dif.sh[i] = estS[i] - k.sh[i];
             const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, (ORDER == 4 || ORDER == 3) ? gq_tol<T>(role).est.y * K.ec.w3 : gq_tol<T>(role).est.y)));     // (the ETD component's estimate carries f3)
-            const T tolmul = (it <= n_grace) ? T(SC_GRACE_MUL) : T(1);
+            const T tolmul = (t_now <= t_grace) ? T(SC_GRACE_MUL) : T(1);
             flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;
         }
-        if (it == n_win) break;
+        if (closing) break;
+        {   // this window's length from its rate bound (rk_delta, decision for decision)
+            const T sc = T(SC_PRE_MARGIN) * lam * hnom_nom * M::rcp(S);
+            T hw_t = hw_nom;
+            if (sc > T(1) && sc <= T(SC_PRE_MAX)) hw_t = hw_nom * M::rcp(sc);
+            else if (sc > T(SC_PRE_MAX))
+                hw_t = M::min(hw_nom * T(1.0 / SC_PRE_MAX), M::max(hw_nom * T(1.0 / SC_BURST_DIV), T(SC_BURST_STEPS / SC_PRE_MARGIN) * S * M::rcp(lam)));
+            const T nl = M::max(T(1), ceil_pos(t_left * M::rcp(hw_t) - T(1e-3)));
+            n_left = (int)nl;
+            hw = t_left * M::rcp(nl); hnom = hw / T(WINR);
+        }
         T hs = M::min(S * M::rcp(lam), hnom);
         const T hs_stab = hs;                                  // what stability alone allows in this window (rk_delta)
         // movement limiter; ORDER 5: its allowance grows with the head-room the window's rate bound leaves below the stability limit
@@ -537,10 +542,10 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             limited0 = mv * hs > move_allow;
             hs = limited0 ? move_allow * M::rcp(mv) : hs;
         }
-        const T hmin = hnom * T(1.0 / SC_MAX_REFINE);
+        const T hmin = hnom_nom * T(1.0 / SC_MAX_REFINE);
         const bool capped = !(hs >= hmin);
         hs = capped ? hmin : hs;
-        n_cap += capped ? 1 : 0;
+        t_cap += capped ? hw : T(0);
         capped_prev = capped;
         T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
         T h = hw * M::rcp(n_rem);
@@ -702,7 +707,12 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             slow7(del, end7);
             for (int j = 0; j < 7; ++j) dprev[j] = end7[j] - dwin[j];
         }
-        harvest((it == n_win - 1) ? T(0.5) * hw : hw);
+        t_now = (n_left <= 1) ? dt : t_now + hw;
+        {
+            const T target = M::min(dt, t_now + T(0.5) * hw);
+            harvest(M::max(T(0), target - t_harv));
+            t_harv = M::max(t_harv, target);
+        }
     }
     if (role == 3) del.o[1] = dt * T(1.0 / 86400.0);          // x27 = time [days]
     st.n_steps = n_steps;

@@ -860,6 +860,11 @@ static double dsat_vp(double t) { return sat_vp(t) * 17.2694 * 238.3 / ((t + 238
  * ---------------------------------------------------------------------------------- */
 int gl_sc_exp = 1;
 int gl_sc_prescale = 1;
+int gl_sc_burst_div = 8;         /* varwin: a window whose bound is beyond SC_PRE_MAX x the limit is at least 1 / this of the nominal one */
+int gl_sc_varwin = 1;            /* round 5: the window length follows the rate bound (see rk_sc_impl); 0 (studies): round 4's rule --
+                                  * the pre-pass at x0 alone, a rate bound frozen for every nominal window */
+static __thread double sc_windows_taken = 0.0;
+double gl_oracle_last_windows(void) { return sc_windows_taken; }
 double gl_sc_move_pow = 1.0, gl_sc_move_hmax = 4.0;      /* order 5: head-room exponent / cap of the movement allowance (the kernels: 1, 4; 0 = round 4's limiter) */
 int gl_sc_adapt = 1;         /* round 5: limiter-bound windows of the five-stage scheme re-partition their remainder sub-step by sub-step (rk_sc_impl) */
 /* (Tried for the window-length error and removed, round 4: an Euler-Maclaurin end correction of cBuf's midpoint quadrature and a
@@ -867,6 +872,7 @@ int gl_sc_adapt = 1;         /* round 5: limiter-bound windows of the five-stage
  * costs 1e-5 on the soil chain: DESIGN.md 2.6.) */
 #define SC_PRE_MARGIN 1.02
 #define SC_PRE_MAX 2.0
+#define SC_BURST_STEPS 8.0
 /* E = e^z, E2 = e^(z/2), Q = (h/2) phi1(z/2), f1 = h (phi1 - 3 phi2 + 4 phi3), f2 = h (phi2 - 2 phi3), f3 = h (4 phi3 - phi2)
  * at z = -a h;  phi3 by its Taylor series (no cancellation), phi2, phi1, e^z by the recurrence phi_{k-1} = z phi_k + 1/(k-1)! */
 static void etd_coefs(double a, double h, double *c)
@@ -1162,7 +1168,7 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
     ls_have_prev = 0;
     int n_win = (n_sub + window - 1) / window;
     memcpy(x, x0, sizeof x);
-    if (gl_sc_prescale) {
+    if (gl_sc_prescale && !gl_sc_varwin) {
         /* Round 4: the environment's OWN number of windows.  n_sub is the nominal (= minimum) count; an environment whose rate
          * bound at the start of the env-step asks for a shorter sub-step gets proportionally more windows (at most SC_PRE_MAX x),
          * so that it runs with `window` equal sub-steps per window like everybody else instead of window + 1 longer ones: a
@@ -1175,26 +1181,35 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         const double sc = fmin(SC_PRE_MARGIN * lam0 * hn0 / S, SC_PRE_MAX);
         if (sc > 1.0) n_win = (int)ceil((double)n_win * sc - 1e-9);          /* NaN: unchanged */
     }
-    const double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
-    double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0, h_last = hnom;
+    double hw = dt / (double)n_win, hnom = hw / (double)window, hmin = hnom / SC_MAX_REFINE;
+    const double hw_nom = hw, hnom_nom = hnom;           /* (varwin: the nominal window; hw, hnom, hmin are the current window's) */
+    double n_steps = 0.0, emax = 0.0, lmax = 0.0, t_cap = 0.0, h_last = hnom, t_now = 0.0;
     int flags = 0;
     const int n_grace = (int)ceil(SC_GRACE_S / hw);
+    const double t_grace = (double)n_grace * hw_nom;
     memset(dprev, 0, sizeof dprev);
     x[23] = harvest_flow_ref(x[23], p[144], 0.5 * hw);
     x[25] = harvest_flow_ref(x[25], p[145], 0.5 * hw);
+    double t_harv = 0.5 * hw;      /* varwin: how far the exact harvest flow has been applied (it leads the windows by half a window) */
+    sc_windows_taken = 0.0;
     int side_prev[3] = {0, 0, 0}, capped_prev = 0;
+    double n_left_prev = 0.0;      /* varwin: how many equal windows the rest of the env-step was divided into when the last window was chosen */
     /* n_win windows + one closing evaluation at the final state (it == n_win): the error estimate of the last sub-step and
      * the branch invariant of the last window (round 2 left that tail unchecked) */
-    for (int it = 0; it <= n_win; ++it) {
+    for (int it = 0; gl_sc_varwin || it <= n_win; ++it) {
+        const double t_left = dt - t_now;
+        const int closing = gl_sc_varwin ? (it > 0 && n_left_prev <= 1.0) : (it == n_win);
         if (t_cap > SC_CAP_S) flags |= 1;
         if (flags & 1) break;
         /* window start: tier 2b at the predicted midpoint, first stage + rate bound, estimate of the previous sub-step */
+        /* (dprev is the increment over the window just taken, whatever its length: scaling it to the length the next window is expected
+         * to have extrapolates the rates of a violent 1-2 s transient over 7 s -- 100 of the 576 raw-jump tuples above 1e-4) */
         for (int i = 0; i < GL_NX; ++i) ym[i] = x[i] + 0.5 * dprev[i];
         memcpy(xw, x, sizeof xw);
         rhs_lagged(x, ym, u, d, p, k1, pipe);
         int side[3];
         double Gs[6];
-        double lam = rate_bound_impl(x, u, d, p, k1, hnom, side, Gs, em);
+        double lam = rate_bound_impl(x, u, d, p, k1, gl_sc_varwin ? hnom_nom : hnom, side, Gs, em);      /* (the harm gate and the look-ahead of the pinned analysis: the nominal sub-step) */
         if (pipe && !((d[10] < 1.0) || (d[12] > 0.0))) lam = fmax(lam, 1.0);
         if (lam > lmax) lmax = lam;
         /* branch invariant (sc_pinned): a wet surface that was below its air node at the last look and now sits above it in
@@ -1231,11 +1246,32 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
             for (int j = 0; j < 9; ++j) worst = fmax(worst, fabs(est[j] - kz(k1, SC_FAST[j])) / SC_TOL[j]);
             worst *= h_last * est_fac;
             if (getenv("SC_TRACE")) fprintf(stderr, "it %d h %.3f ratio %.4f lam %.3f\n", it, h_last, worst, lam);
-            if (it <= n_grace) worst *= 1.0 / SC_GRACE_MUL;
+            if (gl_sc_varwin ? (t_now <= t_grace + 0.01 * hw_nom) : (it <= n_grace)) worst *= 1.0 / SC_GRACE_MUL;
             if (!(worst <= 1.0)) flags |= 4;
             if (worst > emax) emax = worst;
         }
-        if (it == n_win) break;
+        if (closing) break;
+        if (gl_sc_varwin) {
+            /* Round 5: the WINDOW LENGTH follows the rate bound.  A lane whose bound asks for sc x the nominal sub-step count
+             * takes m = max(window, floor(sc window)) sub-steps in a window of hw_nom m / (sc window) <= hw_nom seconds: sc times the
+             * stages, never (window + 1) / window times for a rate 5 % over the limit -- decided window by window (the pre-pass at x0
+             * decided it once, from the smooth slopes only); beyond SC_PRE_MAX (a pinned surface's burst) the nominal window is refined
+             * inside as before.  The rest of the env-step is divided into equal windows of at most that length. */
+            const double sc = SC_PRE_MARGIN * lam * hnom_nom / S;
+            double hw_t = hw_nom;
+            if (sc > 1.0 && sc <= SC_PRE_MAX) {
+                hw_t = hw_nom / sc;                /* `window` sub-steps at the rate bound */
+            } else if (sc > SC_PRE_MAX) {
+                /* a burst (a wet surface pinned at a rate of tens per second) or a persistently fast lane: a window of SC_BURST_STEPS
+                 * sub-steps at the rate bound, at least hw_nom / gl_sc_burst_div and at most hw_nom / SC_PRE_MAX long -- the bound is looked
+                 * at again after 1-2 s instead of being frozen for the nominal 14 */
+                hw_t = fmin(hw_nom / SC_PRE_MAX, fmax(hw_nom / (double)gl_sc_burst_div, SC_BURST_STEPS * S / (SC_PRE_MARGIN * lam)));
+            }                                                                          /* (NaN: the nominal window) */
+            const double n_left = fmax(1.0, ceil(t_left / hw_t - 1e-3));      /* (1e-3: the fp32 kernels accumulate t_now in float) */
+            n_left_prev = n_left;
+            hw = t_left / n_left; hnom = hw / (double)window;        /* (hmin stays the nominal window's: the refinement cap is a time) */
+        }
+        sc_windows_taken += 1.0;
         double hs = fmin(S / lam, hnom);
         const double hs_stab = hs;       /* what stability alone allows in this window */
         int limited0 = 0;                /* the movement limiter, not the rate bound, set the sub-step at the window start */
@@ -1309,7 +1345,15 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
             n_steps += 1.0;
         }
         for (int i = 0; i < GL_NX; ++i) dprev[i] = x[i] - xw[i];
-        const double hh = (it == n_win - 1) ? 0.5 * hw : hw;
+        t_now = (gl_sc_varwin && n_left_prev <= 1.0) ? dt : t_now + hw;
+        double hh = (it == n_win - 1) ? 0.5 * hw : hw;
+        if (gl_sc_varwin) {
+            /* Strang splitting with windows of varying length: the flow is kept half a window (the one just taken: the next one's
+             * length is not known yet) ahead of the windows, never beyond the end of the env-step; equal windows: H(hw/2) [RK H(hw)]^(n-1) RK H(hw/2) */
+            const double target = fmin(dt, t_now + 0.5 * hw);
+            hh = fmax(0.0, target - t_harv);
+            t_harv = fmax(t_harv, target);
+        }
         x[23] = harvest_flow_ref(x[23], p[144], hh);
         x[25] = harvest_flow_ref(x[25], p[145], hh);
     }
