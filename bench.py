@@ -515,7 +515,7 @@ def main():
                        "scheme": ("five-stage FOURTH-order explicit Runge-Kutta scheme in 2N-storage form (stability interval 5.009 = 1.00 per "
                                   "right-hand side; classical RK4: 0.70)" if args.scheme == "ls5" else args.scheme.upper()) +
                                  " with the cover pair's conduction integrated exactly, "
-                                 "stability-controlled per environment (rate bound -> the environment's own number of windows, "
+                                 "stability-controlled per environment (rate bound at every window -> that window's own length, "
                                  "more, smaller sub-steps per window where needed; embedded error estimate as safety net), "
                                  "Strang-split exact harvest flow, slow sub-expressions once per window at the predicted midpoint "
                                  "(DESIGN.md 2)"},

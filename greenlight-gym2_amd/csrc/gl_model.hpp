@@ -1506,7 +1506,8 @@ template <> struct RkVec<float> {
 // below) -- 2 = explicit midpoint (2.0, i.e. 1.0 per stage, conduction in its right-hand side; second order).  WIN: nominal
 // number of sub-steps per WINDOW; a window shares one tier-2b evaluation and one pair of harvest half steps.
 //
-// The env-step is n_win = ceil(n_sub / WIN) windows of length hw.  Inside a window every lane takes
+// The env-step is n_win = ceil(n_sub / WIN) NOMINAL windows of length hw (round 5: a window whose rate bound asks for shorter sub-steps
+// is itself shortened -- SC_PRE_MARGIN below -- so that it holds WIN sub-steps again).  Inside a window every lane takes
 //        n = ceil(t_rem / hs)  equal sub-steps,     hs = min(hw / WIN, S / lam),     S = SC_SAFETY * (2.785 | 2.513 | 2.0),
 // lam being the rate bound rhs_fast<RATES> returns with the first stage of the window's first sub-step (that stage is
 // evaluated at the END of the previous sub-step: it is also the comparison stage of the error estimate below) and, once

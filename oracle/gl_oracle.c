@@ -816,7 +816,8 @@ void gl_oracle_rk4_lagged_pipe(const double *x0, const double *u, const double *
  * and a fixed step then returns finite but wrong states.  The reference's implicit, error-controlled
  * solver (greenlight_model.cpp:46-63) has no such limit.
  *
- * What: the env-step is still n_sub / window windows of length hw, each with one tier-2b evaluation and one harvest
+ * What: the env-step is n_sub / window nominal windows of length hw (round 5: a window whose rate bound asks for shorter
+ * sub-steps is itself shortened, see rk_sc_impl), each with one tier-2b evaluation and one harvest
  * half-step pair (as before); inside a window the lane takes  n = ceil(t_rem / hs)  equal sub-steps,
  *   hs = min(hw / window, S / lam),  S = SAFETY * (2.785 | 2.0),
  * where lam is an analytic bound on the spectral radius of the fast block (gl_rate_bound below: Gershgorin rows of the
@@ -1252,11 +1253,11 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
         }
         if (closing) break;
         if (gl_sc_varwin) {
-            /* Round 5: the WINDOW LENGTH follows the rate bound.  A lane whose bound asks for sc x the nominal sub-step count
-             * takes m = max(window, floor(sc window)) sub-steps in a window of hw_nom m / (sc window) <= hw_nom seconds: sc times the
-             * stages, never (window + 1) / window times for a rate 5 % over the limit -- decided window by window (the pre-pass at x0
-             * decided it once, from the smooth slopes only); beyond SC_PRE_MAX (a pinned surface's burst) the nominal window is refined
-             * inside as before.  The rest of the env-step is divided into equal windows of at most that length. */
+            /* Round 5: the WINDOW LENGTH follows the rate bound (gl_model.hpp, SC_PRE_MARGIN): a lane whose bound asks for sc x the
+             * nominal sub-step count takes `window` sub-steps in a window of hw_nom / sc seconds -- sc times the stages, never
+             * (window + 1) / window times for a rate 5 % over the limit -- decided window by window with the window's own bound (round 4's
+             * pre-pass decided it once, at x0, from the smooth slopes only: a lane that drifted 6 % over the limit inside the env-step
+             * paid 50 %).  The rest of the env-step is divided into equal windows of at most that length. */
             const double sc = SC_PRE_MARGIN * lam * hnom_nom / S;
             double hw_t = hw_nom;
             if (sc > 1.0 && sc <= SC_PRE_MAX) {

@@ -1,0 +1,16 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+python -m pytest tests -m gpu -q -s 2>&1 | tee gpurun_out/r05/gputest_full.log | grep -E "passed|failed|error" | tail -5
+python bench.py > gpurun_out/r05/bench_full.log 2>&1; grep "^{" gpurun_out/r05/bench_full.log > gpurun_out/r05/r05_bench_line_default.json
+python bench.py --steps 12000 --warmup 500 --no-cpu-baseline --no-alt-scheme --no-parity-config 2>/dev/null | grep "^{" > gpurun_out/r05/r05_soak_ls5_bench_line.json
+python tools/substep_hist.py 300 > gpurun_out/r05/r05_substep_hist.txt 2>&1
+python tools/evalf_latency.py 300 > gpurun_out/r05/r05_evalf_latency.txt 2>&1
+python tools/small_batch_rate.py float32 > gpurun_out/r05/r05_small_batch_rate_fp32.txt 2>&1
+python tools/small_batch_rate.py float64 > gpurun_out/r05/r05_small_batch_rate_fp64.txt 2>&1
+bash tools/profile_r05.sh > gpurun_out/r05/profile.log 2>&1
+tail -12 gpurun_out/r05/profile.log
+bash tools/bench_variants_r05.sh > gpurun_out/r05/variants.log 2>&1
+cat gpurun_out/r05/variants.log
+GLGYM_OCC=2 python bench.py --batch 262144 --steps 200 --warmup 50 --no-cpu-baseline --no-alt-scheme --no-parity-config --no-parity 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('occ2 B262144', d['value'], d['ms_per_step'])"
+GLGYM_TOOL_B=262144 python tools/flag_tuples.py 340 2>&1 | tail -3
