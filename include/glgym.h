@@ -70,9 +70,10 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  * implicit; any scheme that meets the accuracy bar against it is admissible).  n_sub is the NOMINAL (= minimum) number
  * of sub-steps per env-step.  Both schemes are stability-controlled per environment: a bound on the fastest local
  * relaxation rate (top-compartment exchange 0.2-0.7 1/s, up to 1.1 1/s in storms; a wet screen pinned to
- * the air temperature 3 ... 15 1/s) is evaluated once per window of 1-4 nominal sub-steps and the environment takes as
- * many smaller sub-steps in that window as its scheme's stability interval asks for; an embedded error estimate is the
- * safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 64x the nominal count for more than 120 s,
+ * the air temperature 3 ... 15 1/s) is evaluated at the start of every window of 1-4 nominal sub-steps; a window whose bound asks
+ * for shorter sub-steps is itself shortened (round 5: 6 % over the limit costs 6 % more stages; a pinned surface's burst is looked at
+ * again after 1-2 s), and beyond that the environment takes as many smaller sub-steps in the window as its scheme's stability
+ * interval asks for; an embedded error estimate is the safety net.  An attempt that is flagged (error estimate, non-finite, rate beyond 64x the nominal count for more than 120 s,
  * a wet surface that changed sides inside its bistable regime in a capped window) or that took 3x the nominal number of sub-steps is UNVERIFIED:
  * the env-step is redone with 2x, 4x, 8x n_sub until an attempt is clean or two consecutive attempts agree on the fast states
  * (step doubling; counted in GLGYM_NMETRIC).  An environment for which no two attempts agree is reported like a failed CVODES
@@ -81,8 +82,7 @@ typedef enum { GLGYM_ODE = 0, GLGYM_ODE_PIPE = 1 } glgym_variant;
  *     between the two faces of the cover glass (hCovInCovE, aux_states.hpp:918 / ode.hpp:37-42; 0.65 1/s, state-independent) is
  *     integrated exactly -- Cox-Matthews' exponential RK4 on w = tCovIn - tCovE, classical RK4 on every other state.  The
  *     nominal sub-step is then set by the top compartment's air exchange: use n_sub 240 (nominal environments cover rates up to
- *     0.68 1/s).  An environment whose rate bound at the start of the env-step asks for a shorter sub-step gets proportionally
- *     more windows (up to 2x); what changes during the env-step is followed window by window.  The slow sub-expressions and the
+ *     0.68 1/s).  The slow sub-expressions and the
  *     harvest flow are evaluated once per window of four nominal sub-steps in both precisions (n_sub is rounded up to a multiple of 4).
  *     That window is what sets the accuracy at a given n_sub (max scaled error on the tight one-step tuples, fp64: 6.2e-5 at 240,
  *     1.5e-5 at 480, 8.7e-6 at 640, 6.9e-6 at 720; 10-day rollout 1.5e-5 at 240): for PARITY runs against the reference's solver set
