@@ -1501,9 +1501,10 @@ template <> struct RkVec<float> {
 // ---------------------------------------------------------------------------------------------------
 // The sub-stepper, round 2: STABILITY-CONTROLLED.
 //
-// ORDER: 4 = RK4 (stability interval 2.785 on the negative real axis, 0.70 per stage), 3 = the three-stage third-order scheme
-// (2.513: 0.84 per stage) -- both with the cover pair's conduction taken out of the explicit part and integrated exactly (round 4,
-// below) -- 2 = explicit midpoint (2.0, i.e. 1.0 per stage, conduction in its right-hand side; second order).  WIN: nominal
+// ORDER: 5 = the five-stage fourth-order 2N-storage scheme (round 5: stability interval 5.009 on the negative real axis, 1.00 per
+// stage; the default), 4 = RK4 (2.785, 0.70 per stage), 3 = the three-stage third-order scheme (2.513: 0.84 per stage), 2 = explicit
+// midpoint (2.0, i.e. 1.0 per stage; second order) -- ALL with the cover pair's conduction taken out of the explicit part and
+// integrated exactly (COVEXP is constexpr true: ETD-RK forms for 4 / 3 / 2, round 4; Lawson form inside the 2N recurrence for 5).  WIN: nominal
 // number of sub-steps per WINDOW; a window shares one tier-2b evaluation and one pair of harvest half steps.
 //
 // The env-step is n_win = ceil(n_sub / WIN) NOMINAL windows of length hw (round 5: a window whose rate bound asks for shorter sub-steps
