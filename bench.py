@@ -424,6 +424,12 @@ def main():
         if quad:
             variant += "_quad"
         pmc = load_pmc(variant + "_b65536") if (quad and B > 16384) else None      # recorded at this size (four rounds of waves)
+        # batches of two or more wavefronts per SIMD take the two-waves-per-SIMD build of the one-lane kernel (glgym.hip launch_step;
+        # GLGYM_OCC forces either build): another kernel, other counters (recorded at B = 262 144)
+        occ_env = os.environ.get("GLGYM_OCC", "")
+        occ2 = (not quad) and args.dtype == "f32" and not args.uncertainty and (occ_env == "2" or (occ_env != "1" and B >= 131072))
+        if occ2:
+            pmc = load_pmc(variant + "_occ2")
         pmc = pmc or load_pmc(variant)
         waves = (4 if quad else 1) * ((B + 63) // 64)
         roof = {"bound": "valu", "kernel": "step_kernel_quad" if quad else "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["fma"],

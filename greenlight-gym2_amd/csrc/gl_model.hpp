@@ -1677,9 +1677,14 @@ template <class T> GL_HD void ls_coefs(T a, T h, LsCoef<T>& c)
 #define SC_BURST_DIV 8.0
 
 // win_rt > 0 overrides the compile-time window WIN at run time (glgym_set_window: e.g. ls5 with one sub-step per window = the parity preset)
-template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
+// WBUF (round 5, the two-waves-per-SIMD build): what the windows read ONCE each lives in a caller-provided buffer in LDS instead of
+// registers -- wbuf[0 .. NX) = z0 (the integrator's coordinates of x0, filled by the caller: x0 is not read), wbuf[NX .. NX + GL_N_SLOW)
+// = the previous window's increments of the slow slots, which share their storage with the window-start values they are differenced
+// against -- and `del` may point into LDS too: 28 + 28 + 18 + 18 + 28 (x0) registers that the 256-register build otherwise spills to
+// scratch, i.e. to L2 / HBM round trips at every window (glgym.hip step_kernel, OCC = 2).  Same arithmetic, same order.
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool WBUF = false>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
-                    int n_sub, T* del, ScStat<T>& st, int win_rt = 0)
+                    int n_sub, T* del, ScStat<T>& st, int win_rt = 0, T* wbuf = nullptr)
 {
     static_assert(ORDER == 5 || ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER: 5 (five-stage fourth-order 2N scheme), 4 (RK4), 3 (three-stage third-order scheme) or 2 (midpoint rule), all with the cover conduction exponential");
     using M = Math<T>;
@@ -1698,14 +1703,19 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     T winc[NX];                     // ORDER 5: the fast states' increments of the current window (added to del at its end)
     // the integrator works in the coordinates of rhs_fast<WETDIFF>: slots 5, 7, 20 = tTop - tCovIn, tAir - tThScr, tAir - tBlScr;
     // with COVEXP slot 6 = w = tCovIn - tCovE
-    T z0[NX];
+    T z0_reg[WBUF ? 1 : NX];
+    T* z0 = WBUF ? wbuf : z0_reg;
+    if (!WBUF) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) z0[i] = x0[i];
-    z0[5] = x0[3] - x0[5]; z0[7] = x0[2] - x0[7]; z0[20] = x0[2] - x0[20];
-    if (COVEXP) z0[6] = x0[5] - x0[6];
+        for (int i = 0; i < NX; ++i) z0[i] = x0[i];
+        z0[5] = x0[3] - x0[5]; z0[7] = x0[2] - x0[7]; z0[20] = x0[2] - x0[20];
+        if (COVEXP) z0[6] = x0[5] - x0[6];
+    }
     const T gamCov = m.iCapCov * m.cCovCond;                   // conduction rate of one face [1/s]; w relaxes at 2 gamCov
     // increments over the previous window of the states tier 2b reads (gl_slow_slot: 0, 2, 4, 8, 10..14, 19, 21..26)
-    T dprev[GL_N_SLOW], dwin[GL_N_SLOW];
+    T dprev_reg[WBUF ? 1 : GL_N_SLOW], dwin_reg[WBUF ? 1 : GL_N_SLOW];
+    T* dprev = WBUF ? wbuf + NX : dprev_reg;
+    T* dwin = WBUF ? dprev : dwin_reg;      // (a slot's dprev is read -- the midpoint prediction -- before its dwin is written, and dwin before dprev at the window's end)
 #pragma unroll
     for (int j = 0; j < GL_N_SLOW; ++j) dprev[j] = T(0);
     SlowCoef<T> q;
@@ -1730,8 +1740,8 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     // Strang splitting: half a window of the exact harvest flow, RK on everything else, half a window again.  The flow is a
     // one-parameter group, so the trailing half of one window and the leading half of the next are ONE call:
     //   H(hw/2) [RK.. H(hw)]^(n-1) RK.. H(hw/2)     (equal windows; in general the flow is kept half the window just taken ahead)
-    del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, T(0.5) * hw_nom);
-    del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, T(0.5) * hw_nom);
+    del[23] += harvest_flow(z0[23] + del[23], cr.cLeafMax, T(0.5) * hw_nom);      // (z0 = x0 on the crop slots)
+    del[25] += harvest_flow(z0[25] + del[25], cr.cFruitMax, T(0.5) * hw_nom);
     // the windows, then one closing evaluation at the final state (the error estimate of the last sub-step and the branch invariant
     // of the last window)
     for (int it = 0;; ++it) {
@@ -2049,8 +2059,8 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         const T target = M::min(dt, t_now + T(0.5) * hw);
         const T hh = M::max(T(0), target - t_harv);
         t_harv = M::max(t_harv, target);
-        del[23] += harvest_flow(x0[23] + del[23], cr.cLeafMax, hh);
-        del[25] += harvest_flow(x0[25] + del[25], cr.cFruitMax, hh);
+        del[23] += harvest_flow(z0[23] + del[23], cr.cLeafMax, hh);
+        del[25] += harvest_flow(z0[25] + del[25], cr.cFruitMax, hh);
     }
     // back to the temperatures: tCovIn = tTop - z5, tThScr = tAir - z7, tBlScr = tAir - z20, tCovE = tCovIn - w
     del[5] = del[3] - del[5]; del[7] = del[2] - del[7]; del[20] = del[2] - del[20];
@@ -2089,10 +2099,10 @@ template <class T> GL_HD bool all_finite(const T* v)
     return chk == T(0);
 }
 
-template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1>
+template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool WBUF = false>
 GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                             int n_sub, T* del, bool* failed, int* extra_steps = nullptr, bool verify = false,
-                            int* first_flags = nullptr, int win_rt = 0)
+                            int* first_flags = nullptr, int win_rt = 0, T* wbuf = nullptr)
 {
     using M = Math<T>;
     const int WINR = win_rt > 0 ? win_rt : WIN;
@@ -2104,7 +2114,7 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         if (done) break;
         ScStat<T> st;
-        rk_delta<T, PIPE, ORDER, WIN>(x0, s, m, cr, dt, n, del, st, win_rt);
+        rk_delta<T, PIPE, ORDER, WIN, WBUF>(x0, s, m, cr, dt, n, del, st, win_rt, wbuf);
         {
             total += st.n_steps;
             const int n_nom = ((n + WINR - 1) / WINR) * WINR;

@@ -157,18 +157,26 @@ template <class T, int SCH> struct SchemeWin { static constexpr int value = SCH 
 // PIPE = true: the reference's ODE_pipe variant (ode.hpp:126-263; weather rows carry tPipe / pipeSwitchOff in columns 10 / 12).
 // SCH = GLGYM_SCHEME_RK2 / _RK3: midpoint / three-stage sub-steps, tier 2b and the harvest flow shared by four / three of them,
 // instead of RK4 sub-steps (GLGYM_SCHEME_RK4) -- rk_delta<T, PIPE, ORDER, WIN> in gl_model.hpp.  One lane per environment: fp32 only.
-// OCC = waves per SIMD the kernel is compiled for.  1 (default): up to 512 registers per lane, no scratch -- the right choice
-// when the batch gives every SIMD one wave (B <= 65 536).  2: 256 registers per lane (spills go to scratch) so that two
-// waves share a SIMD -- a lone wave issues a vector instruction only every ~5 cycles, two co-resident waves one every
-// ~2.7 (tools/microbench.hip with verified placement, profiles/r02_microbench_issue_rates.txt).  Measured on this kernel
-// (profiles/r02_occupancy2_variant.txt, r03_occupancy2_plain.txt): the spills eat all of it -- 0.70x the one-wave build since
-// round 3 -- so it is taken on request only (GLGYM_OCC=2, launch_step); at B = 65 536 the dispatcher would pack its 1 024 waves two
-// per SIMD onto half the chip (3.1e7).
+// OCC = waves per SIMD the kernel is compiled for.  1: up to 512 registers per lane, no scratch -- the right choice
+// when the batch gives every SIMD one wave (B <= 65 536).  2: 256 registers per lane so that two waves share a SIMD -- a lone
+// wave issues a vector instruction only every ~5 cycles, two co-resident waves one every ~2.7 (tools/microbench.hip with
+// verified placement, profiles/r02_microbench_issue_rates.txt).  Rounds 2-4 measured 0.70x for that build: its 120 spilled
+// registers were re-read from scratch at every window, 2 x 63 MB of scratch per launch did not fit the L2 (1.4 GB of HBM reads per
+// launch, 41 % of the wave cycles waiting: tools/pmc_occ2.sh).  Round 5: what the windows read once each (z0, del, the slow
+// slots' differences; x0 is re-read after the integrator) lives in LDS, 73 floats per lane = eight wavefronts per CU
+// (rk_delta<WBUF>); 208 B of scratch are left and stay in the L2: 1.06x at B = 131 072, 1.08x at 262 144, 1.11x from 524 288 --
+// the build batches of two or more wavefronts per SIMD take (launch_step).
 template <class T, bool PER_ENV_CROP, bool DEFAULT_P, bool PIPE = false, int SCH = 0, int OCC = GL_STEP_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
     const ModelConst<T>& m = DEFAULT_P ? device_default<T>() : m_arg;
-    __shared__ float sh_act[WAVE * NU];
+    // OCC = 2 (round 5): what the windows read once each -- z0, the increments del, the slow slots' window differences -- lives in LDS,
+    // WSTRIDE floats per lane (odd: conflict-free), 19.2 KB per wavefront = eight wavefronts per CU; the action tile of the prologue
+    // shares the storage (it is consumed before the integrator starts).  gl_model.hpp rk_delta<WBUF>.
+    constexpr bool WBUF = OCC == 2;
+    constexpr int WSTRIDE = (2 * NX + GL_N_SLOW) | 1;
+    __shared__ float sh_w[WBUF ? WAVE * WSTRIDE : WAVE * NU];
+    float* sh_act = sh_w;
     const int lane = threadIdx.x;
     const int b0 = blockIdx.x * WAVE;
     const int b = b0 + lane;
@@ -230,11 +238,23 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
 #pragma unroll
         for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
     }
-    T del[NX];
+    T del_reg[WBUF ? 1 : NX];
+    T* wb = reinterpret_cast<T*>(sh_w) + (size_t)lane * WSTRIDE;
+    T* del = WBUF ? wb + NX + GL_N_SLOW : del_reg;
+    if (WBUF) {
+        __syncthreads();                                   // every lane has taken its actions out of the shared storage
+#pragma unroll
+        for (int i = 0; i < NX; ++i) wb[i] = x0[i];
+        wb[5] = x0[3] - x0[5]; wb[7] = x0[2] - x0[7]; wb[20] = x0[2] - x0[20]; wb[6] = x0[5] - x0[6];      // rk_delta's coordinates
+    }
     bool bad;
     int extra_steps, first_flags = 0;
-    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags, a.window);
+    const int retries = rk4_delta_guarded<T, PIPE, gl_order(SCH), SchemeWin<T, SCH>::value, WBUF>(x0, s, m, cr, a.dt, a.n_sub, del, &bad, &extra_steps, a.verify != 0, &first_flags, a.window, wb);
     const T uBoil = a.u[(size_t)0 * a.ld + bb], uCo2 = a.u[(size_t)1 * a.ld + bb], uLamp = a.u[(size_t)4 * a.ld + bb];
+    if (WBUF) {                                            // the state again (not kept across the integrator in this build)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x0[i] = a.x[(size_t)i * a.ld + bb];
+    }
 
     // ---- failure (tomato_env.py:119-123: on an integrator error the state is left unchanged and the env terminates)
     T x1[NX];
@@ -1237,7 +1257,7 @@ struct glgym_handle_s {
     int use_specialised = 1;            // GLGYM_GENERIC=1 in the environment forces the generic kernels (A/B tests)
     int window = 0;                     // glgym_set_window: 0 = the scheme's own
     int layout = GLGYM_LAYOUT_AUTO;     // glgym_set_layout (fp32); initial value from GLGYM_LAYOUT at glgym_create
-    int occupancy = 1;                  // glgym_set_occupancy (one-lane fp32 kernel); initial value from GLGYM_OCC at glgym_create
+    int occupancy = 0;                  // glgym_set_occupancy (one-lane fp32 kernel): 0 = by batch size; initial value from GLGYM_OCC at glgym_create
     int ladder_parallel = 1;            // glgym_set_ladder_parallel: verified glgym_evalF calls may run two rungs of the ladder side by side
     int n_simd = 1024;                  // SIMDs of the device (4 per CU)
     float du = 0.1f, u_min[NU] = {0, 0, 0, 0, 0, 0}, u_max[NU] = {1, 1, 1, 1, 1, 1};   // glgym_set_control_limits
@@ -1325,7 +1345,7 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
     // initial values of glgym_set_layout / glgym_set_occupancy, read ONCE here (A/B tools set them before creating their handle); the
     // launch path reads handle state only
     if (const char* e = std::getenv("GLGYM_LAYOUT")) h->layout = (e[0] == 'q') ? GLGYM_LAYOUT_QUAD : (e[0] == 'o') ? GLGYM_LAYOUT_ONE : GLGYM_LAYOUT_AUTO;
-    if (const char* e = std::getenv("GLGYM_OCC")) h->occupancy = (std::atoi(e) == 2) ? 2 : 1;
+    if (const char* e = std::getenv("GLGYM_OCC")) h->occupancy = (std::atoi(e) == 2) ? 2 : (std::atoi(e) == 1) ? 1 : 0;
     // from here on a failure must release what was acquired: run the steps through one exit point
     int rc = [&]() -> int {
         HIPCHK(hipMalloc(&h->p0_crop_dev, NCROP * sizeof(float)));
@@ -1403,7 +1423,7 @@ int glgym_set_layout(glgym_handle h, int layout)
 
 int glgym_set_occupancy(glgym_handle h, int waves_per_simd)
 {
-    if (!h || (waves_per_simd != 1 && waves_per_simd != 2)) { g_err = "glgym_set_occupancy: 1 or 2 waves per SIMD"; return GLGYM_EINVAL; }
+    if (!h || waves_per_simd < 0 || waves_per_simd > 2) { g_err = "glgym_set_occupancy: 0 (by batch size), 1 or 2 waves per SIMD"; return GLGYM_EINVAL; }
     h->occupancy = waves_per_simd;
     return GLGYM_OK;
 }
@@ -1710,9 +1730,10 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
             HIPCHK(hipGetLastError());
             return GLGYM_OK;
         }
-        // The two-waves-per-SIMD build (256 registers + scratch) is taken on request only (GLGYM_OCC=2, read per launch): it spills and
-        // runs 0.70x the one-wave build at every batch size (profiles/r03_occupancy2_plain.txt).
-        const bool occ2 = def && !a->crop_p && h->occupancy == 2;
+        // The two-waves-per-SIMD build (256 registers; the windows' state in LDS since round 5: profiles/r05_occupancy2.txt) is what batches
+        // of at least two wavefronts per SIMD take (131 072 environments on MI355X: 1.08x there, 1.11x from 524 288); glgym_set_occupancy
+        // forces either build.  Default parameters and shared crop blocks only (the variants it is instantiated for).
+        const bool occ2 = def && !a->crop_p && (h->occupancy == 2 || (h->occupancy == 0 && (size_t)a->B >= (size_t)2 * WAVE * h->n_simd));
         if (h->scheme == GLGYM_SCHEME_RK2) launch_step_sch<GLGYM_SCHEME_RK2>(a, k, m, rw, grid, block, st, def, occ2);
         else if (h->scheme == GLGYM_SCHEME_RK3) launch_step_sch<GLGYM_SCHEME_RK3>(a, k, m, rw, grid, block, st, def, occ2);
         else if (h->scheme == GLGYM_SCHEME_LS5) launch_step_sch<GLGYM_SCHEME_LS5>(a, k, m, rw, grid, block, st, def, occ2);

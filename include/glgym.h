@@ -240,8 +240,10 @@ int glgym_set_window(glgym_handle h, int window);
  * one | quad read ONCE at glgym_create (A/B tools), else AUTO. */
 typedef enum { GLGYM_LAYOUT_AUTO = 0, GLGYM_LAYOUT_ONE = 1, GLGYM_LAYOUT_QUAD = 2 } glgym_layout;
 int glgym_set_layout(glgym_handle h, int layout);
-/* Waves per SIMD the one-lane fp32 step kernel is built for: 1 (default; up to 512 registers, no scratch) or 2 (256 registers, the rest
- * in scratch; measured slower at every batch size, on request only).  Initial value: GLGYM_OCC = 1 | 2 read once at glgym_create. */
+/* Waves per SIMD the one-lane fp32 step kernel is built for: 1 (up to 512 registers, no scratch), 2 (256 registers, the windows' state
+ * in LDS: two wavefronts share a SIMD) or 0 (default): 2 for batches of at least two wavefronts per SIMD (131 072 environments on
+ * MI355X: 1.06-1.11x), 1 below.  Results of the two builds agree to rounding (tests/test_gpu_parity.py).  Initial value: GLGYM_OCC =
+ * 1 | 2 read once at glgym_create. */
 int glgym_set_occupancy(glgym_handle h, int waves_per_simd);
 /* Verified glgym_evalF calls (GLGYM_VERIFY_AUTO / _ALWAYS) on batches that leave lanes free -- rows * 8 lanes <= one wavefront per SIMD of the
  * device: 8 192 rows on MI355X -- run the step-doubling ladder two rungs at a time on two lane groups per row (n_sub and 2 n_sub side by

@@ -48,6 +48,10 @@ fi
 variant f32_ls5 "step_kernel<float, false, true, false, 3, 1>" 128 F32
 variant f32_rk4 "step_kernel<float, false, true, false, 0, 1>" 240 F32 --scheme rk4
 variant f32_ls5_config5 "step_kernel<float, true, true, false, 3, 1>" 128 F32 --uncertainty 0.2
+# the two-waves-per-SIMD build (what batches of >= 131 072 environments run), recorded at B = 262 144
+PBATCH=262144
+variant f32_ls5_occ2 "step_kernel<float, false, true, false, 3, 2>" 128 F32 --batch 262144
+PBATCH=65536
 # fp64 runs the four-lanes-per-environment kernel at every batch size and in every variant (glgym.hip launch_step)
 PBATCH=65536
 variant f64_ls5_quad_b65536 "step_kernel_quad<double, false, 3, true, false>" 128 F64 --dtype f64
@@ -60,7 +64,7 @@ PBATCH=65536
 python - <<PY
 import json
 out = {}
-for v in ("f32_ls5", "f32_rk4", "f32_ls5_config5", "f64_ls5_quad_b65536", "f64_ls5_quad", "f64_rk4_quad", "f32_ls5_quad"):
+for v in ("f32_ls5", "f32_rk4", "f32_ls5_config5", "f32_ls5_occ2", "f64_ls5_quad_b65536", "f64_ls5_quad", "f64_rk4_quad", "f32_ls5_quad"):
     try:
         out[v] = json.load(open("$OUT/%s/constants.json" % v))
     except OSError:

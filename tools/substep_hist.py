@@ -12,7 +12,8 @@ from gl_gym_amd.utils import synthetic_weather  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n_sub = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
 scheme = sys.argv[3] if len(sys.argv) > 3 else "ls5"
-B = 65536
+import os
+B = int(os.environ.get("GLGYM_TOOL_B", "65536"))
 w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024); starts = np.arange(0, 35040 - 5760 - 60, 96)
 for label, sr in (("bench workload", starts), ("uniform batch (one start row, same actions)", [960])):
     env = TomatoVecEnv(B, weather=w, dtype="float32", scheme=scheme, n_sub=n_sub, season_length=60, pred_horizon=0.5, seed=666, start_rows=sr, auto_reset=True)
