@@ -428,12 +428,15 @@ def main():
         # GLGYM_OCC forces either build): another kernel, other counters (recorded at B = 262 144)
         occ_env = os.environ.get("GLGYM_OCC", "")
         occ2 = (not quad) and args.dtype == "f32" and not args.uncertainty and (occ_env == "2" or (occ_env != "1" and B >= 131072))
-        if occ2:
-            pmc = load_pmc(variant + "_occ2")
+        pmc_key = variant + "_b65536" if pmc is not None else variant
+        if occ2 and load_pmc(variant + "_occ2") is not None:
+            pmc, pmc_key = load_pmc(variant + "_occ2"), variant + "_occ2"
         pmc = pmc or load_pmc(variant)
         waves = (4 if quad else 1) * ((B + 63) // 64)
         roof = {"bound": "valu", "kernel": "step_kernel_quad" if quad else "step_kernel", "achieved": None, "peak": PEAKS_TFLOPS["fma"],
                 "unit": "TFLOP/s", "frac": None, "traffic": None, "waves_per_launch": waves, "waves_per_simd": waves / N_SIMD}
+        if occ2:
+            roof["kernel"] = "step_kernel, two-waves-per-SIMD build (256 registers, window state in LDS: glgym.hip launch_step)"
         if pmc is not None:
             pmc_batch = float(pmc.get("batch", 65536))
             scale = (B / pmc_batch) * (args.n_sub / float(pmc.get("n_sub", N_SUB[args.scheme])))
@@ -484,7 +487,7 @@ def main():
                                   "not `frac` -- is how close the kernel is to the ceiling its launch geometry allows",
                 "traffic": pmc["traffic_bytes"] * (B / pmc_batch),
                 "valu_insts_per_launch": valu, "trans_insts_per_launch": trans,
-                "pmc_source": pmc.get("source"), "pmc_variant": variant,
+                "pmc_source": pmc.get("source"), "pmc_variant": pmc_key,
             })
         roof.update({
             "peaks_TFLOPs": PEAKS_TFLOPS,
