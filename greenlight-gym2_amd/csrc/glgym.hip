@@ -805,7 +805,10 @@ template <class T> __global__ __launch_bounds__(256) void obs_kernel(ObsArgsT<T>
         if (!a.mask && nrows == ROWS) {                      // full span: 16-byte stores (rb*dim*4 is a multiple of 32)
             const int n4 = (ROWS * dim) >> 2;                // ROWS multiple of 8 -> exact
             float4* out4 = reinterpret_cast<float4*>(out);
-            for (int e = tid; e < n4; e += 256) out4[e] = span4[e];
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f* src4 = reinterpret_cast<const v4f*>(span4);
+            v4f* dst4 = reinterpret_cast<v4f*>(out4);
+            for (int e = tid; e < n4; e += 256) __builtin_nontemporal_store(src4[e], &dst4[e]);      // 69 MB per call, read by nobody on the device before the next step kernel has run
         } else {
             for (int r = 0; r < nrows; ++r) {
                 if (a.mask && !a.mask[rb + r]) continue;
