@@ -613,6 +613,8 @@ class TomatoVecEnv:
         L.check(self._lib.glgym_set_layout(self._h, L.LAYOUTS[layout]), "glgym_set_layout")
 
     def set_occupancy(self, waves_per_simd: int):
+        """0 (default): the one-lane fp32 kernel's two-waves-per-SIMD build from 131 072 environments, the one-wave build below; 1 / 2 force a build
+        (include/glgym.h glgym_set_occupancy)."""
         L.check(self._lib.glgym_set_occupancy(self._h, int(waves_per_simd)), "glgym_set_occupancy")
 
     def set_n_sub(self, n_sub: int):
