@@ -763,7 +763,17 @@ def test_two_waves_per_simd_build_matches_one_wave_build(scheme):
             assert err < (1e-5 if name in ("reward", "info") else 5e-6), (name, k, err)      # (reward / profit: differences through zero)
         assert torch.equal(large.x_T[:, :Bs], large.x_T[:, Bl - Bs:Bl])            # copies agree bit for bit
         assert torch.equal(d_l, d_s.repeat(rep))
+    # ... and through the verified ladder (raw controls: every environment takes at least two attempts, each re-reading the window state
+    # the two-wave build keeps in LDS)
+    ctrl = torch.rand(Bs, 6, generator=g, device=small.device, dtype=small.tdtype)
+    small.set_verify("auto"); large.set_verify("auto")                             # (this module's handles are created unverified)
+    small.step_tensor(controls_t=ctrl); large.step_tensor(controls_t=ctrl.repeat(rep, 1))
+    ref = small.x_T[:, :Bs].repeat(1, rep)
+    scale = torch.maximum(ref.abs(), 1e-3 * ref.abs().amax(dim=1, keepdim=True)).clamp_min(1e-30)
+    err = float(((large.x_T[:, :Bl] - ref).abs() / scale).max())
+    assert err < 5e-6, ("raw control", err)
     ms, ml = small.metrics(), large.metrics()
+    assert ml["n_guard_retries"] >= Bl                                             # verified: at least one extra attempt each
     assert ml["n_env_steps"] == rep * ms["n_env_steps"] and ml["n_ode_fail"] == 0
     assert abs(ml["sum_reward"] - rep * ms["sum_reward"]) < 1e-4 * abs(rep * ms["sum_reward"]) + 1.0
     print(f"occupancy-2 build vs occupancy-1 build ({scheme}): worst relative difference {worst:.1e}")
