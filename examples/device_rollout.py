@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-envs", type=int, default=65536)
     ap.add_argument("--n-steps", type=int, default=64, help="rollout length per env (PPO n_steps)")
-    ap.add_argument("--scheme", default="rk4", choices=["rk4", "rk2"])
+    ap.add_argument("--scheme", default="ls5", choices=["ls5", "rk4", "rk3", "rk2"])
     ap.add_argument("--hidden", type=int, default=64)
     args = ap.parse_args()
 
