@@ -199,6 +199,44 @@ def test_config3_shard_10day_horizon_at_full_batch(golden):
     env.close()
 
 
+def test_config3_shard_distinct_environments_10day_against_fine_truth(oracle):
+    """The same shard with 65 536 DISTINCT environments (the fixture test above runs identical rows): the bench
+    workload's synthetic year, per-environment episode starts, jittered states, fresh U(-1, 1) actions every step, over the 10-day
+    horizon (961 steps); eight environments spread over the wavefronts are integrated alongside on the CPU with plain classical RK4
+    at 2 048 sub-steps from the same controls -- free-running, never re-synchronised -- and must stay inside the 1e-4 bar to the end."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.utils import synthetic_weather
+    B, n_steps = 65536, 961
+    w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
+    starts = np.arange(0, 35040 - 5760 - 60, 96)
+    env = TomatoVecEnv(B, weather=w, dtype="float32", season_length=60, pred_horizon=0.5, seed=666, start_rows=starts, auto_reset=True)
+    env.reset_tensor()
+    dev = env.device
+    env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)).to(env.tdtype))
+    gen = torch.Generator(device=dev).manual_seed(667)
+    pick = np.array([8192 * i + (11 * i) % 64 for i in range(8)])
+    p = env.p.astype(np.float64)
+    w_off = env.w_off_t.cpu().numpy()[pick]
+    x_true = env.x[pick].double().cpu().numpy().copy()
+    pool = ThreadPoolExecutor(8)
+    worst = 0.0
+    for k in range(n_steps):
+        env.action_t.uniform_(-1.0, 1.0, generator=gen)
+        env._launch_step(raw_control=False)
+        u = env.u[pick].double().cpu().numpy()
+        x_true = np.array(list(pool.map(lambda j: oracle.rk4_split(x_true[j], u[j], w[w_off[j] + k], p, 900.0, 2048), range(8))))
+        if k % 96 == 95 or k == n_steps - 1:
+            worst = max(worst, scaled_err(env.x[pick].double().cpu().numpy(), x_true))
+        env._launch_reset(env.done_t)
+    m = env.metrics()
+    print(f"config 3 shard, 65 536 distinct envs x {n_steps} steps: 8 envs free-running vs RK4-2048 {worst:.1e}; failed {m['n_ode_fail']:.0f}, "
+          f"extra attempts {m['n_guard_retries']:.0f}, refined sub-steps per env-step {m['n_refined_substeps'] / m['n_env_steps']:.3f}")
+    assert worst < 1e-4 and m["n_ode_fail"] == 0 and m["n_env_steps"] == B * n_steps
+    env.close()
+
+
 @pytest.mark.parametrize("scheme,n_sub", [("ls5", 128), ("rk4", 256)])
 def test_step_kernel_matches_env_oracle(golden, oracle, scheme, n_sub):
     """Fused step (control clip, weather row, sub-stepper, reward, info, terminal test) vs the numpy env oracle."""
