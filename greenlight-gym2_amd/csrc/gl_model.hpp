@@ -1675,6 +1675,7 @@ template <class T> GL_HD void ls_coefs(T a, T h, LsCoef<T>& c)
 // fixture unchanged (oracle/studies/lsrk_study_result.txt, fourth batch).  oracle/gl_oracle.c rk_sc_impl (gl_sc_varwin) restates it.
 #define SC_BURST_STEPS 8.0
 #define SC_BURST_DIV 8.0
+#define SC_KEEP 0.97
 
 // win_rt > 0 overrides the compile-time window WIN at run time (glgym_set_window: e.g. ls5 with one sub-step per window = the parity preset)
 // WBUF (round 5, the two-waves-per-SIMD build): what the windows read ONCE each lives in a caller-provided buffer in LDS instead of
@@ -1788,9 +1789,15 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             if (sc > T(1) && sc <= T(SC_PRE_MAX)) hw_t = hw_nom * M::rcp(sc);
             else if (sc > T(SC_PRE_MAX))
                 hw_t = M::min(hw_nom * T(1.0 / SC_PRE_MAX), M::max(hw_nom * T(1.0 / SC_BURST_DIV), T(SC_BURST_STEPS / SC_PRE_MARGIN) * S * M::rcp(lam)));
+            // hysteresis (SC_KEEP): the window just taken keeps its length while that length is still allowed and at most 3 % shorter than
+            // what the bound now allows -- a storm lane's bound drifts by a fraction of a percent per window, and every new window length is
+            // a new sub-step length: five exponentials for the conduction coefficients, executed by the whole wavefront
+            const bool keep = it > 0 && !(hw > hw_t * T(1.0 + 1e-6)) && hw >= T(SC_KEEP) * hw_t;
+            hw_t = keep ? hw : hw_t;
             const T nl = M::max(T(1), ceil_pos(t_left * M::rcp(hw_t) - T(1e-3)));
             n_left = (int)nl;
-            hw = t_left * M::rcp(nl); hnom = hw / T(WINR);
+            hw = (nl <= T(1)) ? t_left : (keep ? hw : t_left * M::rcp(nl));
+            hnom = hw / T(WINR);
         }
         // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
         T hs = M::min(S * M::rcp(lam), hnom);

@@ -527,9 +527,12 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             if (sc > T(1) && sc <= T(SC_PRE_MAX)) hw_t = hw_nom * M::rcp(sc);
             else if (sc > T(SC_PRE_MAX))
                 hw_t = M::min(hw_nom * T(1.0 / SC_PRE_MAX), M::max(hw_nom * T(1.0 / SC_BURST_DIV), T(SC_BURST_STEPS / SC_PRE_MARGIN) * S * M::rcp(lam)));
+            const bool keep = it > 0 && !(hw > hw_t * T(1.0 + 1e-6)) && hw >= T(SC_KEEP) * hw_t;      // hysteresis (rk_delta)
+            hw_t = keep ? hw : hw_t;
             const T nl = M::max(T(1), ceil_pos(t_left * M::rcp(hw_t) - T(1e-3)));
             n_left = (int)nl;
-            hw = t_left * M::rcp(nl); hnom = hw / T(WINR);
+            hw = (nl <= T(1)) ? t_left : (keep ? hw : t_left * M::rcp(nl));
+            hnom = hw / T(WINR);
         }
         T hs = M::min(S * M::rcp(lam), hnom);
         const T hs_stab = hs;                                  // what stability alone allows in this window (rk_delta)

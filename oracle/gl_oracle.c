@@ -874,6 +874,7 @@ int gl_sc_adapt = 1;         /* round 5: limiter-bound windows of the five-stage
 #define SC_PRE_MARGIN 1.02
 #define SC_PRE_MAX 2.0
 #define SC_BURST_STEPS 8.0
+#define SC_KEEP 0.97
 /* E = e^z, E2 = e^(z/2), Q = (h/2) phi1(z/2), f1 = h (phi1 - 3 phi2 + 4 phi3), f2 = h (phi2 - 2 phi3), f3 = h (4 phi3 - phi2)
  * at z = -a h;  phi3 by its Taylor series (no cancellation), phi2, phi1, e^z by the recurrence phi_{k-1} = z phi_k + 1/(k-1)! */
 static void etd_coefs(double a, double h, double *c)
@@ -1268,9 +1269,15 @@ static void rk_sc_impl(const double *x0, const double *u, const double *d, const
                  * at again after 1-2 s instead of being frozen for the nominal 14 */
                 hw_t = fmin(hw_nom / SC_PRE_MAX, fmax(hw_nom / (double)gl_sc_burst_div, SC_BURST_STEPS * S / (SC_PRE_MARGIN * lam)));
             }                                                                          /* (NaN: the nominal window) */
+            /* hysteresis: the window just taken keeps its length while that length is still allowed and at most 3 % shorter than what the
+             * bound now allows -- a storm lane's bound drifts by a fraction of a percent per window, and every new window length is a new
+             * sub-step length, i.e. five exponentials for the conduction coefficients of the whole wavefront (SC_KEEP) */
+            const int keep = it > 0 && !(hw > hw_t * (1.0 + 1e-6)) && hw >= SC_KEEP * hw_t;
+            if (keep) hw_t = hw;
             const double n_left = fmax(1.0, ceil(t_left / hw_t - 1e-3));      /* (1e-3: the fp32 kernels accumulate t_now in float) */
             n_left_prev = n_left;
-            hw = t_left / n_left; hnom = hw / (double)window;        /* (hmin stays the nominal window's: the refinement cap is a time) */
+            hw = (n_left <= 1.0) ? t_left : (keep ? hw : t_left / n_left);
+            hnom = hw / (double)window;        /* (hmin stays the nominal window's: the refinement cap is a time) */
         }
         sc_windows_taken += 1.0;
         double hs = fmin(S / lam, hnom);
