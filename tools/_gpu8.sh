@@ -12,5 +12,9 @@ bash tools/profile_r05.sh > gpurun_out/r05/profile.log 2>&1
 tail -12 gpurun_out/r05/profile.log
 bash tools/bench_variants_r05.sh > gpurun_out/r05/variants.log 2>&1
 cat gpurun_out/r05/variants.log
+for B in 131072 262144 524288 1048576; do for occ in 1 2; do GLGYM_OCC=$occ python bench.py --batch $B --steps 100 --warmup 30 --no-cpu-baseline --no-alt-scheme --no-parity-config --no-parity 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(\"B\", $B, \"occ\", $occ, \"%.4g env-steps/s\" % d[\"value\"], \"kernel %.3f ms\" % d[\"roofline\"][\"kernel_ms\"])"; done; done
 GLGYM_OCC=2 python bench.py --batch 262144 --steps 200 --warmup 50 --no-cpu-baseline --no-alt-scheme --no-parity-config --no-parity 2>&1 | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('occ2 B262144', d['value'], d['ms_per_step'])"
 GLGYM_TOOL_B=262144 python tools/flag_tuples.py 340 2>&1 | tail -3
+python bench.py --batch 262144 --steps 3000 --warmup 100 --no-cpu-baseline --no-alt-scheme --no-parity-config 2>/dev/null | grep "^{" > gpurun_out/r05/r05_soak_b262144_bench_line.json
+for s in rk4 rk3 rk2; do python bench.py --scheme $s --steps 12000 --warmup 500 --no-cpu-baseline --no-alt-scheme --no-parity-config 2>/dev/null | grep "^{" > gpurun_out/r05/r05_soak_${s}_bench_line.json; done
+OCCS="1 2" bash tools/pmc_occ2.sh > gpurun_out/r05/pmc_occ2.log 2>&1

@@ -12,6 +12,7 @@ run config5_uncertainty --uncertainty 0.2 --steps 1000 --warmup 100
 run b8_f32 --batch 8 --steps 1000 --warmup 100 --no-parity-config
 run b4096_f32 --batch 4096 --steps 1000 --warmup 100 --no-parity-config
 run b16384_f32 --batch 16384 --steps 1000 --warmup 100 --no-parity-config
+run b131072 --batch 131072 --steps 300 --warmup 30 --no-parity-config
 run b262144 --batch 262144 --steps 300 --warmup 30 --no-parity-config
 run b524288 --batch 524288 --steps 200 --warmup 20 --no-parity-config
 run rk4 --scheme rk4 --steps 1000 --warmup 100
