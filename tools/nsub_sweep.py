@@ -13,7 +13,7 @@ scheme = sys.argv[1] if len(sys.argv) > 1 else "ls5"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 B = 65536
 w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024); starts = np.arange(0, 35040 - 5760 - 60, 96)
-for n_sub in ((120, 124, 128, 132, 136, 140, 144, 152) if scheme == "ls5" else (224, 232, 240, 248, 256)):
+for n_sub in ((104, 112, 120, 124, 128, 132, 136, 144) if scheme == "ls5" else (224, 232, 240, 248, 256)):
     env = TomatoVecEnv(B, weather=w, dtype="float32", scheme=scheme, n_sub=n_sub, season_length=60, pred_horizon=0.5, seed=666, start_rows=starts, auto_reset=True)
     env.reset_tensor()
     env.x_T.mul_(1 + 1e-3 * torch.randn(env.x_T.shape, device=env.device, generator=torch.Generator(device=env.device).manual_seed(1234)).to(env.tdtype))
