@@ -198,10 +198,14 @@ def test_slowest_lanes_of_the_bench_workload_stay_cheap(hostmath, oracle, golden
     p = golden("params_default")["p"].astype(np.float64)
     X, U, D = g["X"], g["U"], g["D"]
     scale = np.maximum(np.abs(X).max(axis=0), 1e-3)
-    steps64, steps32, worst = [], [], 0.0
+    import ctypes
+    last_windows = oracle.lib().gl_oracle_last_windows
+    last_windows.restype = ctypes.c_double
+    steps64, steps32, windows, worst = [], [], [], 0.0
     for i in range(len(X)):
         truth = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, 4096, 4, 4)[0]
         ref, retries, refined, failed = oracle.rk_sc_guarded(X[i], U[i], D[i], p, 900.0, 128, 5, 2)
+        windows.append(last_windows())
         assert not failed and retries == 0
         out, st = hostmath.step_scheme(X[i], U[i], D[i], p, False, 900.0, 128, 5, 2, stats=True)
         assert int(st[0]) == 128 + refined and int(st[1]) == 0, (i, st, refined)          # decision for decision
@@ -209,7 +213,8 @@ def test_slowest_lanes_of_the_bench_workload_stay_cheap(hostmath, oracle, golden
         out32, st32 = hostmath.step_scheme(X[i], U[i], D[i], p, True, 900.0, 128, 5, 2, stats=True)
         steps64.append(st[0]); steps32.append(st32[0])
         worst = max(worst, float(np.max(np.abs(out32 - truth) / np.maximum(np.abs(truth), scale))))
-    print(f"heavy tuples: round 4's rule took {128 + g['extra_round4_rule'].mean():.0f} sub-steps on average (GPU), now {np.mean(steps64):.0f} "
+    print(f"heavy tuples: windows {np.mean(windows):.1f} on average (nominal 64, max {max(windows):.0f}); round 4's rule took {128 + g['extra_round4_rule'].mean():.0f} sub-steps on average (GPU), now {np.mean(steps64):.0f} "
           f"(fp64) / {np.mean(steps32):.0f} (fp32), max {max(steps32):.0f}; fp32 result vs RK4-4096: {worst:.1e}")
     assert np.mean(steps64) < 150 and np.mean(steps32) < 150 and max(steps32) < 200
+    assert 64 <= min(windows) and np.mean(windows) < 72 and max(windows) < 100       # windows shrink with the bound, by a few per cent; never 2x
     assert worst < 3e-5
