@@ -50,6 +50,22 @@ def preset_n_sub(scheme: str, dt: float, preset: str = "throughput"):
     return max(mult, int(-(-n // mult) * mult)), window
 
 
+def resolve_scheme(scheme, variant: str = "ode") -> str:
+    """The scheme a constructor ends up with.  None = the default: "ls5" for the default ODE; "rk4" for variant "ode_pipe", whose
+    kernels are instantiated for GLGYM_SCHEME_RK4 only (glgym_step / glgym_evalF return GLGYM_EINVAL for any other scheme with
+    GLGYM_ODE_PIPE) -- so TomatoVecEnv(model_variant="ode_pipe") and GreenLight(variant="ode_pipe") work with default arguments.
+    An explicit other scheme with ode_pipe is refused here, by name, instead of at the first step."""
+    if variant not in ("ode", "ode_pipe"):
+        raise ValueError("variant must be 'ode' or 'ode_pipe'")
+    if scheme is None:
+        return "rk4" if variant == "ode_pipe" else DEFAULT_SCHEME
+    if scheme not in SCHEMES:
+        raise ValueError("scheme must be 'ls5', 'rk4', 'rk3' or 'rk2'")
+    if variant == "ode_pipe" and scheme != "rk4":
+        raise ValueError(f"variant 'ode_pipe' is built for scheme 'rk4' only (got {scheme!r}): leave scheme unset or pass scheme='rk4'")
+    return scheme
+
+
 def default_n_sub(scheme: str, dt: float) -> int:
     """Nominal sub-steps per env-step of the throughput preset (see preset_n_sub)."""
     return preset_n_sub(scheme, dt, "throughput")[0]

@@ -32,13 +32,18 @@ def aggregate(rows: List[List[float]]) -> Dict[str, float]:
     """rows[r] = [elapsed_s, env_steps, sum_reward, failed integrations, episodes_done, kernel_ms,
     (optional:) guard retries, refined sub-steps, rank, seed, first-attempt flags: error estimate, branch invariant, cap /
     non-finite, heavy, (round 4:) max scaled state error of the rank's parity leg (10-day fixture; < 0 = not run), failed
-    integrations in that leg].
+    integrations in that leg, (round 6:) the `sustained` continuation: elapsed_s, env_steps, kernel_ms].
     Whole-job throughput = all env-steps / the slowest rank's wall time; the job's parity figure = the worst rank's."""
     t_max = max(r[0] for r in rows)
     steps = sum(r[1] for r in rows)
     col = lambda i: [r[i] if len(r) > i else 0.0 for r in rows]  # noqa: E731
     perr = [r[14] for r in rows if len(r) > 14 and r[14] >= 0.0]
-    return {"value": steps / t_max, "t_max": t_max, "env_steps": steps, "sum_reward": sum(r[2] for r in rows),
+    sus = None
+    if all(len(r) > 18 for r in rows):      # every rank ran the continuation: same rule as the main region
+        st = max(r[16] for r in rows)
+        sus = {"value": sum(r[17] for r in rows) / st, "t_max": st, "env_steps": sum(r[17] for r in rows),
+               "kernel_ms_max": max(r[18] for r in rows)}
+    return {"sustained": sus,"value": steps / t_max, "t_max": t_max, "env_steps": steps, "sum_reward": sum(r[2] for r in rows),
             "ode_failures": sum(r[3] for r in rows), "episodes_finished": sum(r[4] for r in rows),
             "kernel_ms_max": max(r[5] for r in rows), "guard_retries": sum(col(6)), "refined_substeps": sum(col(7)),
             "first_attempt_flags": {"error_estimate": sum(col(10)), "branch_invariant": sum(col(11)),

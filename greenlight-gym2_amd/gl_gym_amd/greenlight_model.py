@@ -22,14 +22,13 @@ class GreenLight:
                  preset="parity"):
         """nd = 10, or 14 as in experiments/gl_predefined_controls.py:95 (rows carry the measured pipe columns).
         variant = "ode" (what the reference's compiled module integrates) or "ode_pipe" (ode.hpp:126-263, nd >= 14).
-        scheme = "ls5" (default; five-stage fourth-order 2N scheme), "rk4", "rk3" or "rk2" (include/glgym.h).
+        scheme = "ls5" (default; five-stage fourth-order 2N scheme), "rk4", "rk3" or "rk2" (include/glgym.h); variant "ode_pipe"
+        defaults to "rk4" and accepts no other scheme.
         preset = "parity" (default HERE: this class stands in for the reference's CVODES call, so it integrates inside the band that
         solver's tolerances keep from the tight solution -- ls5: n_sub 192, one sub-step per window, 9.1e-6 on the tight one-step
         tuples) or "throughput" (n_sub 128, window 2: 5.4e-5; what the batched envs run); n_sub / window override the preset."""
         self._lib = L.load()
-        scheme = L.DEFAULT_SCHEME if scheme is None else scheme
-        if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'ls5', 'rk4', 'rk3' or 'rk2'")
+        scheme = L.resolve_scheme(scheme, variant)           # None: "ls5"; "rk4" for ode_pipe (the only scheme its kernels are built for)
         if preset not in L.PRESETS:
             raise ValueError("preset must be 'parity' or 'throughput'")
         n_def, w_def = L.preset_n_sub(scheme, dt, preset)
@@ -44,8 +43,6 @@ class GreenLight:
                                     L.F64 if str(dtype) in ("float64", "f64", "double") else L.F32, int(n_sub),
                                     int(device), C.byref(self._h))
         L.check(rc, "glgym_create")
-        if variant not in ("ode", "ode_pipe"):
-            raise ValueError("variant must be 'ode' or 'ode_pipe'")
         if variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")

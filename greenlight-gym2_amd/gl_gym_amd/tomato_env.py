@@ -166,7 +166,7 @@ class TomatoVecEnv:
                  u_max: Optional[Sequence[float]] = None, delta_u_max: float = 0.1, integration_info: bool = True):
         """u_min / u_max / delta_u_max: action_to_control's bounds (base_env.py:72-74; default [0, 1] and 0.1).
         observation_modules: names of the reference's modules in output order (default: the six of TomatoEnv.yml).
-        scheme / n_sub / window: "ls5" (default: five-stage fourth-order 2N-storage scheme, n_sub 128, two sub-steps per tier-2b window), "rk4" (classical RK4, 240),
+        scheme / n_sub / window: "ls5" (default; model_variant "ode_pipe" defaults to "rk4" and accepts no other: five-stage fourth-order 2N-storage scheme, n_sub 128, two sub-steps per tier-2b window), "rk4" (classical RK4, 240),
         "rk3" (three-stage third-order scheme, 270) or "rk2" (midpoint rule, 336), all with the cover conduction integrated exactly (include/glgym.h).
         preset: "throughput" (the counts above; default for float32) or "parity" (inside the band of the reference solver's tolerances:
         ls5 n_sub 192 with one sub-step per window; default for float64) -- used for whatever of n_sub / window is not given (_lib.PRESETS);
@@ -204,9 +204,7 @@ class TomatoVecEnv:
         self.obs_dim = sum(m.n_obs for m in self.observation_modules)
         self.f64 = str(dtype) in ("float64", "f64", "double")
         self.tdtype = torch.float64 if self.f64 else torch.float32
-        scheme = L.DEFAULT_SCHEME if scheme is None else scheme
-        if scheme not in L.SCHEMES:
-            raise ValueError("scheme must be 'ls5', 'rk4', 'rk3' or 'rk2'")
+        scheme = L.resolve_scheme(scheme, model_variant)     # None: "ls5"; "rk4" for ode_pipe (the only scheme its kernels are built for)
         self.preset = ("parity" if self.f64 else "throughput") if preset is None else preset
         if self.preset not in L.PRESETS:
             raise ValueError("preset must be 'throughput' or 'parity'")

@@ -494,7 +494,8 @@ def g_jump():
                         truth_agreement=AG, seed=SEED)
 
 
-def _reference_env(season_length=1, uncertainty_scale=0.0, training=True, observation_modules=None):
+def _reference_env(season_length=1, uncertainty_scale=0.0, training=True, observation_modules=None, year=2009, start_day=0,
+                   dt=None, pred_horizon=None):
     """The reference's REAL TomatoEnv (gl_gym/environments/tomato_env.py, base_env.py, observations.py, rewards.py,
     noise.py, utils.py, parameters.py -- imported from /root/reference, nothing copied) with its two absent third-party
     dependencies substituted at import time:
@@ -535,8 +536,12 @@ def _reference_env(season_length=1, uncertainty_scale=0.0, training=True, observ
     base, spec = cfg["GreenLightEnv"], cfg["TomatoEnv"]
     # the Amsterdam KNMI files are not in the mount: Bleiswijk GL2009, day 0, a short season
     base.update(weather_data_dir=WEATHER_DIR, location="Bleiswijk", data_source="GL", season_length=season_length,
-                start_train_year=2009, end_train_year=2009, start_train_day=0, end_train_day=0, training=training)
-    spec["eval_options"] = dict(eval_days=[0], eval_years=[2009], location="Bleiswijk", data_source="GL")
+                start_train_year=year, end_train_year=year, start_train_day=start_day, end_train_day=start_day, training=training)
+    if dt is not None:
+        base["dt"] = dt                                   # experiments/run_time.py:27
+    if pred_horizon is not None:
+        base["pred_horizon"] = pred_horizon               # experiments/run_time.py:26
+    spec["eval_options"] = dict(eval_days=[start_day], eval_years=[year], location="Bleiswijk", data_source="GL")
     if observation_modules is not None:
         spec["observation_modules"] = list(observation_modules)
     env = TomatoEnv(base_env_params=base, uncertainty_scale=uncertainty_scale, **spec)
@@ -658,7 +663,145 @@ def g_refobs():
     np.savez_compressed(HERE / "refenv_obs_layouts.npz", n_layouts=len(layouts), **out)
 
 
-ALL = dict(jump=g_jump, refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
+# ---------------------------------------------------------------------------------------------
+# HOLD-OUT fixtures (round 6; VERDICT r05 "missing 1").  Every fixture above was in front of the builder while the sub-stepper's
+# ~16 constants were chosen.  These four were generated AFTER the constants were frozen (git: the commit that adds them touches no
+# SC_* constant) from inputs no earlier fixture touches: the reference's second weather file (Bleiswijk GL2010: winter, lamps and
+# heating on, tOut -8.5 ... 5.9 C), days 10-72 of GL2009, and the reference's own timing-harness configuration.
+def _sc_rows(X, XT, scale):
+    return np.max(np.abs(X - XT) / np.maximum(np.abs(XT), scale), axis=1)
+
+
+def _bdf_band(X, U, W, p, dt):
+    """Distance of a BDF rtol = atol = 1e-6 solve (the reference's CVODES settings, greenlight_model.cpp:51-52; scipy stand-in)
+    from the tight states: (a) one-step maps started from the tight state of every step, (b) the free-running BDF rollout."""
+    scale = 1e-3 * np.abs(X).max(axis=0)
+    one = np.zeros(len(U)); free = np.zeros(len(U))
+    xb = X[0].copy()
+    for k in range(len(U)):
+        y, _ = tight_step(X[k], U[k], W[k], p, dt=dt, tol=1e-6, method="BDF")
+        one[k] = _sc_rows(y[None], X[k + 1][None], scale)[0]
+        xb, _ = tight_step(xb, U[k], W[k], p, dt=dt, tol=1e-6, method="BDF")
+        free[k] = _sc_rows(xb[None], X[k + 1][None], scale)[0]
+    return one, free
+
+
+def g_holdout_random():
+    """(a) 10 days / 961 steps of Bleiswijk GL2010 from day 20 (10-20 February: frost, low sun, lamps and heating on), step()
+    semantics with Delta-u-bounded random actions from a new seed.  Truth Radau 1e-11; BDF-1e-6 band beside it."""
+    p = init_default_params(208).astype(np.float64)
+    w = load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2010, 20, 10, 1, 900, 10)
+    acts = np.random.default_rng(20261006).uniform(-1, 1, (961, 6)).astype(np.float32)
+    x = init_state(w[0]); u = np.zeros(6)
+    Xs = [x.copy()]; Us = []
+    for k in range(961):
+        u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))   # tomato_env.py:113 (f32 bounds)
+        x, _ = tight_step(x, u, w[k], p)
+        Xs.append(x.copy()); Us.append(np.array(u, dtype=np.float64))
+    X, U = np.array(Xs), np.array(Us)
+    one, free = _bdf_band(X, U, w, p, 900.0)
+    print("holdout_gl2010_random: tOut %.1f..%.1f, iGlob max %.0f, tAir %.1f..%.1f; BDF-1e-6 band: one-step %.2e, free-running %.2e"
+          % (w[:961, 1].min(), w[:961, 1].max(), w[:961, 0].max(), X[:, 2].min(), X[:, 2].max(), one.max(), free.max()))
+    np.savez_compressed(HERE / "holdout_gl2010_random.npz", actions=acts, weather=w[:1012], X=X, U=U, bdf_one_step=one, bdf_free=free)
+
+
+def _closed_loop_rule_based(env, n_max):
+    """The reference's RuleBasedController (baseline.py:68-227) in closed loop on the reference's TomatoEnv through
+    step_raw_control (experiments/evaluate_baseline.py:22-23); returns the recorded controls, states, rewards."""
+    ctrl = RuleBasedController(**RULE_BASED)
+    U, X, Rw = [], [np.array(env.x, dtype=np.float64)], []
+    done, k = False, 0
+    while not done and k < n_max:
+        u = np.array(ctrl.predict(env.x, env.weather_data[env.timestep], env), dtype=np.float64)
+        obs, r, done, trunc, info = env.step_raw_control(u)
+        U.append(u); X.append(np.array(env.x, dtype=np.float64)); Rw.append(float(r))
+        k += 1
+    return np.array(U), np.array(X), np.array(Rw)
+
+
+def g_holdout_rulebased():
+    """(b) the same ten GL2010 days under the reference's RuleBasedController: the REFERENCE's TomatoEnv (shims of _reference_env,
+    evalF = Radau 1e-11) in closed loop; the recorded bang-bang controls are what the tests replay through step_raw_control,
+    free-running (replayed controls: no closed-loop chaos, and the verified mode of raw-control steps is what gets tested)."""
+    env, base, spec = _reference_env(season_length=10, year=2010, start_day=20, pred_horizon=0)
+    env.reset(seed=666)
+    assert env.N == 960 and env.Np == 0
+    w = np.array(env.weather_data)
+    U, X, Rw = _closed_loop_rule_based(env, 2000)
+    assert len(U) == env.N + 1
+    p = np.asarray(env.p, dtype=np.float64)
+    one, free = _bdf_band(X, U, w, p, 900.0)
+    jumps = np.abs(np.diff(U, axis=0)).max(axis=1)
+    print("holdout_gl2010_rulebased: %d steps, control jumps > 0.5 in %d steps, lamps on in %d steps, sum reward %.3f; BDF-1e-6 band: "
+          "one-step %.2e, free-running %.2e" % (len(U), int((jumps > 0.5).sum()), int((U[:, 4] > 0.5).sum()), Rw.sum(), one.max(), free.max()))
+    np.savez_compressed(HERE / "holdout_gl2010_rulebased.npz", weather=w[:len(U) + 2], X=X, U=U, reward=Rw, p=np.asarray(env.p),
+                        bdf_one_step=one, bdf_free=free)
+
+
+def g_holdout_runtime():
+    """(c) the reference's timing harness, experiments/run_time.py:19-48: dt = 300 s, pred_horizon 0, season 10 days,
+    env.p = set_matlab_params(env.p) (gl_predefined_controls.py:70-77: six overrides -> the kernels' GENERIC parameter path),
+    set_crop_state(cBuf=0, cLeaf=0.9e5, cStem=2.5e5, cFruit=2.8e5, tCanSum=3000), raw controls through step_raw_control.
+    The harness's control / weather CSVs (data/AgriControl/...) are not in the mount: weather = GL2010 from day 35 through the
+    reference's loader at h = 300, controls = the reference's rule-based controller recorded in closed loop (2 881 steps)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("gl_predefined_controls", "/root/reference/gl_gym/experiments/gl_predefined_controls.py")
+    env, base, spec = _reference_env(season_length=10, year=2010, start_day=35, dt=300, pred_horizon=0)
+    mod = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(mod)       # (main-guarded; imports TomatoEnv under the shims)
+    env.reset(seed=666)
+    env.p = mod.set_matlab_params(env.p)
+    env.reset(seed=666)                                                                # run_time.py:40-43
+    env.set_crop_state(cBuf=0, cLeaf=0.9e5, cStem=2.5e5, cFruit=2.8e5, tCanSum=3000)
+    assert env.N == 2880 and env.dt == 300 and env.Np == 0
+    w = np.array(env.weather_data)
+    x0 = np.array(env.x, dtype=np.float64)
+    U, X, Rw = _closed_loop_rule_based(env, 5000)
+    assert len(U) == env.N + 1 and np.array_equal(X[0], x0)
+    p = np.asarray(env.p, dtype=np.float64)
+    one, free = _bdf_band(X, U, w, p, 300.0)
+    print("holdout_runtime_dt300: %d steps, cFruit %.0f -> %.0f (cFruitMax %.0f), sum reward %.3f; BDF-1e-6 band: one-step %.2e, "
+          "free-running %.2e" % (len(U), X[0, 25], X[-1, 25], p[145], Rw.sum(), one.max(), free.max()))
+    np.savez_compressed(HERE / "holdout_runtime_dt300.npz", weather=w[:len(U) + 2], X=X[::3], X_last=X[-1], x0=x0, U=U.astype(np.float32),
+                        reward=Rw, p=np.asarray(env.p), bdf_one_step=one, bdf_free=free)
+
+
+def _season_one(args):
+    b, x0, acts_q, w, p = args
+    x = x0.copy(); u = np.zeros(6)
+    keep = [x.copy()]
+    for k in range(len(acts_q)):
+        a = acts_q[k].astype(np.float32) / np.float32(127.0)
+        u = np.clip(u + a * np.float32(0.1), np.float32(0), np.float32(1))
+        x, _ = tight_step(x, u, w[k], p)
+        if (k + 1) % 96 == 0 or k == len(acts_q) - 1:
+            keep.append(x.copy())
+    return np.array(keep)
+
+
+def g_holdout_season():
+    """(d) the reference's default episode (configs/envs/TomatoEnv.yml:16, season_length 60: 5 761 steps) for 8 DISTINCT
+    environments: Bleiswijk GL2009 from day 10 (the earlier fixtures use days 0-10), episode starts six hours apart, per-env
+    random actions (stored as int8 q, action = q / 127 in float32), Radau 1e-11 truth kept once per day and at the end."""
+    from concurrent.futures import ProcessPoolExecutor
+    p = init_default_params(208).astype(np.float64)
+    w = load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2009, 10, 61.75, 1, 900, 10)
+    starts = 24 * np.arange(8)
+    n_steps = 5761
+    assert starts[-1] + n_steps + 50 <= len(w), len(w)
+    q = np.random.default_rng(20261007).integers(-127, 128, (8, n_steps, 6)).astype(np.int8)
+    jobs = [(b, init_state(w[starts[b]]), q[b], w[starts[b]:starts[b] + n_steps], p) for b in range(8)]
+    with ProcessPoolExecutor(8) as ex:
+        X = np.array(list(ex.map(_season_one, jobs)))
+    days = np.append(np.arange(0, 5761, 96), 5761)
+    assert X.shape == (8, len(days), 28)
+    print("holdout_season60: 8 envs x %d steps, cFruit at the end %.3e..%.3e, tCanSum %.0f..%.0f" %
+          (n_steps, X[:, -1, 25].min(), X[:, -1, 25].max(), X[:, -1, 26].min(), X[:, -1, 26].max()))
+    np.savez_compressed(HERE / "holdout_season60.npz", weather=w[:starts[-1] + n_steps + 50].astype(np.float64), start_rows=starts,
+                        actions_q=q, X=X, kept_steps=days)
+
+
+ALL = dict(holdout_random=g_holdout_random, holdout_rulebased=g_holdout_rulebased, holdout_runtime=g_holdout_runtime,
+           holdout_season=g_holdout_season, jump=g_jump, refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
 if __name__ == "__main__":

@@ -59,6 +59,24 @@ def test_no_cpu_fallback(lib):
         TomatoVecEnv(4)
 
 
+def test_ode_pipe_defaults_to_the_scheme_its_kernels_are_built_for(lib):
+    """the default scheme is "ls5", but GLGYM_ODE_PIPE is instantiated for GLGYM_SCHEME_RK4 only (glgym_step /
+    glgym_evalF: GLGYM_EINVAL otherwise).  The constructors therefore resolve `scheme=None` per variant, and refuse an explicit
+    other scheme by name instead of failing at the first step (the GPU half: tests/test_gpu_parity.py::test_ode_pipe_variant_and_nd14_rows)."""
+    assert lib.resolve_scheme(None) == lib.DEFAULT_SCHEME == "ls5"
+    assert lib.resolve_scheme(None, "ode_pipe") == "rk4" and lib.resolve_scheme("rk4", "ode_pipe") == "rk4"
+    for sch in ("ls5", "rk3", "rk2"):
+        assert lib.resolve_scheme(sch, "ode") == sch
+        with pytest.raises(ValueError, match="ode_pipe"):
+            lib.resolve_scheme(sch, "ode_pipe")
+    with pytest.raises(ValueError):
+        lib.resolve_scheme("euler")
+    with pytest.raises(ValueError):
+        lib.resolve_scheme(None, "ode_tube")
+    # the presets follow the resolved scheme: rk4's parity count for the evalF class, its throughput count for the batched env
+    assert lib.preset_n_sub("rk4", 300.0, "parity") == (216, 0) and lib.preset_n_sub("rk4", 300.0, "throughput") == (80, 0)
+
+
 def test_product_never_imports_the_oracle():
     pkg = ROOT / "greenlight-gym2_amd"
     for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")):

@@ -1,0 +1,205 @@
+"""HOLD-OUT parity (round 6; VERDICT r05 "missing 1" / "next 1"): the HIP path through the C ABI on fixtures the sub-stepper's
+constants have NOT seen.
+
+Every other accuracy fixture (step_tight, storm, jump, the two rollouts, the bench tuples) was in front of the builder while the
+~16 constants of the stability control were chosen.  The four fixtures here were generated after those constants were frozen
+(tests/golden/make_golden.py g_holdout_*; the commit that adds them touches no SC_* constant), from inputs none of the earlier
+ones touch:
+  holdout_gl2010_random     10 days of the reference's SECOND weather file (Bleiswijk GL2010 from day 20: frost, -8.5 ... 5.9 C,
+                            low sun, lamps and heating on), step() with Delta-u-bounded random actions from a new seed;
+  holdout_gl2010_rulebased  the same days under the reference's RuleBasedController: its recorded bang-bang controls (656 of 961
+                            steps jump by more than 0.5) replayed through step_raw_control, FREE-RUNNING, i.e. verified mode;
+  holdout_runtime_dt300     the reference's timing harness (experiments/run_time.py:19-48): dt = 300 s, pred_horizon 0,
+                            set_matlab_params (-> the kernels' GENERIC parameter path), set_crop_state(cBuf = 0, cFruit = 2.8e5 ...:
+                            inside the fruit-harvest zone), 2 881 raw-control steps on GL2010 from day 35;
+  holdout_season60          the reference's default 60-day episode (5 761 steps) for 8 distinct environments (GL2009 from day
+                            10, starts six hours apart, their own actions).
+Truth: Radau rtol = atol = 1e-11 on the reference-text right-hand side (every step); the distance of a BDF solve at the
+reference's own tolerances (1e-6) from that truth is stored with each fixture (`bdf_one_step`, `bdf_free`).
+
+Matrix: throughput and parity presets x float32 / float64 x every kernel build a batch can take (float32: one lane per
+environment one-wave build, two-waves-per-SIMD build, four lanes per environment; float64: four lanes per environment).
+
+THE BAR, and what the frost fixture found (profiles/r06_holdout.txt has every number).  The metric is conftest.scaled_err,
+|dx| / max(|x|, 1e-3 max_t |x|).  In the frost fixtures the cover temperatures pass within 0.02 C of 0 C, where a relative error
+in degrees CELSIUS stops meaning anything: the floor 1e-3 x max_t |T| is 0.017 K there and the bar 1e-4 asks for 1.7e-6 K.
+float64 meets it anyway with the constants as shipped.  float32 as shipped in round 5 did not: 2.2e-4 (3.7e-6 K on a cover
+at 0.009 C; a BDF solve at the reference's tolerances is itself 9.3e-5 there) -- rounding of (T + 273.15) in the long-wave
+terms, not the scheme: the same build in float64 is at 4.4e-5 / 7.4e-6.  So the tests assert
+  (a) no state away from the freezing point above the bar, none failed, in every build;
+  (b) the plain metric: float64 within the bar (throughput) / inside the reference-tolerance band (parity);
+      float32: recorded, and bounded by a regression guard `F32_PLAIN_GUARD` per fixture.
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import judge_rollout as judge
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+REPORT = ROOT / "gpurun_out" / "r06_holdout.txt"
+# float32 regression guards on the PLAIN metric (measured values in profiles/r06_holdout.txt; the bar proper is asserted through
+# `judge` below: nothing above 1e-4 except temperatures within 2 C of the freezing point that are off by less than 2e-4 K -- the
+# rule tests/test_jump_fixture.py has used since round 3)
+F32_PLAIN_GUARD = {"holdout_gl2010_random": 1e-4, "holdout_gl2010_rulebased": 1e-4, "holdout_runtime_dt300": 1e-4,
+                   "holdout_season60": 1e-4}
+
+
+def report(line):
+    print(line)
+    try:
+        REPORT.parent.mkdir(exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+BUILDS = [("float32", "one", 1), ("float32", "one", 2), ("float32", "quad", 0), ("float64", "quad", 0)]
+BUILD_IDS = ["f32-one-lane", "f32-two-waves", "f32-quad", "f64-quad"]
+
+
+def make_env(g, dtype, layout, occ, preset, dt, season, B=64, params=None, pred_horizon=0.5, scheme=None, **kw):
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    env = TomatoVecEnv(B, weather=g["weather"], params=params, dtype=dtype, dt=dt, scheme=scheme, preset=preset, season_length=season,
+                       pred_horizon=pred_horizon, auto_reset=False, **kw)
+    if dtype == "float32":
+        env.set_layout(layout)
+        if occ:
+            env.set_occupancy(occ)
+    return env
+
+
+def rollout(env, n_steps, actions=None, controls=None, x0=None, keep_every=1):
+    """Free-running rollout of B identical environments; -> states of row 0 after every `keep_every` steps (float64, incl. the start)."""
+    import torch
+    B = env.B
+    env.reset_tensor()
+    if x0 is not None:
+        env.x_T[:, :B] = torch.as_tensor(x0, dtype=env.tdtype, device=env.device)[:, None]
+    src = torch.as_tensor(actions if actions is not None else controls, device=env.device,
+                          dtype=torch.float32 if actions is not None else env.tdtype)
+    keep = torch.empty(n_steps // keep_every + 1, 28, dtype=torch.float64, device=env.device)
+    keep[0] = env.x[0].double()
+    for k in range(n_steps):
+        row = src[k][None].expand(B, 6).contiguous()
+        if actions is not None:
+            env.step_tensor(row, want_obs=False)
+        else:
+            env.step_tensor(controls_t=row, want_obs=False)
+        if (k + 1) % keep_every == 0:
+            keep[(k + 1) // keep_every] = env.x[0].double()
+    assert bool((env.x_T[:, :B] == env.x_T[:, :1]).all())          # identical rows stay identical: lane independence
+    return keep.cpu().numpy()
+
+
+def check(name, tag, dtype, preset, X, XR, m, g, extra=""):
+    plain, who, step, real, floor = judge(X, XR)
+    band = float(g["bdf_free"].max()) if "bdf_free" in g.files else float("nan")
+    report(f"{name:26s} {tag:14s} {preset:10s} plain metric {plain:.2e} ({who} at kept step {step}); states above 1e-4 away from 0 C: {real} steps, "
+           f"at the 0 C floor: {floor} steps; failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}, refined sub-steps per env-step "
+           f"{m['n_refined_substeps'] / max(m['n_env_steps'], 1):.2f}; BDF-1e-6 free-running band {band:.2e}{extra}")
+    assert m["n_ode_fail"] == 0
+    assert real == 0, (name, tag, preset, plain, who, step)
+    if dtype == "float64":
+        assert floor == 0
+        if preset == "parity":      # inside the band a solve at the reference's own tolerances keeps from the truth -- and tight in absolute terms
+            assert plain < 2e-5 and (not np.isfinite(band) or plain <= band), (plain, band)
+        else:
+            assert plain < 1e-4, plain
+    else:
+        assert plain < F32_PLAIN_GUARD[name], (name, tag, preset, plain)
+
+
+@pytest.mark.parametrize("preset", ["throughput", "parity"])
+@pytest.mark.parametrize("dtype,layout,occ", BUILDS, ids=BUILD_IDS)
+def test_holdout_gl2010_random_actions(golden, dtype, layout, occ, preset):
+    g = golden("holdout_gl2010_random")
+    acts, XR = g["actions"], g["X"]
+    env = make_env(g, dtype, layout, occ, preset, 900.0, 10)
+    assert (env.scheme, env.n_sub, env.window) == (("ls5", 128, 0) if preset == "throughput" else ("ls5", 192, 1))
+    X = rollout(env, len(acts), actions=acts)
+    check("holdout_gl2010_random", BUILD_IDS[BUILDS.index((dtype, layout, occ))], dtype, preset, X, XR, env.metrics(), g)
+    env.close()
+
+
+@pytest.mark.parametrize("preset", ["throughput", "parity"])
+@pytest.mark.parametrize("dtype,layout,occ", BUILDS, ids=BUILD_IDS)
+def test_holdout_gl2010_rule_based_controls_replayed_free_running(golden, dtype, layout, occ, preset):
+    """step_raw_control semantics: verified integration (the control jumps), free-running over all 961 steps."""
+    g = golden("holdout_gl2010_rulebased")
+    U, XR = g["U"], g["X"]
+    env = make_env(g, dtype, layout, occ, preset, 900.0, 10, params=g["p"], pred_horizon=0)
+    X = rollout(env, len(U), controls=U)
+    m = env.metrics()
+    assert m["n_guard_retries"] >= 64 * len(U)                     # verified: at least one extra attempt per env-step
+    check("holdout_gl2010_rulebased", BUILD_IDS[BUILDS.index((dtype, layout, occ))], dtype, preset, X, XR, m, g)
+    env.close()
+
+
+@pytest.mark.parametrize("preset", ["throughput", "parity"])
+@pytest.mark.parametrize("dtype,layout,occ", [b for b in BUILDS if b[2] != 2], ids=[i for i, b in zip(BUILD_IDS, BUILDS) if b[2] != 2])
+def test_holdout_reference_timing_harness_dt300_matlab_params(golden, dtype, layout, occ, preset):
+    """experiments/run_time.py:19-48.  The six parameter overrides take the GENERIC kernels (constants in SGPRs / LDS instead of
+    literals; no two-waves-per-SIMD build exists for them), the crop state starts inside the fruit-harvest zone."""
+    g = golden("holdout_runtime_dt300")
+    U, XR = g["U"].astype(np.float64), np.vstack([g["X"], g["X_last"][None]]) if (len(g["U"]) % 3) else g["X"]
+    assert len(U) == 2881 and not np.array_equal(g["p"], golden("params_default")["p"])
+    env = make_env(g, dtype, layout, occ, preset, 300.0, 10, params=g["p"], pred_horizon=0)
+    assert env.N == 2880 and env.n_sub == (44 if preset == "throughput" else 64)
+    X = rollout(env, len(U), controls=U, x0=g["x0"], keep_every=3)
+    Xl = env.x[0].double().cpu().numpy()
+    X = np.vstack([X, Xl[None]]) if (len(U) % 3) else X
+    check("holdout_runtime_dt300", BUILD_IDS[BUILDS.index((dtype, layout, occ))], dtype, preset, X, XR, env.metrics(), g)
+    env.close()
+
+
+@pytest.mark.parametrize("preset", ["throughput", "parity"])
+@pytest.mark.parametrize("dtype,layout,occ", BUILDS, ids=BUILD_IDS)
+def test_holdout_60_day_season_eight_distinct_environments(golden, dtype, layout, occ, preset):
+    """configs/envs/TomatoEnv.yml:16 (season_length 60): 5 761 steps, 8 environments with their own weather offsets and actions
+    (replicated 8 x over the 64 rows), truth kept once per day."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = golden("holdout_season60")
+    w, starts, q, XR, kept = g["weather"], g["start_rows"], g["actions_q"], g["X"], g["kept_steps"]
+    n_steps = q.shape[1]
+    B = 64
+    env = TomatoVecEnv(B, weather=w, dtype=dtype, preset=preset, season_length=60, pred_horizon=0.5, auto_reset=False,
+                       start_rows=list(starts), start_days=[0.0] * len(starts))
+    if dtype == "float32":
+        env.set_layout(layout)
+        if occ:
+            env.set_occupancy(occ)
+    env.reset_tensor()
+    # row b runs environment b % 8: its start row, the reset state of that row, its action stream
+    from gl_gym_amd.utils import init_state
+    idx = np.arange(B) % 8
+    env.w_off_t.copy_(torch.as_tensor(starts[idx].astype(np.int32), device=env.device))
+    env.x_T[:, :B] = torch.as_tensor(np.array([init_state(w[starts[i]]) for i in idx]).T, dtype=env.tdtype, device=env.device)
+    env.u_T.zero_()
+    acts = (torch.as_tensor(q, device=env.device).to(torch.float32) / 127.0)[torch.as_tensor(idx, device=env.device)]      # [B, n_steps, 6]
+    keep = torch.empty(len(kept), 8, 28, dtype=torch.float64, device=env.device)
+    keep[0] = env.x[:8].double()
+    j = 1
+    for k in range(n_steps):
+        env.step_tensor(acts[:, k].contiguous(), want_obs=False)
+        if k + 1 == kept[j]:
+            keep[j] = env.x[:8].double()
+            j += 1
+    assert j == len(kept) and bool((env.x_T[:, :8] == env.x_T[:, 56:64]).all())
+    X = keep.cpu().numpy().transpose(1, 0, 2)                            # [8, days, 28]
+    m = env.metrics()
+    worst = max(judge(X[b], XR[b]) for b in range(8))
+    tag = BUILD_IDS[BUILDS.index((dtype, layout, occ))]
+    real = sum(judge(X[b], XR[b])[3] for b in range(8)); floor = sum(judge(X[b], XR[b])[4] for b in range(8))
+    report(f"{'holdout_season60':26s} {tag:14s} {preset:10s} plain metric {worst[0]:.2e} ({worst[1]} at day {worst[2]}; worst of 8 environments); states above 1e-4 "
+           f"away from 0 C: {real}, at the 0 C floor: {floor}; failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}, refined sub-steps per "
+           f"env-step {m['n_refined_substeps'] / max(m['n_env_steps'], 1):.2f}")
+    assert m["n_ode_fail"] == 0 and real == 0
+    assert worst[0] < (F32_PLAIN_GUARD["holdout_season60"] if dtype == "float32" else (2e-5 if preset == "parity" else 1e-4))
+    env.close()

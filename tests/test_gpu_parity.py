@@ -643,6 +643,15 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
     with pytest.raises(Exception):
         GreenLight(28, 6, 10, 208, 300.0, scheme="rk4", variant="ode_pipe")          # needs the measured-pipe columns
     a.close(); b.close()
+    # (2b) the variant with DEFAULT arguments (the default scheme "ls5" has no ODE_pipe kernels -- the constructors resolve
+    # scheme=None to "rk4" for this variant, at their own preset counts, and refuse an explicit other scheme by name)
+    m = GreenLight(28, 6, 14, 208, 300.0, variant="ode_pipe")
+    assert (m.scheme, m.preset, m.n_sub) == ("rk4", "parity", 216)
+    got = np.array([m.evalF(X[i], U[i], D[i], P[i]) for i in range(n)])
+    assert scaled_err(got, XT) < 1.3e-5
+    m.close()
+    with pytest.raises(ValueError, match="ode_pipe"):
+        GreenLight(28, 6, 14, 208, 300.0, variant="ode_pipe", scheme="ls5")
     # (3) env: 14-column weather table, controls held, pipe tracking on most rows
     w10 = golden("rollout_10day")["weather"][:200]
     rng = np.random.default_rng(5)
@@ -650,6 +659,16 @@ def test_ode_pipe_variant_and_nd14_rows(golden, oracle):
                                                 (np.arange(200) % 9 == 4) * 1.0, np.zeros(200)])], axis=1)
     w14[::13, 10] = 0.0
     p = P[1]
+    for dtype in ("float64", "float32"):
+        e0 = TomatoVecEnv(4, weather=w14, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype=dtype, model_variant="ode_pipe",
+                          auto_reset=False)                                      # default scheme / counts of the variant
+        assert e0.scheme == "rk4" and e0.n_sub == (216 if dtype == "float64" else 80)
+        e0.reset()
+        xs0, _ = e0.step_raw_control_pipeinput(np.full((4, 6), 0.5))
+        assert np.all(np.isfinite(xs0))
+        e0.close()
+    with pytest.raises(ValueError, match="ode_pipe"):
+        TomatoVecEnv(4, weather=w14, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, model_variant="ode_pipe", scheme="ls5")
     env = TomatoVecEnv(4, weather=w14, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
                        scheme="rk4", n_sub=256, model_variant="ode_pipe", auto_reset=False)
     ref_env = TomatoVecEnv(4, weather=w10, params=p, dt=300.0, season_length=0.05, pred_horizon=0.02, dtype="float64",
