@@ -48,10 +48,7 @@
 #define GL_WAVE_ANY(c) (c)
 #endif
 
-// stability control of the sub-stepper (rk_delta): fraction of the scheme's real-axis stability interval a sub-step may use
-#ifndef SC_SAFETY
-#define SC_SAFETY 0.92
-#endif
+// (the tunables of the stability control live in sc_policy.hpp, included below once Math<T> and the scheme coefficients exist)
 
 namespace glm {
 
@@ -215,6 +212,11 @@ template <> struct Math<float> {
     static GL_HD float min(float a, float b) { return ::fminf(a, b); }
     static GL_HD float max(float a, float b) { return ::fmaxf(a, b); }
 };
+
+}  // namespace glm
+// the scalar policy of the stability-controlled sub-stepper and every one of its tunables (needs Math<T> and ceil_pos above)
+#include "sc_policy.hpp"
+namespace glm {
 
 // ---------------------------------------------------------------------------------------------------
 // tier 1b: crop constants.  Uniform (part of ModelConst) unless per-env crop-parameter noise is on,
@@ -486,7 +488,7 @@ template <class T> struct StepCoef {
     // stomata (depend on rCan = a45 only)
     T cEvap3, cEvap4, rSK;      // a169, a170, p42*a171
     // FIR (sigma lives in the K^4 values)
-    T qSky;                     // (tSky+C2K)^4  (sigma is folded into every FIR coefficient)
+    T qSky;                     // Q4(tSky): (tSky+C2K)^4, in fp32 minus C2K^4 (sigma is folded into every FIR coefficient)
     T cCanCovIn, cCanSky, cCanThScr, cCanBlScr;                        // x aCan
     T cPipeCovIn, cPipeSky, cPipeThScr, cPipeBlScr;                    // x gap
     T cFlrCovIn, cFlrSky, cFlrThScr, cFlrBlScr;                        // x gap
@@ -523,6 +525,22 @@ template <class T> struct StepCoef {
 template <class T> struct Kelvin {
     static GL_HD T c2k() { return T(273.15); }
     static GL_HD T c2kF32() { return T((double)273.15f); }
+};
+
+// q(T) = (T + 273.15)^4 [K^4] of the long-wave terms (sigma lives in the coefficients).  It enters every balance only through
+// DIFFERENCES  c_ij (q_i - q_j).  fp64: formed as written.  fp32 (round 6): forming T + 273.15 first rounds the temperature to the
+// spacing of floats at 280 K, 3e-5 K -- a noise of 4 T^3 x 1.5e-5 K = 1.2e3 in q, i.e. 7e-5 W m-2 per exchange term, which moves a cover
+// face held between fluxes of tens of W m-2 K-1 by micro-kelvins: 2.2e-4 on the scaled metric where that face sits at 0.01 C (the frost
+// hold-out, tests/test_gpu_holdout.py).  The constant 273.15^4 cancels in every difference, so fp32 carries
+//     q'(T) = q(T) - 273.15^4 = T (4 T0^3 + T (6 T0^2 + T (4 T0 + T)))          (Horner in the CELSIUS temperature: add, 2 FMA, mul)
+// whose rounding error is relative to q' (|q'| <= 5e9 at 60 C, 8e5 at 0.01 C) instead of to 5.6e9: one more (packed) instruction per
+// surface pair and stage for a 15x quieter long-wave balance (frost hold-out, host build: 2.2e-4 -> 2.5e-5).  Same polynomial.
+template <class T> struct Q4 {
+    static GL_HD T of(T tC) { const T k = tC + Kelvin<T>::c2k(); const T k2 = k * k; return k2 * k2; }
+};
+template <> struct Q4<float> {
+    static constexpr float C1 = (float)(4.0 * 273.15), C2 = (float)(6.0 * 273.15 * 273.15), C3 = (float)(4.0 * 273.15 * 273.15 * 273.15);
+    static GL_HD float of(float tC) { return tC * (C3 + tC * (C2 + tC * (C1 + tC))); }
 };
 
 template <class T>
@@ -584,9 +602,7 @@ GL_HD void precompute(const T* u, const T* d, const ModelConst<T>& m, const Crop
     // -- FIR view factors (aux_states.hpp:476-691)
     const T tauThF = one - uTh * m.thOneMinusTauFir, tauBlF = one - uBl * m.blOneMinusTauFir;
     const T thbl = tauThF * tauBlF, uThBl = uTh * tauBlF;
-    const T skyK = tSky + Kelvin<T>::c2k();
-    const T sk2 = skyK * skyK;
-    s.qSky = sk2 * sk2;
+    s.qSky = Q4<T>::of(tSky);
     s.cCanCovIn = m.bCanCovIn * thbl;    s.cCanSky = m.bCanSky * thbl;
     s.cCanThScr = m.bCanThScr * uThBl;   s.cCanBlScr = m.bCanBlScr * uBl;
     s.cPipeCovIn = m.bPipeCovIn * thbl;  s.cPipeSky = m.bPipeSky * tauThF;      // :520 has no blackout factor
@@ -801,8 +817,7 @@ GL_HD void slow_coef(const T* ym, const StepCoef<T>& s, const ModelConst<T>& m, 
 
     // ---- grow pipes (aux_states.hpp:560, 930)
     {
-        const T c2k = Kelvin<T>::c2k();
-        auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };
+        auto q4 = [&](T tC) { return Q4<T>::of(tC); };
         const T dGA = ym[19] - tAir;
         q.hGroPipeAir = m.cGroPipeAir * M::powa(M::abs(dGA + eps), T(0.32)) * dGA;
         q.rGroPipeCan = m.fGroPipeCan * (q4(ym[19]) - q4(tCan));
@@ -825,8 +840,7 @@ template <class T> struct FirBlock {
                           const StepCoef<T>& s, const ModelConst<T>& m, FirNet<T>& f, T& qCan, T& qPipe, T& qFlr, T& qLamp,
                           T& qThScr, T& qBlScr, T& qCovIn)
     {
-        const T c2k = Kelvin<T>::c2k();
-        auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };
+        auto q4 = [&](T tC) { return Q4<T>::of(tC); };
         qCan = q4(tCan); qCovIn = q4(tCovIn); qThScr = q4(tThScr); qFlr = q4(tFlr);
         qPipe = q4(tPipe); qLamp = q4(tLamp); qBlScr = q4(tBlScr);
         const T qCovE = q4(tCovE), qSky = s.qSky;
@@ -880,7 +894,8 @@ template <> struct FirBlock<float> {
                                                float& qCan, float& qPipe, float& qFlr, float& qLamp, float& qThScr,
                                                float& qBlScr, float& qCovIn)
     {
-        auto q4 = [](gl_f2 tc) { const gl_f2 k = tc + sp(273.15f); const gl_f2 k2 = k * k; return k2 * k2; };
+        // Q4<float>::of on a register pair: v_pk_add, 2 x v_pk_fma, v_pk_mul
+        auto q4 = [](gl_f2 tc) { return tc * (sp(Q4<float>::C3) + tc * (sp(Q4<float>::C2) + tc * (sp(Q4<float>::C1) + tc))); };
         const gl_f2 qP1 = q4(mk(tCan, tPipe)), qP2 = q4(mk(tFlr, tLamp)), qP3 = q4(mk(tThScr, tBlScr));
         const gl_f2 qP4 = q4(mk(tCovIn, tCovE));
         qCan = qP1.x; qPipe = qP1.y; qFlr = qP2.x; qLamp = qP2.y; qThScr = qP3.x; qBlScr = qP3.y; qCovIn = qP4.x;
@@ -1143,7 +1158,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
     const T tCan24 = x[21], cLeaf = x[23], cFruit = x[25];
 
     // ---- long wave: net FIR gain of every surface (FirBlock above; aux_states.hpp:493-632)
-    auto q4 = [&](T tC) { const T k = tC + c2k; const T k2 = k * k; return k2 * k2; };   // sigma lives in the coefficients
+    auto q4 = [&](T tC) { return Q4<T>::of(tC); };   // sigma lives in the coefficients
     FirNet<T> fir;
     T qCan, qPipe, qFlr, qLamp, qThScr, qBlScr, qCovIn;
     FirBlock<T>::run(tCan, tPipe, tFlr, tLamp, tThScr, tBlScr, tCovIn, tCovE, q, s, m, fir, qCan, qPipe, qFlr, qLamp, qThScr,
@@ -1332,20 +1347,10 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         // skips its arithmetic otherwise)
         int sbits = 0;
         const bool want_far = side && GL_WAVE_ANY(*side != 0);
-        auto harmful = [&](T iCap, T hcoef, T hec, T g, T tSurf, T dT, T ddT, int j) {
-            const T tc = M::min(M::max(M::abs(tSurf), T(2)), T(40));
-            const T kap = iCap * M::abs(hcoef), G = LK * M::max(g, T(0));
-            const T kG = kap * G;
-            const T rfree = ddT + iCap * hec * (dT + LK * g);
-            const T kG3 = kG * kG * kG;
-            sbits |= (dT > T(0)) ? (8 << j) : 0;
-            if (want_far) sbits |= ((dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
-            return (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
-                   (kG3 > T(0.3) * rfree * rfree);
-        };
-        const bool harm5 = harmful(m.iCapCov, m.cTopCov, hTopCovAbs, gCov, tCovIn, dTopCov, dx[3] - dCovIn, 0);
-        const bool harm7 = harmful(m.iCapThScr, s.hTh, hecAirTh, gTh, tThScr, dATh, dx[2] - dx[7], 1);
-        const bool harm20 = harmful(m.iCapBlScr, s.hBl, hecAirBl, gBl, tBlScr, dABl, dx[2] - dx[20], 2);
+        // side bits + harm gate: sc_policy.hpp sc_wet_surface (one statement for both layouts)
+        const bool harm5 = sc_wet_surface<T>(true, 0, m.iCapCov, m.cTopCov, hTopCovAbs, gCov, tCovIn, dTopCov, dx[3] - dCovIn, LK, h_nominal, want_far, sbits);
+        const bool harm7 = sc_wet_surface<T>(true, 1, m.iCapThScr, s.hTh, hecAirTh, gTh, tThScr, dATh, dx[2] - dx[7], LK, h_nominal, want_far, sbits);
+        const bool harm20 = sc_wet_surface<T>(true, 2, m.iCapBlScr, s.hBl, hecAirBl, gBl, tBlScr, dABl, dx[2] - dx[20], LK, h_nominal, want_far, sbits);
         if (side) *side = sbits;
         T row5 = m.iCapCov * (base5 + f43 * hTopCovAbs);
         T r7 = m.iCapThScr * (base7 + f43 * hecAirTh);
@@ -1357,7 +1362,7 @@ GL_HD void rhs_fast(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, cons
         // a storm: 2 ... 15 1/s).  Otherwise the surface passes through dT = 0 at finite speed and only the smooth slope
         // counts.
         if (GL_WAVE_ANY(harm5 || harm7 || harm20)) {
-            const T look = T(4) * h_nominal;
+            const T look = T(SC_LOOK) * h_nominal;
             row5 = sc_pinned_rate<T>(harm5, m.iCapCov, m.cTopCov, hTopCovAbs, LK * gCov, dTopCov, dx[3] - dCovIn, row5, look);
             r7 = sc_pinned_rate<T>(harm7, m.iCapThScr, s.hTh, hecAirTh, LK * gTh, dATh, dx[2] - dx[7], r7, look);
             r20 = sc_pinned_rate<T>(harm20, m.iCapBlScr, s.hBl, hecAirBl, LK * gBl, dABl, dx[2] - dx[20], r20, look);
@@ -1525,24 +1530,16 @@ template <> struct RkVec<float> {
 // It is checked at every window boundary (every sub-step once refined); SC_FLAG_ERR makes the guard redo the env-step
 // with 2x, then 4x windows.  oracle/gl_oracle.c (rk_sc_impl) restates all of it.
 // ---------------------------------------------------------------------------------------------------
-#ifndef SC_MAX_REFINE
-#define SC_MAX_REFINE 64
-#endif
-// After a control jump the fast states legitimately move by kelvins within seconds (the estimate decays 5x per window,
-// e.g. 0.16 K -> 0.034 -> 0.006 after a 0 -> 1 actuator jump at n_sub = 320): the estimate tolerance is SC_GRACE_MUL x
-// looser during the first SC_GRACE_S seconds of an env-step.  An instability keeps growing and is caught after that.
-#define SC_GRACE_S 60.0
-#define SC_GRACE_MUL 64.0
-#define SC_CAP_S 120.0
-#define SC_MOVE 8.0
-#define SC_MOVE_HMAX 4.0
-constexpr int SC_FLAG_CAP = 1, SC_FLAG_NONFINITE = 2, SC_FLAG_ERR = 4, SC_FLAG_BRANCH = 8;
+// (tunables, flags and every scalar decision of the scheme: sc_policy.hpp, included after the scheme coefficients below.  After a
+// control jump the fast states legitimately move by kelvins within seconds -- the estimate decays 5x per window, e.g. 0.16 K -> 0.034
+// -> 0.006 after a 0 -> 1 actuator jump at n_sub = 320 -- hence the grace period SC_GRACE_S / SC_GRACE_MUL; an instability keeps growing
+// and is caught after it.)
 constexpr int SC_NFAST = 9;
 GL_HD constexpr int sc_fast(int j) { return j == 0 ? 1 : j == 1 ? 3 : j == 2 ? 5 : j == 3 ? 6 : j == 4 ? 7 : j == 5 ? 15 : j == 6 ? 16 : j == 7 ? 17 : 20; }
 // 1 / tolerance of the per-sub-step error estimate: co2Top 12.5 mg m-3, temperatures 0.125 K (lamp 0.5 K), vapour
 // pressures 12.5 Pa.  Accurate steps stay below 0.07 x that on the storm fixture and below 1e-2 x on nominal rollouts
 // (outside the grace period below); an instability that has become visible in the state is far above it.
-GL_HD constexpr double sc_itol(int j) { return (j == 0 || j == 5 || j == 6) ? 1.0 / 12.5 : j == 7 ? 1.0 / 0.5 : 1.0 / 0.125; }
+GL_HD constexpr double sc_itol(int j) { return (j == 0 || j == 5 || j == 6) ? 1.0 / SC_TOL_P : j == 7 ? 1.0 / SC_TOL_LAMP : 1.0 / SC_TOL_T; }
 
 template <class T> struct ScStat {
     int n_steps;      // sub-steps taken
@@ -1658,8 +1655,7 @@ template <class T> GL_HD void ls_coefs(T a, T h, LsCoef<T>& c)
 // windows (SC_PRE_MARGIN x, at most SC_PRE_MAX x) instead of WIN + 1 longer sub-steps per window: a rate 5 % over the nominal limit
 // then costs that lane 5 % more stages, not 50 % -- and at one wave per SIMD the whole launch waits for its slowest lane.  What
 // changes inside the env-step is still followed window by window.
-#define SC_PRE_MARGIN 1.02
-#define SC_PRE_MAX 2.0
+// (SC_PRE_MARGIN = 1.02, SC_PRE_MAX = 2: sc_policy.hpp)
 // Round 5: that decision is taken at EVERY window, with the window's own (full) rate bound -- the window LENGTH follows the bound:
 //   sc = SC_PRE_MARGIN lam hnom_nominal / S   <= 1: the nominal window;
 //   <= SC_PRE_MAX: a window of hw_nominal / sc seconds (WIN sub-steps at the bound);
@@ -1673,16 +1669,16 @@ template <class T> GL_HD void ls_coefs(T a, T h, LsCoef<T>& c)
 // The exact harvest flow stays half a window ahead of the windows (the one just taken: the next one's length is not known yet).
 // Slowest lanes of the bench workload (396 env-steps with >= 40 extra sub-steps of 2.6e7): 269 -> 61 us extra on average; every
 // fixture unchanged (oracle/studies/lsrk_study_result.txt, fourth batch).  oracle/gl_oracle.c rk_sc_impl (gl_sc_varwin) restates it.
-#define SC_BURST_STEPS 8.0
-#define SC_BURST_DIV 8.0
-#define SC_KEEP 0.97
+// (SC_BURST_STEPS = 8, SC_BURST_DIV = 8, SC_KEEP = 0.97 and the rule itself: sc_policy.hpp sc_window_length)
 
 // win_rt > 0 overrides the compile-time window WIN at run time (glgym_set_window: e.g. ls5 with one sub-step per window = the parity preset)
 // WBUF (round 5, the two-waves-per-SIMD build): what the windows read ONCE each lives in a caller-provided buffer in LDS instead of
 // registers -- wbuf[0 .. NX) = z0 (the integrator's coordinates of x0, filled by the caller: x0 is not read), wbuf[NX .. NX + GL_N_SLOW)
 // = the previous window's increments of the slow slots, which share their storage with the window-start values they are differenced
-// against -- and `del` may point into LDS too: 28 + 28 + 18 + 18 + 28 (x0) registers that the 256-register build otherwise spills to
-// scratch, i.e. to L2 / HBM round trips at every window (glgym.hip step_kernel, OCC = 2).  Same arithmetic, same order.
+// against (GL_N_SLOW = 16 entries, ONE array for dprev and dwin) -- and `del` may point into LDS too: 28 (z0) + 16 (dprev / dwin) + 28 (del)
+// = 72 values per lane (73 with the odd stride), plus x0 which is re-read from global memory after the integrator -- registers that the
+// 256-register build otherwise spills to scratch, i.e. to L2 / HBM round trips at every window (glgym.hip step_kernel, OCC = 2).  Same
+// arithmetic, same order.
 template <class T, bool PIPE = false, int ORDER = 4, int WIN = 1, bool WBUF = false>
 GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, const CropConst<T>& cr, T dt,
                     int n_sub, T* del, ScStat<T>& st, int win_rt = 0, T* wbuf = nullptr)
@@ -1691,13 +1687,11 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
     using M = Math<T>;
     constexpr bool COVEXP = true;                  // every scheme of the family integrates the cover conduction exactly (round 4)
     const int WINR = win_rt > 0 ? win_rt : WIN;
-    const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0));
-    const T est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
-    // the nominal windows; the window about to be taken gets its own length from its rate bound (hw, hnom: see SC_PRE_MARGIN above)
-    const int n_win = (n_sub + WINR - 1) / WINR;
-    const T hw_nom = dt / T(n_win), hnom_nom = hw_nom / T(WINR), hmin = hnom_nom * T(1.0 / SC_MAX_REFINE);
+    const T S = ScScheme<T, ORDER>::S(), est_fac = ScScheme<T, ORDER>::est_fac();
+    // the nominal windows; the window about to be taken gets its own length from its rate bound (sc_policy.hpp sc_window_length)
+    const ScGrid<T> grid = sc_grid<T>(dt, n_sub, WINR);
+    const T hw_nom = grid.hw_nom, hnom_nom = grid.hnom_nom;
     T hw = hw_nom, hnom = hnom_nom;
-    const T t_grace = T((int)::ceil(SC_GRACE_S / (double)hw_nom)) * hw_nom + T(0.01) * hw_nom;
     T t_now = T(0), t_harv = T(0.5) * hw_nom;       // elapsed time; how far the exact harvest flow has been applied
     int n_left = 0;                                 // the equal windows the rest of the env-step was divided into when the last one was chosen
     T y[NX], xs[NX], k[NX], acc[NX], est[SC_NFAST];
@@ -1769,7 +1763,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         // in a saddle-node when the drive passes through zero, and feedback through the other exchange paths can turn the
         // drive positive again right after): 2 % of the raw-jump tuples, 7e-7 of the bench workload's env-steps, every
         // ladder level agreeing with the truth.
-        flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
+        flags |= sc_branch_flag(side_prev, side, capped_prev);
         side_prev = side;
         if (it > 0) {                                             // embedded error estimate of the previous sub-step
             T worst = T(0);
@@ -1779,29 +1773,14 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 const T wj = ((ORDER == 4 || ORDER == 3) && sc_fast(j) == 6) ? T(sc_itol(j)) * ec.w3 : T(sc_itol(j));
                 worst = M::max(worst, M::abs(est[j] - k[sc_fast(j)]) * wj);
             }
-            const T tolmul = (t_now <= t_grace) ? T(SC_GRACE_MUL) : T(1);
-            flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;    // NaN -> flagged
+            flags |= sc_estimate_flag<T>(grid, worst, h_last, est_fac, t_now);
         }
         if (closing) break;
-        {   // ---- this window's length from its rate bound (SC_PRE_MARGIN above)
-            const T sc = T(SC_PRE_MARGIN) * lam * hnom_nom * M::rcp(S);
-            T hw_t = hw_nom;                                      // (a NaN rate leaves the nominal window)
-            if (sc > T(1) && sc <= T(SC_PRE_MAX)) hw_t = hw_nom * M::rcp(sc);
-            else if (sc > T(SC_PRE_MAX))
-                hw_t = M::min(hw_nom * T(1.0 / SC_PRE_MAX), M::max(hw_nom * T(1.0 / SC_BURST_DIV), T(SC_BURST_STEPS / SC_PRE_MARGIN) * S * M::rcp(lam)));
-            // hysteresis (SC_KEEP): the window just taken keeps its length while that length is still allowed and at most 3 % shorter than
-            // what the bound now allows -- a storm lane's bound drifts by a fraction of a percent per window, and every new window length is
-            // a new sub-step length: five exponentials for the conduction coefficients, executed by the whole wavefront
-            const bool keep = it > 0 && !(hw > hw_t * T(1.0 + 1e-6)) && hw >= T(SC_KEEP) * hw_t;
-            hw_t = keep ? hw : hw_t;
-            const T nl = M::max(T(1), ceil_pos(t_left * M::rcp(hw_t) - T(1e-3)));
-            n_left = (int)nl;
-            hw = (nl <= T(1)) ? t_left : (keep ? hw : t_left * M::rcp(nl));
-            hnom = hw / T(WINR);
-        }
-        // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN
-        T hs = M::min(S * M::rcp(lam), hnom);
-        const T hs_stab = hs;                                     // what stability alone allows in this window
+        // ---- this window's length from its rate bound (a storm lane's bound drifts by a fraction of a percent per window, and every new
+        // window length is a new sub-step length -- five exponentials for the conduction coefficients, executed by the whole wavefront:
+        // hence the hysteresis SC_KEEP)
+        sc_window_length<T>(grid, S, lam, t_left, it == 0, hw, hnom, n_left);
+        // ---- this lane's sub-steps in the window: as many equal ones as stability asks for, never fewer than WIN (sc_plan)
         // accuracy limiter: no fast state (the lamp aside: linear, and it legitimately jumps by tens of K) may move by
         // more than SC_MOVE x its tolerance scale -- 1 K, 100 Pa, 100 mg m-3 -- in one sub-step.  It resolves the initial
         // layer of an env-step: the weather row and the controls jump, and a strongly ventilated top compartment (time
@@ -1826,27 +1805,19 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
                 }
             return mv;
         };
-        T move_allow = T(SC_MOVE);
-        if (ORDER == 5) move_allow = T(SC_MOVE) * M::min(M::max(S * M::rcp(lam * hnom), T(1)), T(SC_MOVE_HMAX));
-        bool limited0;
-        {
-            const T mv = fast_move(k, y[6]);
-            limited0 = mv * hs > move_allow;
-            hs = limited0 ? move_allow * M::rcp(mv) : hs;
-        }
-        const bool capped = !(hs >= hmin);                        // also true for a NaN rate
-        hs = capped ? hmin : hs;
+        const ScPlan<T> plan = sc_plan<T, ORDER>(grid, S, lam, hw, hnom, fast_move(k, y[6]));
+        const bool capped = plan.capped;
         t_cap += capped ? hw : T(0);
         capped_prev = capped;
-        T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
-        T h = hw * M::rcp(n_rem);
+        T n_rem = plan.n_rem;
+        T h = plan.h;
         h_last = h;
         // ORDER 5: a window whose sub-step was set by the limiter re-evaluates it with the first stage of EVERY sub-step and
         // re-partitions the REST of the window (the initial layer decays with a time constant of 1-2 s: the sub-step that resolves
         // its first second is 5-10 x shorter than what the window's last ten seconds need); at most doubling from one sub-step to
         // the next.  A window the limiter left alone is taken as before: n equal sub-steps.  Per lane; the wavefront only shares
         // whether the code runs at all.
-        const bool adaptive = (ORDER == 5) && limited0 && !capped;
+        const bool adaptive = plan.adaptive;
         T t_rem = hw;
         // ORDER 5: the fast states' increments of this WINDOW are accumulated apart (winc; stage input = y + winc with y = z0 + del of
         // the window's start) and reach del once, at the window's end.  The 2N scheme adds five stage increments per sub-step where
@@ -2035,16 +2006,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
             }
             if (ORDER == 5 && GL_WAVE_ANY(adaptive)) {
                 // the limiter again, with this sub-step's first stage; the rest of the window re-partitioned (rk_sc_impl restates it)
-                const T mvj = fast_move(k, w_now);
-                T hsj = (mvj * hs_stab > move_allow) ? move_allow * M::rcp(mvj) : hs_stab;
-                hsj = !(hsj >= hmin) ? hmin : hsj;
-                T nn = M::max(T(1), ceil_pos(t_rem * M::rcp(hsj) - T(1e-3)));
-                T hj = t_rem * M::rcp(nn);
-                const bool grow = hj > T(2.0001) * h;        // (2.0001: t_rem / nn IS 2 h in exact arithmetic when the doubling meets the equal partition)
-                hj = grow ? T(2) * h : hj;
-                nn = (grow && nn < T(2)) ? T(2) : nn;
-                h = adaptive ? hj : h;
-                n_rem = adaptive ? nn : n_rem;
+                sc_replan<T>(grid, plan, adaptive, t_rem, fast_move(k, w_now), h, n_rem);
                 h_last = h;
                 if (h != h_ec) { ls_coefs<T>(T(2) * gamCov, h, lc); h_ec = h; }
             }
@@ -2063,9 +2025,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
         for (int i = 0; i < NX; ++i)
             if (gl_slow_slot(i) >= 0) dprev[gl_slow_slot(i)] = del[i] - dwin[gl_slow_slot(i)];
         t_now = (n_left <= 1) ? dt : t_now + hw;
-        const T target = M::min(dt, t_now + T(0.5) * hw);
-        const T hh = M::max(T(0), target - t_harv);
-        t_harv = M::max(t_harv, target);
+        const T hh = sc_harvest_advance<T>(dt, t_now, hw, t_harv);
         del[23] += harvest_flow(z0[23] + del[23], cr.cLeafMax, hh);
         del[25] += harvest_flow(z0[25] + del[25], cr.cFruitMax, hh);
     }
@@ -2095,9 +2055,7 @@ GL_HD void rk_delta(const T* x0, const StepCoef<T>& s, const ModelConst<T>& m, c
 // Returns the number of extra attempts used (0 in the common case); *extra_steps = sub-steps beyond n_sub, all attempts.
 // oracle/gl_oracle.c (gl_oracle_rk_sc_guarded2) restates it.
 // ---------------------------------------------------------------------------------------------------
-#define SC_HEAVY 3
-#define SC_AGREE 1e-2
-#define SC_ATTEMPTS 4
+// (SC_HEAVY = 3, SC_AGREE = 1e-2, SC_ATTEMPTS = 4 and the acceptance rules: sc_policy.hpp sc_ladder_judge)
 template <class T> GL_HD bool all_finite(const T* v)
 {
     T chk = T(0);
@@ -2113,49 +2071,31 @@ GL_HD int rk4_delta_guarded(const T* x0, const StepCoef<T>& s, const ModelConst<
 {
     using M = Math<T>;
     const int WINR = win_rt > 0 ? win_rt : WIN;
-    int n = n_sub, extra = 0, total = 0;
-    bool done = false, ok = false, have_prev = false;
+    ScLadder L = sc_ladder_start(n_sub);
     T prev[SC_NFAST];
 #pragma unroll
     for (int j = 0; j < SC_NFAST; ++j) prev[j] = T(0);
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
-        if (done) break;
+        if (L.done) break;
         ScStat<T> st;
-        rk_delta<T, PIPE, ORDER, WIN, WBUF>(x0, s, m, cr, dt, n, del, st, win_rt, wbuf);
-        {
-            total += st.n_steps;
-            const int n_nom = ((n + WINR - 1) / WINR) * WINR;
-            // diagnostics: why the FIRST attempt was not accepted as it stood (SC_FLAG_* | 16 = SC_HEAVY sub-steps)
-            if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);
-            const bool complete = all_finite(del) && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE));
-            const bool clean = complete && st.flags == 0 && st.n_steps < SC_HEAVY * n_nom;
-            T worst = T(0);
+        rk_delta<T, PIPE, ORDER, WIN, WBUF>(x0, s, m, cr, dt, L.n, del, st, win_rt, wbuf);
+        // distance from the previous attempt on the nine fast states, in units of the estimate tolerances
+        T worst = T(0);
 #pragma unroll
-            for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(del[sc_fast(j)] - prev[j]) * T(sc_itol(j)));
-            // ... and the finest attempt is taken as it stands when nothing flagged it: where consecutive attempts disagree although
-            // each is resolved (env-steps that start ON a kink -- the reset state -- or pass a bifurcation: which branch a wet
-            // screen ends on is sensitive at the 1e-4 level for any solver), the best available answer beats a failed episode
-            // (agreement verifies flagged attempts too, the branch flag included: on 6 500 raw-jump tuples with half-hour spin-ups,
-            // tools/gpu_stress.py, 81 env-steps carried it at every level -- 80 agreeing with the fine truth, one agreeing on the
-            // wrong branch at 320 ... 2 560 sub-steps, where scipy's BDF at 1e-6 lands on the same wrong branch.  Refusing them all
-            // would trade one silent error for 80 false failures: profiles/r03_gpu_stress.txt)
-            const bool by_clean = clean && !verify, by_agree = complete && have_prev && worst <= T(SC_AGREE);
-            ok = by_clean || by_agree || (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
-            // how a result that was not simply a clean first-class attempt got accepted (glgym.h GLGYM_SF_*): 32 = by agreement
-            // although the accepted attempt carried a flag itself, 64 = the finest attempt alone, unflagged but not agreeing
-            // with the one before it (in verified mode as well)
-            if (first_flags && ok && !by_clean) *first_flags |= by_agree ? ((st.flags != 0) ? 32 : 0) : 64;
-            done = ok || attempt == SC_ATTEMPTS - 1;
-            have_prev = complete;
+        for (int j = 0; j < SC_NFAST; ++j) worst = M::max(worst, M::abs(del[sc_fast(j)] - prev[j]) * T(sc_itol(j)));
+        // (where consecutive attempts disagree although each is resolved -- env-steps that start ON a kink, the reset state, or pass a
+        // bifurcation: which branch a wet screen ends on is sensitive at the 1e-4 level for any solver -- the finest unflagged attempt
+        // beats a failed episode; agreement verifies flagged attempts too, the branch flag included: on 6 500 raw-jump tuples with
+        // half-hour spin-ups, tools/gpu_stress.py, 81 env-steps carried it at every level -- 80 agreeing with the fine truth, one
+        // agreeing on the wrong branch at 320 ... 2 560 sub-steps, where scipy's BDF at 1e-6 lands on the same wrong branch.  Refusing
+        // them all would trade one silent error for 80 false failures: profiles/r03_gpu_stress.txt)
+        sc_ladder_judge<T>(L, attempt, st.flags, st.n_steps, WINR, all_finite(del), worst, verify, first_flags);
 #pragma unroll
-            for (int j = 0; j < SC_NFAST; ++j) prev[j] = del[sc_fast(j)];
-            extra += done ? 0 : 1;
-        }
-        n *= 2;
+        for (int j = 0; j < SC_NFAST; ++j) prev[j] = del[sc_fast(j)];
     }
-    *failed = !ok;
-    if (extra_steps) { const int ex = total - ((n_sub + WINR - 1) / WINR) * WINR; *extra_steps = ex > 0 ? ex : 0; }
-    return extra;
+    *failed = !L.ok;
+    if (extra_steps) *extra_steps = sc_ladder_extra_steps(L, n_sub, WINR);
+    return L.extra;
 }
 
 template <class T, bool PIPE = false>

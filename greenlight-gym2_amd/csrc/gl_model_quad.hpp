@@ -235,7 +235,9 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const T TpX = scr ? tAir - y.p.x : cov ? tTop - y.p.x : y.p.x;
     const P2<T> Tp = gq_mk<T>(TpX, scr ? tAir - y.p.y : cov ? TpX - y.p.y : y.p.y);
     // ---- long wave: gather the eight q's, 4 source lanes x 2 packed terms
-    const P2<T> kk = Tp + gq_sp<T>(c2k), k2 = kk * kk, qp = k2 * k2;
+    P2<T> qp;                                                        // Q4<T>::of on the pair (fp32: the offset form, gl_model.hpp Q4)
+    if constexpr (sizeof(T) == 4) qp = Tp * (gq_sp<T>(Q4<float>::C3) + Tp * (gq_sp<T>(Q4<float>::C2) + Tp * (gq_sp<T>(Q4<float>::C1) + Tp)));
+    else { const P2<T> kk = Tp + gq_sp<T>(c2k), k2 = kk * kk; qp = k2 * k2; }
     P2<T> fir = K.cSky * (gq_sp<T>(s.qSky) - qp);
     {
         const T q0x = gq_bcast<0>(qp.x), q0y = gq_bcast<0>(qp.y), q1x = gq_bcast<1>(qp.x), q1y = gq_bcast<1>(qp.y);
@@ -249,7 +251,7 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     T dInt = T(0), hIntAir = T(0);
     if (m.intLampActive) {
         const T tInt = gq_bcast<3>(y.o[0]);                          // x18 lives on lane 3
-        const T ki = tInt + c2k, ki2 = ki * ki, qInt = ki2 * ki2;
+        const T qInt = Q4<T>::of(tInt);
         const P2<T> iTo = K.iC * (gq_sp<T>(qInt) - qp);              // into the pair's surfaces
         fir = fir + iTo;
         hIntAir = m.cIntLampAir * (tInt - tAir);
@@ -359,16 +361,10 @@ __device__ __forceinline__ T gq_rate_bound(int role, const QVec<T>& y, const QVe
     const bool want_far = GL_WAVE_ANY(*side != 0);          // in: was the window just taken capped? (rhs_fast<RATES>)
     T rows = T(0);
     auto surface = [&](bool on, int j, T iCap, T hcoef, T hecAbs, T g, T tSurf, T dT, T ddT, T base) {
-        // harm gate, side bits and (second pass) the pinned rate: gl_model.hpp harmful() / sc_pinned_rate()
-        const T tc = M::min(M::max(M::abs(tSurf), T(2)), T(40));
-        const T kap = iCap * M::abs(hcoef), G = LK * M::max(g, T(0));
-        const T kG = kap * G, rfree = ddT + iCap * hecAbs * (dT + LK * g), kG3 = kG * kG * kG;
-        sbits |= (on && dT > T(0)) ? (8 << j) : 0;
-        if (want_far) sbits |= (on && (dT < T(0)) && (rfree > T(0)) && (rfree * rfree * rfree < T(27.0 / 256.0) * kG3 * G)) ? (1 << j) : 0;
-        const bool harm = on && (kG * h_nominal > T(2.154e-3) * (T(1.5874) + T(0.26603) * (tc - T(2)))) && (dT > T(0)) && (rfree > T(0)) &&
-                          (kG3 > T(0.3) * rfree * rfree);
+        // harm gate and side bits: sc_policy.hpp sc_wet_surface; (second pass) the pinned rate: gl_model.hpp sc_pinned_rate()
+        const bool harm = sc_wet_surface<T>(on, j, iCap, hcoef, hecAbs, g, tSurf, dT, ddT, LK, h_nominal, want_far, sbits);
         T row = iCap * (base + f43 * hecAbs);
-        if (GL_WAVE_ANY(harm)) row = sc_pinned_rate_inl<T>(harm, iCap, hcoef, hecAbs, LK * g, dT, ddT, row, T(4) * h_nominal);
+        if (GL_WAVE_ANY(harm)) row = sc_pinned_rate_inl<T>(harm, iCap, hcoef, hecAbs, LK * g, dT, ddT, row, T(SC_LOOK) * h_nominal);
         rows = M::max(rows, on ? row : T(0));
     };
     // x component: cover (lane 3) | thermal screen (lane 2)
@@ -428,14 +424,14 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     static_assert(ORDER == 5 || ORDER == 4 || ORDER == 3 || ORDER == 2, "ORDER");
     using M = Math<T>;
     const int WINR = win_rt > 0 ? win_rt : WIN;               // run-time window (glgym_set_window), rk_delta
-    // the nominal windows; each window gets its own length from its rate bound (rk_delta, SC_PRE_MARGIN)
-    const int n_win = (n_sub + WINR - 1) / WINR;
-    const T hw_nom = dt / T(n_win), hnom_nom = hw_nom / T(WINR);
+    // the nominal windows; each window gets its own length from its rate bound (sc_policy.hpp: the decisions below are rk_delta's, by
+    // construction -- both layouts call the same functions)
+    const ScGrid<T> grid = sc_grid<T>(dt, n_sub, WINR);
+    const T hw_nom = grid.hw_nom, hnom_nom = grid.hnom_nom;
     T hw = hw_nom, hnom = hnom_nom;
-    const T t_grace = T((int)::ceil(SC_GRACE_S / (double)hw_nom)) * hw_nom + T(0.01) * hw_nom;
     T t_now = T(0), t_harv = T(0.5) * hw_nom;
     int n_left = 0;
-    const T S = T(SC_SAFETY * (ORDER == 5 ? Ls5<T>::S : ORDER == 4 ? 2.785 : ORDER == 3 ? 2.5127 : 2.0)), est_fac = T(ORDER == 5 ? Ls5<T>::B(4) : 1.0 / 6.0);
+    const T S = ScScheme<T, ORDER>::S(), est_fac = ScScheme<T, ORDER>::est_fac();
     T ls_Nprev = T(0), ls_hprev = T(0);       // ORDER 5, cover lane: N_w at the start of the previous sub-step and its length (0: none yet)
     const bool lane0 = role == 0, crop = role == 2, cov = role == 3;
     const T gam = m.iCapCov * m.cCovCond, cw = cov ? T(0.5) : T(0);
@@ -510,50 +506,27 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
         int side = capped_prev ? 1 : 0;
         T lam = gq_rate_bound<T>(role, y, k, R, K, s, m, hnom_nom, &side);
         if (PIPE) lam = (s.pipeTrack != T(0)) ? M::max(lam, T(1)) : lam;      // dxdt(9) = tPipeSet - x9: rate 1 1/s (rhs_fast<RATES, PIPE>)
-        flags |= ((((side_prev >> 3) & side & 7) != 0) && capped_prev) ? SC_FLAG_BRANCH : 0;
+        flags |= sc_branch_flag(side_prev, side, capped_prev);
         side_prev = side;
         if (it > 0) {
             QVec<T> dif;
             dif.p = estP - k.p;
             for (int i = 0; i < 6; ++i) dif.sh[i] = estS[i] - k.sh[i];
             const T worst = gq_max(gq_fast_max(dif, gq_mk<T>(gq_tol<T>(role).est.x, (ORDER == 4 || ORDER == 3) ? gq_tol<T>(role).est.y * K.ec.w3 : gq_tol<T>(role).est.y)));     // (the ETD component's estimate carries f3)
-            const T tolmul = (t_now <= t_grace) ? T(SC_GRACE_MUL) : T(1);
-            flags |= (worst * h_last * est_fac <= tolmul) ? 0 : SC_FLAG_ERR;
+            flags |= sc_estimate_flag<T>(grid, worst, h_last, est_fac, t_now);
         }
         if (closing) break;
-        {   // this window's length from its rate bound (rk_delta, decision for decision)
-            const T sc = T(SC_PRE_MARGIN) * lam * hnom_nom * M::rcp(S);
-            T hw_t = hw_nom;
-            if (sc > T(1) && sc <= T(SC_PRE_MAX)) hw_t = hw_nom * M::rcp(sc);
-            else if (sc > T(SC_PRE_MAX))
-                hw_t = M::min(hw_nom * T(1.0 / SC_PRE_MAX), M::max(hw_nom * T(1.0 / SC_BURST_DIV), T(SC_BURST_STEPS / SC_PRE_MARGIN) * S * M::rcp(lam)));
-            const bool keep = it > 0 && !(hw > hw_t * T(1.0 + 1e-6)) && hw >= T(SC_KEEP) * hw_t;      // hysteresis (rk_delta)
-            hw_t = keep ? hw : hw_t;
-            const T nl = M::max(T(1), ceil_pos(t_left * M::rcp(hw_t) - T(1e-3)));
-            n_left = (int)nl;
-            hw = (nl <= T(1)) ? t_left : (keep ? hw : t_left * M::rcp(nl));
-            hnom = hw / T(WINR);
-        }
-        T hs = M::min(S * M::rcp(lam), hnom);
-        const T hs_stab = hs;                                  // what stability alone allows in this window (rk_delta)
-        // movement limiter; ORDER 5: its allowance grows with the head-room the window's rate bound leaves below the stability limit
-        T move_allow = T(SC_MOVE);
-        if (ORDER == 5) move_allow = T(SC_MOVE) * M::min(M::max(S * M::rcp(lam * hnom), T(1)), T(SC_MOVE_HMAX));
-        bool limited0;
-        {
-            const T mv = gq_max(gq_fast_max(true_rates(k, y), gq_tol<T>(role).mov));
-            limited0 = mv * hs > move_allow;
-            hs = limited0 ? move_allow * M::rcp(mv) : hs;
-        }
-        const T hmin = hnom_nom * T(1.0 / SC_MAX_REFINE);
-        const bool capped = !(hs >= hmin);
-        hs = capped ? hmin : hs;
+        // this window's length from its rate bound; its sub-steps from stability, the movement limiter (the quad's largest movement
+        // rate) and the refinement cap (sc_policy.hpp)
+        sc_window_length<T>(grid, S, lam, t_left, it == 0, hw, hnom, n_left);
+        const ScPlan<T> plan = sc_plan<T, ORDER>(grid, S, lam, hw, hnom, gq_max(gq_fast_max(true_rates(k, y), gq_tol<T>(role).mov)));
+        const bool capped = plan.capped;
         t_cap += capped ? hw : T(0);
         capped_prev = capped;
-        T n_rem = M::max(T(1), ceil_pos(hw * M::rcp(hs) - T(1e-3)));
-        T h = hw * M::rcp(n_rem);
-        // ORDER 5: a limiter-bound window re-partitions its remainder sub-step by sub-step (rk_delta); uniform inside the quad
-        const bool adaptive = (ORDER == 5) && limited0 && !capped;
+        T n_rem = plan.n_rem;
+        T h = plan.h;
+        // ORDER 5: a limiter-bound window re-partitions its remainder sub-step by sub-step; uniform inside the quad
+        const bool adaptive = plan.adaptive;
         T t_rem = hw;
         if (h != h_last) {
             if (ORDER == 5) ls_coefs<T>(cov ? T(2) * gam : T(0), h, K.lc); else etd_coefs<T>(cov ? T(2) * gam : T(0), h, K.ec);
@@ -679,16 +652,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             }
             if (ORDER == 5 && GL_WAVE_ANY(adaptive)) {
                 // the limiter again with this sub-step's first stage; the rest of the window re-partitioned (rk_delta, decision for decision)
-                const T mvj = gq_max(gq_fast_max(true_rates(k, xs), gq_tol<T>(role).mov));
-                T hsj = (mvj * hs_stab > move_allow) ? move_allow * M::rcp(mvj) : hs_stab;
-                hsj = !(hsj >= hmin) ? hmin : hsj;
-                T nn = M::max(T(1), ceil_pos(t_rem * M::rcp(hsj) - T(1e-3)));
-                T hj = t_rem * M::rcp(nn);
-                const bool grow = hj > T(2.0001) * h;
-                hj = grow ? T(2) * h : hj;
-                nn = (grow && nn < T(2)) ? T(2) : nn;
-                h = adaptive ? hj : h;
-                n_rem = adaptive ? nn : n_rem;
+                sc_replan<T>(grid, plan, adaptive, t_rem, gq_max(gq_fast_max(true_rates(k, xs), gq_tol<T>(role).mov)), h, n_rem);
                 if (h != h_last) ls_coefs<T>(cov ? T(2) * gam : T(0), h, K.lc);
                 h_last = h;
             }
@@ -711,11 +675,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
             for (int j = 0; j < 7; ++j) dprev[j] = end7[j] - dwin[j];
         }
         t_now = (n_left <= 1) ? dt : t_now + hw;
-        {
-            const T target = M::min(dt, t_now + T(0.5) * hw);
-            harvest(M::max(T(0), target - t_harv));
-            t_harv = M::max(t_harv, target);
-        }
+        harvest(sc_harvest_advance<T>(dt, t_now, hw, t_harv));
     }
     if (role == 3) del.o[1] = dt * T(1.0 / 86400.0);          // x27 = time [days]
     st.n_steps = n_steps;
@@ -735,27 +695,20 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
                                                       const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps,
                                                       bool verify, int* first_flags, int win_rt = 0)
 {
-    using M = Math<T>;
     const int WINR = win_rt > 0 ? win_rt : WIN;
     const QTol<T> tol = gq_tol<T>(role);
-    int n = n_sub, extra = 0, total = 0;
-    bool done = false, ok = false, have_prev = false;
+    ScLadder L = sc_ladder_start(n_sub);
     QVec<T> prev;
     prev.p = gq_sp<T>(T(0));
     for (int i = 0; i < 6; ++i) prev.sh[i] = T(0);
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
-        if (done) break;                                   // uniform inside the quad: every decision below is
+        if (L.done) break;                                 // uniform inside the quad: every decision below is
         ScStat<T> st;
-        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
-        total += st.n_steps;
-        const int n_nom = ((n + WINR - 1) / WINR) * WINR;
-        if (first_flags && attempt == 0) *first_flags = st.flags | ((st.n_steps >= SC_HEAVY * n_nom) ? 16 : 0);
+        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, L.n, del, st, win_rt);
         T chk = (del.p.x + del.p.y) * T(0);
         for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
         for (int j = 0; j < 4; ++j) chk += del.o[j] * T(0);
         const bool finite = gq_or((chk == T(0)) ? 0 : 1) == 0;
-        const bool complete = finite && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE));
-        const bool clean = complete && st.flags == 0 && st.n_steps < SC_HEAVY * n_nom;
         QVec<T> now;
         gq_phys_pair<T>(role, del, now.p);
         for (int i = 0; i < 6; ++i) now.sh[i] = del.sh[i];
@@ -763,18 +716,12 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
         dif.p = now.p - prev.p;
         for (int i = 0; i < 6; ++i) dif.sh[i] = now.sh[i] - prev.sh[i];
         const T worst = gq_max(gq_fast_max(dif, tol.est));
-        const bool by_clean = clean && !verify, by_agree = complete && have_prev && worst <= T(SC_AGREE);
-        ok = by_clean || by_agree || (attempt == SC_ATTEMPTS - 1 && complete && st.flags == 0);
-        if (first_flags && ok && !by_clean) *first_flags |= by_agree ? ((st.flags != 0) ? 32 : 0) : 64;     // rk4_delta_guarded
-        done = ok || attempt == SC_ATTEMPTS - 1;
-        have_prev = complete;
+        sc_ladder_judge<T>(L, attempt, st.flags, st.n_steps, WINR, finite, worst, verify, first_flags);      // the acceptance rules: sc_policy.hpp
         prev = now;
-        extra += done ? 0 : 1;
-        n *= 2;
     }
-    *failed = !ok;
-    if (extra_steps) { const int ex = total - ((n_sub + WINR - 1) / WINR) * WINR; *extra_steps = ex > 0 ? ex : 0; }
-    return extra;
+    *failed = !L.ok;
+    if (extra_steps) *extra_steps = sc_ladder_extra_steps(L, n_sub, WINR);
+    return L.extra;
 }
 
 // The verified ladder with TWO rungs at a time (round 5; glgym_evalF at small batches, where lanes are free and the call is a latency

@@ -1625,6 +1625,18 @@ static int evalf_impl(glgym_handle h, const double* x, const double* u, const do
                 " rows (no two consecutive attempts of the n_sub, 2x, 4x, 8x ladder agreed); their rows of x_next are NaN";
         return GLGYM_EODE;
     }
+    // Every row of a call that reports no failure has been written by exactly one lane group; the buffer was NaN-filled before the
+    // launch, so a row that still reads NaN here was written by NO lane -- the signature of the lane-mask miscompile of round 5
+    // (tools/README.md "pair ladder"; designed around, not root-caused).  Never hand such a row back with GLGYM_OK.
+    if (!rhs_only) {
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < NX; ++i)
+                if (std::isnan(out[(size_t)b * NX + i])) {
+                    g_err = "glgym_evalF: row " + std::to_string(b) + " of " + std::to_string(B) + " came back unwritten (state " + std::to_string(i) +
+                            " is NaN although no integration was reported as failed): internal error of the kernel's row-writing lane selection";
+                    return GLGYM_EHIP;
+                }
+    }
     return GLGYM_OK;
 }
 
@@ -1707,7 +1719,8 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // Layout.  fp64 (the parity configuration): four lanes per environment, always -- coefficient blocks in LDS, no mailbox, no scratch
     // to speak of; it scales with the batch in rounds of 16 384 environments (2.86 ms per round at n_sub 240).  fp32: four lanes per
     // environment while the batch leaves SIMDs idle (B <= 16 384; shared crop parameters, default ODE), one lane per environment
-    // beyond.  GLGYM_LAYOUT = one | quad overrides for fp32 (read per launch: tests and tools switch it between steps).
+    // beyond.  glgym_set_layout(h, one | quad) overrides for fp32 -- handle state since round 5; the environment variable GLGYM_LAYOUT is
+    // only its INITIAL value, read once at glgym_create (changing os.environ afterwards has no effect on an existing handle).
     const bool def = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
     if constexpr (sizeof(T) == 8) {
         if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);

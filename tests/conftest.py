@@ -97,7 +97,7 @@ def hostmath():
     import ctypes
     d = ROOT / "tests" / "hostmath"
     so = d / "libhostmath.so"
-    srcs = [d / "hostmath.cpp", PKG / "csrc" / "gl_model.hpp"]
+    srcs = [d / "hostmath.cpp", PKG / "csrc" / "gl_model.hpp", PKG / "csrc" / "sc_policy.hpp"]
     if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                f"-I{PKG / 'csrc'}", "-o", str(so), str(d / "hostmath.cpp")])

@@ -30,7 +30,8 @@ def test_fixtures_are_what_they_say(golden):
     g = golden("holdout_season60")
     assert g["X"].shape == (8, 62, 28) and g["actions_q"].shape == (8, 5761, 6) and g["actions_q"].dtype == np.int8
     assert list(g["kept_steps"][:3]) == [0, 96, 192] and g["kept_steps"][-1] == 5761
-    assert np.all(np.diff(g["X"][:, :, 26], axis=1) > 0) and np.all(np.isfinite(g["X"]))     # the temperature sum only grows
+    assert np.all(np.isfinite(g["X"])) and np.all(g["X"][:, -1, 26] > g["X"][:, 0, 26] + 500)       # 60 days of canopy temperature summed
+    assert len({tuple(g["X"][b, -1, 22:26].round(0)) for b in range(8)}) == 8                       # eight DIFFERENT seasons
 
 
 @pytest.mark.parametrize("name,dt,verify,stride", [("holdout_gl2010_random", 900.0, False, 1), ("holdout_gl2010_rulebased", 900.0, True, 1),

@@ -218,3 +218,33 @@ def test_slowest_lanes_of_the_bench_workload_stay_cheap(hostmath, oracle, golden
     assert np.mean(steps64) < 150 and np.mean(steps32) < 150 and max(steps32) < 200
     assert 64 <= min(windows) and np.mean(windows) < 72 and max(windows) < 100       # windows shrink with the bound, by a few per cent; never 2x
     assert worst < 3e-5
+
+
+def test_every_tunable_is_in_one_place_and_its_sensitivity_is_on_record():
+    """sc_policy.hpp holds every tunable of the stability control once (macro + ScTunables member with provenance); the recorded
+    one-at-a-time study (tools/tunable_sensitivity.py -> profiles/r06_tunable_sensitivity.txt) covers each of them at the shipped value;
+    and neither kernel header defines a tunable of its own any more."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    csrc = root / "greenlight-gym2_amd" / "csrc"
+    pol = (csrc / "sc_policy.hpp").read_text()
+    defs = dict(re.findall(r"^#define (SC_[A-Z_]+) (\S+)$", pol, flags=re.M))
+    assert len(defs) == 22
+    for name in defs:
+        assert re.search(r"static constexpr \w+ \w+ = " + name + r";\s+// \S", pol), f"{name}: no ScTunables member with a provenance comment"
+    for hdr in ("gl_model.hpp", "gl_model_quad.hpp"):
+        assert not re.search(r"^\s*#\s*define\s+SC_", (csrc / hdr).read_text(), flags=re.M), hdr
+    rec = (root / "profiles" / "r06_tunable_sensitivity.txt").read_text()
+    import sys
+    sys.path.insert(0, str(root / "tools"))
+    import tunable_sensitivity as TS
+    for name, val in defs.items():
+        if name in TS.SKIP:
+            assert f"not perturbed: {name}" in rec
+        else:
+            assert re.search(rf"^{name}\s+{re.escape(val)} -> ", rec, flags=re.M), f"{name} = {val}: re-run tools/tunable_sensitivity.py"
+    # the study's own summary: apart from stepping BEYOND the stability interval (SC_SAFETY > 1) no single +-20 % change adds a failure
+    # or a tuple above the bar on any fixture, hold-outs included
+    last = rec.strip().split("\n")[-1]
+    assert "SC_SAFETY" in last and last.count("(") == 1, last

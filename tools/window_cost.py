@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU): what one tier-2b window costs next to one stage.  The fused step kernel on a UNIFORM batch (every lane nominal,
 B = 65 536, fp32) at fixed n_sub with 1, 2, 3, 4, 6 sub-steps per window (glgym_set_window): kernel ms = a x stages + b x windows.
-    python tools/window_cost.py [B]"""
+    python tools/window_cost.py [B] [float32|float64] [auto|one|quad]      (round 6: any dtype / layout, e.g. `8 float64` = the four-lanes-per-
+environment fp64 kernel at the reference's n_envs)"""
 import sys
 from pathlib import Path
 import numpy as np, torch
@@ -10,11 +11,17 @@ sys.path.insert(0, str(ROOT / "greenlight-gym2_amd"))
 from gl_gym_amd.tomato_env import TomatoVecEnv  # noqa: E402
 from gl_gym_amd.utils import synthetic_weather  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+DTYPE = sys.argv[2] if len(sys.argv) > 2 else "float32"
+LAYOUT = sys.argv[3] if len(sys.argv) > 3 else "auto"
+SCHEMES = (("ls5", 128, 5), ("rk4", 240, 4), ("rk3", 270, 3)) if DTYPE == "float32" else (("ls5", 128, 5),)
+print(f"# B = {B}, {DTYPE}, layout {LAYOUT}")
 w = synthetic_weather(n_rows=35040, dt=900.0, seed=2024)
-for scheme, n_sub, stages in (("ls5", 128, 5), ("rk4", 240, 4), ("rk3", 270, 3)):
+for scheme, n_sub, stages in SCHEMES:
     rows = []
     for window in (1, 2, 3, 4, 6):
-        env = TomatoVecEnv(B, weather=w, dtype="float32", scheme=scheme, n_sub=n_sub, window=window, season_length=60, pred_horizon=0.5, seed=666, start_rows=[960], auto_reset=True)
+        env = TomatoVecEnv(B, weather=w, dtype=DTYPE, scheme=scheme, n_sub=n_sub, window=window, season_length=60, pred_horizon=0.5, seed=666, start_rows=[960], auto_reset=True)
+        if DTYPE == "float32":
+            env.set_layout(LAYOUT)
         env.reset_tensor()
         g = torch.Generator(device=env.device).manual_seed(666)
         ms = []
