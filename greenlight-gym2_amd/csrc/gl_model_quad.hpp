@@ -263,7 +263,12 @@ __device__ __forceinline__ void gq_stage(int role, const QVec<T>& y, const LaneK
     const P2<T> nA = gq_mk<T>(negx ? K.nA2.x : K.nA.x, negy ? K.nA2.y : K.nA.y), cA = gq_mk<T>(negx ? K.cA2.x : K.cA.x, negy ? K.cA2.y : K.cA.y);
     const T sgx = role == 1 ? (negx ? -one : one) : K.sgA.x;
     // fp64 (a power is 57 instructions there, 3 in fp32): lane 0's x law is linear -- the canopy, exponent 0, its power slot would
-    // evaluate x^0 = 1 -- so that slot computes the air side's |tAir - tTop|^0.66 for the whole quad instead (one power per stage less)
+    // evaluate x^0 = 1 -- so that slot computes the air side's |tAir - tTop|^0.66 for the whole quad instead (one power per stage less).
+    // (Round 6 tried the rest of that idea and measured nothing: of the quad's 32 transcendental slots 15 are needed -- two y laws are linear,
+    // only the screen lane has a second exchange, four surfaces need a saturation pressure and three a gate -- so the two cube roots went to
+    // the spare y power slots of lanes 1 / 3 and the blackout screen's saturation pressure + gate to the dry floor lane, nine 64-bit DPP
+    // broadcasts in all.  Static vector instructions of the sub-step loop 4 436 -> 4 424, 2.024 -> 2.016 us per stage at B = 8: a 64-bit
+    // quad broadcast (two fenced 32-bit DPP moves + the selects around it) costs what a 20-instruction cube root does.  Reverted.)
     constexpr bool SHARE_POW = sizeof(T) == 8;
     const T powArgX = (SHARE_POW && lane0) ? M::abs(tAir - tTop + eps) : M::abs(sgx * dA.x + eps);
     const T powExpX = (SHARE_POW && lane0) ? T(0.66) : nA.x;
@@ -732,10 +737,14 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
 // attempt's instead of n + 2 n.  Verified mode only
 // (no attempt is accepted on its own; unverified integrations accept a clean first attempt and have nothing to run beside it).
 // *mine: this quad holds the accepted attempt in `del` (the quad that writes the row).
+// Round 6 (glgym_step(control = ...) at small batches runs it too): *extra / *extra_steps / *first_flags as rk4_delta_guarded_quad reports
+// them -- extra attempts, sub-steps beyond the nominal count over all attempts run, the GLGYM_SF_* word of the first attempt and of the
+// acceptance (sc_policy.hpp sc_ladder_judge in verified mode, replayed with integer selects).
 template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
 __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K,
                                                             const ModelConst<T>& m, const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del,
-                                                            int* failed, int* mine, int win_rt = 0)
+                                                            int* failed, int* mine, int win_rt = 0, int* extra = nullptr,
+                                                            int* extra_steps = nullptr, int* first_flags = nullptr)
 {
     static_assert(SC_ATTEMPTS == 4, "two rounds of two attempts");
     const int WINR = win_rt > 0 ? win_rt : WIN;
@@ -745,6 +754,7 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
     // a slot no path had written (hipcc 7.2, the fp32 RK4 / three-stage builds: the row-0 lane of the accepted quad sometimes did not
     // write, depending on what earlier kernels had left in that register -- tools/README.md "pair ladder").
     int done = 0, ok = 0, have_prev = 0, winner = 0;
+    int n_extra = 0, total = 0, fflags = 0;                // what the sequential ladder reports (step_flags): same selects, same barriers
     QVec<T> prev;
     prev.p = gq_sp<T>(T(0));
     for (int i = 0; i < 6; ++i) prev.sh[i] = T(0);
@@ -763,9 +773,9 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
         for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
         for (int j = 0; j < 4; ++j) chk += del.o[j] * T(0);
         const int nonfinite = gq_or((chk == T(0)) ? 0 : 1);
-        // bit 0: complete; bit 1: no flag; bit 2: not heavy
+        // bit 0: complete; bit 1: no flag; bit 2: not heavy; bits 3-6: the attempt's SC_FLAG_* word; bits 8...: its sub-steps
         int code = (((nonfinite == 0) && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE))) ? 1 : 0) | ((st.flags == 0) ? 2 : 0) |
-                   ((st.n_steps < SC_HEAVY * n_nom) ? 4 : 0);
+                   ((st.n_steps < SC_HEAVY * n_nom) ? 4 : 0) | ((st.flags & 15) << 3) | (st.n_steps << 8);
         asm volatile("" : "+v"(code));
         QVec<T> now, oth;
         gq_phys_pair<T>(role, del, now.p);
@@ -788,6 +798,11 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
             const int complete = c & 1, last = (att == SC_ATTEMPTS - 1) ? 1 : 0;
             const int agree = complete & have_prev & ((worst <= T(SC_AGREE)) ? 1 : 0);
             const int ok_n = agree | (last & complete & ((c >> 1) & 1));
+            // sc_ladder_judge's bookkeeping (verified mode: no attempt is accepted as merely clean)
+            total = act ? total + (c >> 8) : total;
+            fflags = (act && att == 0) ? (((c >> 3) & 15) | (((c >> 2) & 1) ? 0 : 16)) : fflags;
+            fflags = (act && ok_n) ? (fflags | (agree ? ((((c >> 1) & 1) == 0) ? 32 : 0) : 64)) : fflags;
+            n_extra = (act && !(ok_n | last)) ? n_extra + 1 : n_extra;
             ok = act ? ok_n : ok;
             winner = act ? holder : winner;
             have_prev = act ? complete : have_prev;
@@ -795,10 +810,14 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
             for (int i = 0; i < 6; ++i) prev.sh[i] = act ? cur.sh[i] : prev.sh[i];
             done = act ? (ok_n | last) : done;
             asm volatile("" : "+v"(done), "+v"(ok), "+v"(winner), "+v"(have_prev));
+            asm volatile("" : "+v"(n_extra), "+v"(total), "+v"(fflags));
         }
     }
     *failed = ok ^ 1;
     *mine = (half == winner) ? 1 : 0;
+    if (extra) *extra = n_extra;
+    if (extra_steps) { const int ex = total - ((n_sub + WINR - 1) / WINR) * WINR; *extra_steps = ex > 0 ? ex : 0; }
+    if (first_flags) *first_flags = fflags;
 }
 
 }  // namespace glm

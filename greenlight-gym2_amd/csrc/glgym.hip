@@ -326,9 +326,13 @@ __global__ __launch_bounds__(WAVE, OCC) void step_kernel(StepArgsT<T> a, ModelCo
 // SCH / CROP as in step_kernel: every scheme of the family, per-env crop blocks (config 5).  PIPE: ODE_pipe compiled in, selected at run
 // time by a.pipe (gq_stage) -- in fp64 this kernel is the only step kernel (round 4: the one-lane fp64 kernels with their LDS mailbox
 // and 2-3 KB of scratch are gone) and is always built with it.
-template <class T, bool DEFAULT_P, int SCH = 0, bool PIPE = false, bool CROP = false>
+// PAIR (round 6): TWO quads per environment run the verified ladder two rungs at a time (gl_model_quad.hpp rk4_delta_guarded_quad_pair, what
+// glgym_evalF has done since round 5): for glgym_step(control = ...) -- step_raw_control, the rule-based controller: config 1 -- on batches
+// that leave lanes free; the quad that holds the accepted attempt writes.  Bit-identical to the sequential ladder incl. step_flags.
+template <class T, bool DEFAULT_P, int SCH = 0, bool PIPE = false, bool CROP = false, bool PAIR = false>
 __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelConst<T> m_arg, RewardConst<T> rw)
 {
+    static_assert(!(PAIR && CROP), "the two-rungs ladder is instantiated for shared crop constants only");
     // fp64: the handle's parameter block is staged in LDS as well (one uniform record per wavefront, broadcast reads behind the stage
     // fence): as a kernel argument its ~180 doubles live in SGPRs, of which there are 100 -- the compiler parks the rest in VGPR
     // lanes and pays two v_readlane per use (2 000 of the kernel's 20 000 static instructions)
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     }
     const ModelConst<T>& m = LDSM ? sh_m[0] : DEFAULT_P ? device_default<T>() : m_arg;
     const int gl = blockIdx.x * WAVE + threadIdx.x, role = gl & 3;
-    const int b = gl >> 2;
+    const int b = PAIR ? gl >> 3 : gl >> 2, half = PAIR ? (gl >> 2) & 1 : 0;
     const bool live = b < a.B;
     const int bb = live ? b : a.B - 1;        // out-of-range quads shadow the last env, stores are masked
     T u[NU];
@@ -412,14 +416,22 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     z0 = x0;
     z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x,
                     role == 2 ? x0.sh[2] - x0.p.y : role == 3 ? x0.p.x - x0.p.y : x0.p.y);      // cover lane: w = tCovIn - tCovE
-    if (live && role == 0) {
+    if (live && role == 0 && half == 0) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) a.u[(size_t)j * a.ld + b] = u[j];
     }
     bool bad;
-    int extra_steps, first_flags = 0;
-    const int retries = rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad,
-                                                                                                      &extra_steps, a.verify != 0, &first_flags, a.window);
+    int extra_steps = 0, first_flags = 0, retries = 0, mine = 1;
+    if (PAIR) {
+        int bad_i;
+        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, false>(role, half, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad_i, &mine,
+                                                                                                   a.window, &retries, &extra_steps, &first_flags);
+        asm volatile("" : "+v"(bad_i), "+v"(mine));
+        bad = bad_i != 0;
+    } else {
+        retries = rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad,
+                                                                                                    &extra_steps, a.verify != 0, &first_flags, a.window);
+    }
     // ---- new state: physical increments of what the lane owns.  Nothing but the integrator's own state is kept live across the
     // integrator (the fp64 build is at its register limit there): the old state and the applied control are read again
     P2<T> dP;
@@ -429,9 +441,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     // 64-bit pointers -- across the integrator)
     int gl2 = blockIdx.x * WAVE + threadIdx.x;
     asm volatile("" : "+v"(gl2));
-    const int role2 = gl2 & 3, b2 = gl2 >> 2;
-    const bool live2 = b2 < a.B;
-    const int bb2 = live2 ? b2 : a.B - 1;
+    const int role2 = gl2 & 3, b2 = PAIR ? gl2 >> 3 : gl2 >> 2;
+    const bool live2 = b2 < a.B && mine != 0;             // (PAIR: the quad that holds the accepted attempt writes)
+    const int bb2 = (b2 < a.B) ? b2 : a.B - 1;
     const int ts2 = a.timestep[bb2];
     auto X2 = [&](int i) { return a.x[(size_t)i * a.ld + bb2]; };
 #pragma unroll
@@ -1679,15 +1691,20 @@ static void launch_step_sch(const glgym_step_args* a, const StepArgsT<float>& k,
 // batches): the shared-crop kernels of every scheme, with the default block compiled in where the handle holds it.
 // (No fp64 build with the default block compiled in: measured without the scheduler flag that used to break it -- csrc/Makefile --
 // it buys 0.7 % over the LDS-staged block, 1.379e6 against 1.369e6 env-steps/s at config 2, for six more 500-register kernels.)
+// pair: verified steps on batches that leave lanes free run the ladder two rungs at a time on two quads per environment (PAIR)
 template <class T, int SCH>
 static void launch_quad_sch(const glgym_step_args* a, const StepArgsT<T>& k, const ModelConst<T>& m, const RewardConst<T>& rw,
-                            dim3 qgrid, dim3 block, hipStream_t st, bool def)
+                            dim3 qgrid, dim3 block, hipStream_t st, bool def, bool pair)
 {
+    const dim3 pgrid((8 * (size_t)a->B + WAVE - 1) / WAVE);
     if constexpr (sizeof(T) == 8) {          // ODE_pipe compiled in, selected by k.pipe
-        if (a->crop_p) hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, true, true>), qgrid, block, 0, st, k, m, rw);
+        if (pair) hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, true, false, true>), pgrid, block, 0, st, k, m, rw);
+        else if (a->crop_p) hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, true, true>), qgrid, block, 0, st, k, m, rw);
         else hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, true, false>), qgrid, block, 0, st, k, m, rw);
     } else {
-        if (def) hipLaunchKernelGGL((step_kernel_quad<T, true, SCH, false, false>), qgrid, block, 0, st, k, m, rw);
+        if (pair && def) hipLaunchKernelGGL((step_kernel_quad<T, true, SCH, false, false, true>), pgrid, block, 0, st, k, m, rw);
+        else if (pair) hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, false, false, true>), pgrid, block, 0, st, k, m, rw);
+        else if (def) hipLaunchKernelGGL((step_kernel_quad<T, true, SCH, false, false>), qgrid, block, 0, st, k, m, rw);
         else hipLaunchKernelGGL((step_kernel_quad<T, false, SCH, false, false>), qgrid, block, 0, st, k, m, rw);
     }
 }
@@ -1722,11 +1739,14 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
     // beyond.  glgym_set_layout(h, one | quad) overrides for fp32 -- handle state since round 5; the environment variable GLGYM_LAYOUT is
     // only its INITIAL value, read once at glgym_create (changing os.environ afterwards has no effect on an existing handle).
     const bool def = h->use_specialised && std::memcmp(&m, &DefaultConst<T>::value, sizeof m) == 0;
+    // verified steps (raw controls) on batches of at most one wavefront per SIMD at EIGHT lanes per environment: the ladder two rungs at a
+    // time (glgym_set_ladder_parallel, as glgym_evalF since round 5): two thirds of the latency, identical results and step_flags
+    const bool pair = k.verify && h->ladder_parallel && !a->crop_p && (size_t)8 * a->B <= (size_t)WAVE * h->n_simd;
     if constexpr (sizeof(T) == 8) {
-        if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);
-        else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def);
-        else if (h->scheme == GLGYM_SCHEME_LS5) launch_quad_sch<T, GLGYM_SCHEME_LS5>(a, k, m, rw, qgrid, block, st, def);
-        else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def);
+        if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def, pair);
+        else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def, pair);
+        else if (h->scheme == GLGYM_SCHEME_LS5) launch_quad_sch<T, GLGYM_SCHEME_LS5>(a, k, m, rw, qgrid, block, st, def, pair);
+        else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def, pair);
         HIPCHK(hipGetLastError());
         return GLGYM_OK;
     } else {
@@ -1734,10 +1754,10 @@ static int launch_step(glgym_handle h, const glgym_step_args* a, const ModelCons
         const bool quad_ok = !pipe && !a->crop_p;
         const int b_small = 4 * h->n_simd * 4;                   // 16 384 on MI355X: one quad-kernel round
         if (quad_ok && (layout_env == 2 || (layout_env == 0 && a->B <= b_small))) {
-            if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def);
-            else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def);
-            else if (h->scheme == GLGYM_SCHEME_LS5) launch_quad_sch<T, GLGYM_SCHEME_LS5>(a, k, m, rw, qgrid, block, st, def);
-            else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def);
+            if (h->scheme == GLGYM_SCHEME_RK2) launch_quad_sch<T, GLGYM_SCHEME_RK2>(a, k, m, rw, qgrid, block, st, def, pair);
+            else if (h->scheme == GLGYM_SCHEME_RK3) launch_quad_sch<T, GLGYM_SCHEME_RK3>(a, k, m, rw, qgrid, block, st, def, pair);
+            else if (h->scheme == GLGYM_SCHEME_LS5) launch_quad_sch<T, GLGYM_SCHEME_LS5>(a, k, m, rw, qgrid, block, st, def, pair);
+            else launch_quad_sch<T, GLGYM_SCHEME_RK4>(a, k, m, rw, qgrid, block, st, def, pair);
             HIPCHK(hipGetLastError());
             return GLGYM_OK;
         }

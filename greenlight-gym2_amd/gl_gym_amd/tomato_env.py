@@ -615,6 +615,11 @@ class TomatoVecEnv:
         (include/glgym.h glgym_set_occupancy)."""
         L.check(self._lib.glgym_set_occupancy(self._h, int(waves_per_simd)), "glgym_set_occupancy")
 
+    def set_ladder_parallel(self, on: bool):
+        """Verified steps (raw controls) on up to 8 192 environments run the step-doubling ladder two rungs at a time (default; identical
+        results and step_flags, two thirds of the latency: include/glgym.h glgym_set_ladder_parallel).  False: always the sequential ladder."""
+        L.check(self._lib.glgym_set_ladder_parallel(self._h, int(bool(on))), "glgym_set_ladder_parallel")
+
     def set_n_sub(self, n_sub: int):
         self.n_sub = int(n_sub)
         L.check(self._lib.glgym_set_n_sub(self._h, self.n_sub), "glgym_set_n_sub")

@@ -248,8 +248,10 @@ int glgym_set_occupancy(glgym_handle h, int waves_per_simd);
 /* Verified glgym_evalF calls (GLGYM_VERIFY_AUTO / _ALWAYS) on batches that leave lanes free -- rows * 8 lanes <= one wavefront per SIMD of the
  * device: 8 192 rows on MI355X -- run the step-doubling ladder two rungs at a time on two lane groups per row (n_sub and 2 n_sub side by
  * side, then 4 n_sub and 8 n_sub if needed): the accepted attempt and the returned state are those of the sequential ladder bit for bit,
- * the elapsed time is the 2 n_sub attempt's instead of n_sub + 2 n_sub (profiles/r05_evalf_latency.txt).  1 (default) = where it applies,
- * 0 = always the sequential ladder (what per-row parameter blocks and larger batches run anyway). */
+ * the elapsed time is the 2 n_sub attempt's instead of n_sub + 2 n_sub (profiles/r05_evalf_latency.txt).  Round 6: verified glgym_step
+ * launches (control = ..., i.e. step_raw_control and the rule-based controller; four-lanes-per-environment kernels, shared crop block) on
+ * batches of up to 8 192 environments do the same on two lane groups per environment, step_flags included.  1 (default) = where it
+ * applies, 0 = always the sequential ladder (what per-row / per-env parameter blocks and larger batches run anyway). */
 int glgym_set_ladder_parallel(glgym_handle h, int on);
 int glgym_set_verify(glgym_handle h, int mode);              /* GLGYM_VERIFY_AUTO (default) | _ALWAYS | _NEVER */
 /* action_to_control (tomato_env.py:109-113): u = clip(u_prev + action * delta_u_max, u_min, u_max), held in float32 like

@@ -163,7 +163,8 @@ def test_quad_kernel_isa_keeps_its_spill_free_inner_loops(device_asm):
     # every scheme (SCH 0 / 1 / 2 / 3) of both kernels in fp64, with and without per-env crop blocks (ODE_pipe is a run-time selection
     # inside them); fp32: four schemes x default / handle parameters
     # (round 5: + the two-rungs-at-a-time evalF kernels, four fp64 and four fp32, and the sequential fp32 evalF quad kernels)
-    assert len([n for n in names if "quadId" in n]) == 20 and len([n for n in names if "quadIf" in n]) == 16, names
+    # (round 6: + the two-rungs-at-a-time STEP kernels for verified raw-control steps: four fp64, eight fp32 -- default / handle parameters)
+    assert len([n for n in names if "quadId" in n]) == 24 and len([n for n in names if "quadIf" in n]) == 24, names
     # round 4: the only fp64 integrator on the device is this layout (no one-lane fp64 kernels, hence no LDS mailbox); fp64 builds
     # with the default block compiled in are not instantiated (0.7 % for six more kernels), and the Makefile must not bring back the
     # scheduler flag under which they -- and a separate ODE_pipe build -- came out wrong

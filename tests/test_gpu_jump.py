@@ -97,6 +97,46 @@ def test_two_rungs_at_a_time_equals_the_sequential_ladder(golden, scheme, n_sub,
     m.close()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("scheme,n_sub", SCHEMES)
+def test_step_kernel_two_rungs_at_a_time_equals_the_sequential_ladder(golden, scheme, n_sub, dtype):
+    """Round 6: verified glgym_step launches (raw controls) on batches of up to 8 192 environments run the ladder two rungs at a time on
+    two lane groups per environment (`step_kernel_quad<..., PAIR>`, include/glgym.h glgym_set_ladder_parallel).  On the raw-jump fixture
+    -- every environment takes two attempts, some three or four -- state, reward, done, info, the per-env step_flags word (first-attempt
+    flags, extra attempts, sub-steps beyond nominal, how the result was accepted) and the metric accumulators must be the sequential
+    ladder's BIT FOR BIT; and a ragged batch (B = 5: one wavefront with 24 idle lanes) must not depend on the lanes around it."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    g = golden("step_tight_jump")
+    X, U, D = g["X"], g["U"], g["D"]
+    out = {}
+    for par in (True, False):
+        for B in (len(X), 5):
+            w = np.repeat(D[:B], 4, axis=0)
+            env = TomatoVecEnv(B, weather=w, dtype=dtype, scheme=scheme, n_sub=n_sub, season_length=0.02, pred_horizon=0, auto_reset=False)
+            env.set_ladder_parallel(par)
+            env.reset()
+            env.w_off_t.copy_(torch.arange(B, dtype=torch.int32, device=env.device) * 4)
+            env.x.copy_(torch.as_tensor(X[:B], dtype=env.tdtype, device=env.device))
+            env.metrics_t.zero_()
+            obs, r, done, info = env.step_raw_control(U[:B])
+            m = env.metrics()
+            out[(par, B)] = (env.x.cpu().numpy().copy(), r.copy(), done.copy(), info.copy(), env.step_flags_t.cpu().numpy().copy(), env.u.cpu().numpy().copy(),
+                             env.timestep_t.cpu().numpy().copy(), {k: m[k] for k in ("n_ode_fail", "n_guard_retries", "n_refined_substeps", "n_flag_err", "n_flag_branch",
+                                                                                    "n_flag_cap", "n_flag_heavy", "n_env_steps")})
+            env.close()
+    for B in (len(X), 5):
+        a, b = out[(True, B)], out[(False, B)]
+        for k in range(7):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (scheme, dtype, B, k, np.nonzero(a[k] != b[k]))
+        assert a[7] == b[7], (a[7], b[7])
+    assert np.array_equal(out[(True, 5)][0], out[(True, len(X))][0][:5])            # rows do not depend on the batch around them
+    flags = out[(True, len(X))][4]
+    assert np.all(((flags >> 8) & 0xff) >= 1) and out[(True, len(X))][7]["n_guard_retries"] >= len(X)       # verified: >= 1 extra attempt each
+    print(f"step kernel, two rungs at a time == sequential ladder ({scheme} {dtype}): {len(X)} + 5 envs bit-identical; envs with 3+ attempts "
+          f"{int((((flags >> 8) & 0xff) >= 2).sum())}, accepted by agreement although flagged {int(((flags & 32) != 0).sum())}, finest alone {int(((flags & 64) != 0).sum())}")
+
+
 def test_unverified_mode_flags_what_round_2_missed(golden):
     """GLGYM_VERIFY_NEVER = the action path's integration (guard only).  On the review's tuples A and B the branch invariant now
     sends the env-step up the ladder: right, or failed -- not silently wrong."""
