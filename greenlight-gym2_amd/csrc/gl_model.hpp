@@ -1426,34 +1426,45 @@ template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
     const T k = T(2.0 * 4.6052 / 1e4), one = T(1);
     const T z0 = k * (c - cMax);
     const T a = k * T(5e4) * t;
-    if (z0 < T(-40)) return T(0);
-    if (z0 - a > T(40)) return T(-5e4) * t;
+    // Round 6: the two regimes that are all a wavefront ever sees on nominal trajectories are taken WAVE-UNIFORMLY.  The compiler had
+    // if-converted the whole function (123 instructions with 11 transcendentals per call, two calls per window: a third of a window's
+    // instructions, 6 % of the fp32 kernel's) although (i) the fruit pool sits 2.4e5 mg below cFruitMax -- z0 = -225: every lane idle --
+    // and (ii) the leaf pool only ever takes the series branch.  Same values lane by lane: only work no lane selects is skipped.
+    if (!GL_WAVE_ANY(!(z0 < T(-40)))) return T(0);                    // the whole wavefront idle (host build: this lane)
     const T E0 = M::exp(-z0);
     const T inv = M::rcp(one + E0);
-    T dz = -a * inv;                                                  // first Newton step from dz = 0
-    if (dz > T(-4e-3)) {
-        // nominal trajectories (c a few thousand mg below cMax: E0 ~ 1e5, dz ~ -1e-3 per window): the series inversion of
-        //   x (1 + E0) + E0 (x^2 / 2 + x^3 / 6 + x^4 / 24 + ...) = a,  x = -dz,  x1 = a / (1 + E0),  r = E0 / (1 + E0):
-        //   x = x1 (1 + c2 x1 + c3 x1^2 + c4 x1^3),  c2 = -r/2,  c3 = r^2/2 - r/6,  c4 = -r (5 r^2/8 - 5 r/12 + 1/24);
-        // truncation x1^4 < 3e-10 relative.  (Round 4: two Newton steps with expm1 here were 7 % of a window.)
-        const T r = E0 * inv, x1 = -dz;
+    const T dz0 = -a * inv;                                           // first Newton step from dz = 0
+    const bool idle = z0 < T(-40), sat = !idle && (z0 - a > T(40)), nominal = dz0 > T(-4e-3);
+    // nominal trajectories (c a few thousand mg below cMax: E0 ~ 1e5, dz ~ -1e-3 per window): the series inversion of
+    //   x (1 + E0) + E0 (x^2 / 2 + x^3 / 6 + x^4 / 24 + ...) = a,  x = -dz,  x1 = a / (1 + E0),  r = E0 / (1 + E0):
+    //   x = x1 (1 + c2 x1 + c3 x1^2 + c4 x1^3),  c2 = -r/2,  c3 = r^2/2 - r/6,  c4 = -r (5 r^2/8 - 5 r/12 + 1/24);
+    // truncation x1^4 < 3e-10 relative.  (Round 4: two Newton steps with expm1 here were 7 % of a window.)
+    T dz;
+    {
+        const T r = E0 * inv, x1 = -dz0;
         const T c2 = T(-0.5) * r, c3 = r * (T(0.5) * r - T(1.0 / 6.0)), c4 = -r * (r * (T(0.625) * r - T(5.0 / 12.0)) + T(1.0 / 24.0));
         dz = -x1 * (one + x1 * (c2 + x1 * (c3 + x1 * c4)));
-    } else if (dz > T(-0.03)) {
-        // small change (always the case on nominal trajectories): two more Newton steps converge to < 1e-12 relative
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const T em = M::expm1(-dz);
-            dz -= (dz - E0 * em + a) * M::rcp(one + E0 * (em + one));
-        }
-    } else {
-        const T D = E0 - z0 + a;                                      // w + ln w = D,  w = exp(-z1)
-        T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
-#pragma unroll
-        for (int it = 0; it < 5; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
-        dz = -M::log(w) - z0;
     }
-    return dz * T(1e4 / (2.0 * 4.6052));
+    if (GL_WAVE_ANY(!nominal && !idle && !sat)) {                     // some lane of the wavefront is close to cMax (per-step parameter noise, config 5)
+        T dn = dz0;
+        if (dz0 > T(-0.03)) {
+            // small change: two more Newton steps converge to < 1e-12 relative
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const T em = M::expm1(-dn);
+                dn -= (dn - E0 * em + a) * M::rcp(one + E0 * (em + one));
+            }
+        } else {
+            const T D = E0 - z0 + a;                                  // w + ln w = D,  w = exp(-z1)
+            T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
+#pragma unroll
+            for (int it = 0; it < 5; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
+            dn = -M::log(w) - z0;
+        }
+        dz = nominal ? dz : dn;
+    }
+    const T out = dz * T(1e4 / (2.0 * 4.6052));
+    return idle ? T(0) : (sat ? T(-5e4) * t : out);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 // rk_delta (gl_model.hpp: one lane per environment) and rk_delta_quad (gl_model_quad.hpp: four lanes per environment) differ in how
 // they hold the state and gather a maximum over it; what they DECIDE -- how long the next window is, how many sub-steps it gets, when
 // the movement limiter or the refinement cap acts, when an attempt is flagged, when the guard's ladder accepts -- is scalar logic per
-// environment, and until round 5 it was written out twice (plus the CPU checker's independent restatement in oracle/gl_oracle.c, which
+// environment, and until round 5 it was written out twice (plus the CPU checker's independent restatement in C, which
 // stays independent: it is the thing these are tested against).  Everything here takes scalars and returns scalars; the operations and
 // their order are exactly those of the round-5 code, so both layouts produce the bits they produced before (tests/test_gpu_fuzz.py,
 // the step-by-step tests of tests/test_gpu_parity.py, quad-vs-one-lane guard words in tests/test_gpu_storm.py).
