@@ -57,7 +57,7 @@ CYC_PLAIN, CYC_TRANS = 2.3, 7.7
 # Recorded rocprofv3 PMC measurements of step_kernel per launch at B = 65 536, one entry per shipped variant (bench.py cannot
 # collect counters itself).  Written by tools/pmc_summary.py from the separate --pmc passes of tools/profile_round.sh /
 # tools/profile_variants.sh; the summaries they come from are committed next to it.
-PMC_FILES = [ROOT / "profiles" / "r05_pmc_constants.json", ROOT / "profiles" / "r04_pmc_constants.json", ROOT / "profiles" / "r03_pmc_constants.json"]
+PMC_FILES = [ROOT / "profiles" / "r06_pmc_constants.json", ROOT / "profiles" / "r05_pmc_constants.json", ROOT / "profiles" / "r04_pmc_constants.json", ROOT / "profiles" / "r03_pmc_constants.json"]
 
 
 def load_pmc(variant: str):

@@ -9,16 +9,16 @@ profiles/rNN_pmc_constants.json; tests/test_capi_surface.py recompiles the devic
 longer are the ones the counters were recorded on.
 
     make -C greenlight-gym2_amd/csrc asm            # writes /tmp/glgym.s with the Makefile's flags
-    python tools/pk_share.py [--update profiles/r05_pmc_constants.json] [ASM]"""
+    python tools/pk_share.py [--update profiles/r06_pmc_constants.json] [ASM]"""
 import json, re, sys
 
 # variant name (bench.py's) -> mangled-name fragment of the instantiation it runs
 KERNELS = {"f32_ls5": "11step_kernelIfLb0ELb1ELb0ELi3ELi1E", "f32_rk4": "11step_kernelIfLb0ELb1ELb0ELi0ELi1E",
            "f32_rk3": "11step_kernelIfLb0ELb1ELb0ELi2ELi1E", "f32_rk2": "11step_kernelIfLb0ELb1ELb0ELi1ELi1E",
            "f32_ls5_config5": "11step_kernelIfLb1ELb1ELb0ELi3ELi1E", "f32_rk4_config5": "11step_kernelIfLb1ELb1ELb0ELi0ELi1E",
-           "f32_ls5_quad": "16step_kernel_quadIfLb1ELi3ELb0ELb0E", "f32_rk4_quad": "16step_kernel_quadIfLb1ELi0ELb0ELb0E",
-           "f64_ls5_quad": "16step_kernel_quadIdLb0ELi3ELb1ELb0E", "f64_ls5_quad_b65536": "16step_kernel_quadIdLb0ELi3ELb1ELb0E",
-           "f64_rk4_quad": "16step_kernel_quadIdLb0ELi0ELb1ELb0E", "f64_rk4_quad_b65536": "16step_kernel_quadIdLb0ELi0ELb1ELb0E",
+           "f32_ls5_quad": "16step_kernel_quadIfLb1ELi3ELb0ELb0ELb0E", "f32_rk4_quad": "16step_kernel_quadIfLb1ELi0ELb0ELb0ELb0E",
+           "f64_ls5_quad": "16step_kernel_quadIdLb0ELi3ELb1ELb0ELb0E", "f64_ls5_quad_b65536": "16step_kernel_quadIdLb0ELi3ELb1ELb0ELb0E",
+           "f64_rk4_quad": "16step_kernel_quadIdLb0ELi0ELb1ELb0ELb0E", "f64_rk4_quad_b65536": "16step_kernel_quadIdLb0ELi0ELb1ELb0ELb0E",
            "f32_ls5_occ2": "11step_kernelIfLb0ELb1ELb0ELi3ELi2E"}
 
 

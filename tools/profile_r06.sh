@@ -54,12 +54,12 @@ variant f32_ls5_occ2 "step_kernel<float, false, true, false, 3, 2>" 128 F32 --ba
 PBATCH=65536
 # fp64 runs the four-lanes-per-environment kernel at every batch size and in every variant (glgym.hip launch_step)
 PBATCH=65536
-variant f64_ls5_quad_b65536 "step_kernel_quad<double, false, 3, true, false>" 128 F64 --dtype f64
+variant f64_ls5_quad_b65536 "step_kernel_quad<double, false, 3, true, false, false>" 128 F64 --dtype f64
 # the four-lanes-per-environment kernels (what batches up to 16 384 run), recorded at B = 4 096 (config 2 in fp64)
 PBATCH=4096
-variant f64_ls5_quad "step_kernel_quad<double, false, 3, true, false>" 128 F64 --dtype f64 --batch 4096
-variant f64_rk4_quad "step_kernel_quad<double, false, 0, true, false>" 240 F64 --dtype f64 --batch 4096 --scheme rk4
-variant f32_ls5_quad "step_kernel_quad<float, true, 3, false, false>" 128 F32 --batch 4096
+variant f64_ls5_quad "step_kernel_quad<double, false, 3, true, false, false>" 128 F64 --dtype f64 --batch 4096
+variant f64_rk4_quad "step_kernel_quad<double, false, 0, true, false, false>" 240 F64 --dtype f64 --batch 4096 --scheme rk4
+variant f32_ls5_quad "step_kernel_quad<float, true, 3, false, false, false>" 128 F32 --batch 4096
 PBATCH=65536
 python - <<PY
 import json
