@@ -430,7 +430,7 @@ def main():
                         "the reference's tolerances (greenlight_model.cpp:51-52) keeps from the tight solution on the one-step tuples "
                         "(ls5 192 / window 1: 1.0e-5; rk4 640: 8.7e-6; tests/test_gpu_parity.py) -- the iso-accuracy throughput "
                         "beside the headline's, whose one-step error is 6.1e-5 (bar 1e-4)"}
-    # final metric gather: the only collective on this path (RCCL all_gather of 16 doubles per rank)
+    # final metric gather: the only collective on this path (RCCL all_gather of 19 doubles per rank: 16 + the `sustained` block's three)
     from gl_gym_amd.dist import gather_metrics, aggregate
     rows = gather_metrics([elapsed, float(B * K), m.get("sum_reward", 0.0), m.get("n_ode_fail", 0.0),
                            m.get("n_done", 0.0), kern_ms, m.get("n_guard_retries", 0.0), m.get("n_refined_substeps", 0.0),
@@ -549,7 +549,7 @@ def main():
                     "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "obs_bytes_per_env_step": obs_bytes}})
         out = {
             "collective": None if not use_dist else {"backend": dist.get_backend(), "world": world,
-                                                     "ranks_gathered": len(rows), "note": "one all_gather of 16 doubles per rank at the end of the run"},
+                                                     "ranks_gathered": len(rows), "note": "one all_gather of 19 doubles per rank at the end of the run"},
             "metric": "TomatoEnv env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

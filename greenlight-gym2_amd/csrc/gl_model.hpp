@@ -1420,12 +1420,42 @@ GL_HD void rhs_stage(const T* x, const SlowCoef<T>& q, const StepCoef<T>& s, con
 //     form (Newton on dz with expm1), so that the tiny change is not lost in fp32;
 //   * else: Newton on w + ln w = D from the asymptotic initial guess (monotone, no overflow).
 // ---------------------------------------------------------------------------------------------------
-template <class T> GL_HD T harvest_flow(T c, T cMax, T t)
+// UNIFORM = false: the function as it stood until round 5, statement for statement (the compiler if-converts its first two regimes).  The
+// fp32 four-lanes-per-environment kernels that hold the handle's parameters in SGPRs (glgym_evalF rows, non-default parameter blocks) take
+// it: their register allocation is brittle -- ~200 parameter scalars for 100 SGPRs, the rest parked in VGPR lanes -- and with the
+// restructured body below their SUB-STEP loop came out 4-19 % longer in v_readlane (2 076 -> 2 167 ... 2 472 vector instructions)
+// although the loop itself is untouched.  Same values either way.
+template <class T, bool UNIFORM = true> GL_HD T harvest_flow(T c, T cMax, T t)
 {
     using M = Math<T>;
     const T k = T(2.0 * 4.6052 / 1e4), one = T(1);
     const T z0 = k * (c - cMax);
     const T a = k * T(5e4) * t;
+    if constexpr (!UNIFORM) {
+        if (z0 < T(-40)) return T(0);
+        if (z0 - a > T(40)) return T(-5e4) * t;
+        const T E0 = M::exp(-z0);
+        const T inv = M::rcp(one + E0);
+        T dz = -a * inv;                                              // first Newton step from dz = 0
+        if (dz > T(-4e-3)) {
+            const T r = E0 * inv, x1 = -dz;
+            const T c2 = T(-0.5) * r, c3 = r * (T(0.5) * r - T(1.0 / 6.0)), c4 = -r * (r * (T(0.625) * r - T(5.0 / 12.0)) + T(1.0 / 24.0));
+            dz = -x1 * (one + x1 * (c2 + x1 * (c3 + x1 * c4)));
+        } else if (dz > T(-0.03)) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const T em = M::expm1(-dz);
+                dz -= (dz - E0 * em + a) * M::rcp(one + E0 * (em + one));
+            }
+        } else {
+            const T D = E0 - z0 + a;
+            T w = (D > one) ? D - M::log(D) : M::exp(D - M::exp(D));
+#pragma unroll
+            for (int it = 0; it < 5; ++it) w -= (w + M::log(w) - D) * w * M::rcp(w + one);
+            dz = -M::log(w) - z0;
+        }
+        return dz * T(1e4 / (2.0 * 4.6052));
+    }
     // Round 6: the two regimes that are all a wavefront ever sees on nominal trajectories are taken WAVE-UNIFORMLY.  The compiler had
     // if-converted the whole function (123 instructions with 11 transcendentals per call, two calls per window: a third of a window's
     // instructions, 6 % of the fp32 kernel's) although (i) the fruit pool sits 2.4e5 mg below cFruitMax -- z0 = -225: every lane idle --

@@ -422,7 +422,8 @@ template <class T> __device__ __forceinline__ T gq_fast_max(const QVec<T>& a, P2
 // (LDSQ builds hold the parameter block `m` in LDS too: its address joins the fence)
 #define GQ_FENCE() do { if (LDSQ && LDSC) asm volatile("" : : "v"(&s), "v"(&K), "v"(&m), "v"(&cr) : "memory"); \
                         else if (LDSQ) asm volatile("" : : "v"(&s), "v"(&K), "v"(&m) : "memory"); } while (0)
-template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
+// HVU: harvest_flow's wave-uniform early exits (gl_model.hpp; false for the fp32 kernels that hold the handle's parameters in SGPRs)
+template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false, bool HVU = true>
 __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
                                               const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, ScStat<T>& st, int win_rt = 0)
 {
@@ -458,7 +459,7 @@ __device__ __forceinline__ void rk_delta_quad(int role, const QVec<T>& z0, const
     // coefficients are those of classical RK4 -- one instruction stream for the four lanes
     // harvest: cLeaf = x23, cFruit = x25 live on lane 2 (o[1], o[3])
     auto harvest = [&](T hh) {
-        const T a = harvest_flow(z0.o[1] + del.o[1], cr.cLeafMax, hh), b = harvest_flow(z0.o[3] + del.o[3], cr.cFruitMax, hh);
+        const T a = harvest_flow<T, HVU>(z0.o[1] + del.o[1], cr.cLeafMax, hh), b = harvest_flow<T, HVU>(z0.o[3] + del.o[3], cr.cFruitMax, hh);
         del.o[1] += crop ? a : T(0); del.o[3] += crop ? b : T(0);
     };
     QVec<T> winc;                 // ORDER 5: the window's increments (see the sub-step loop)
@@ -695,7 +696,7 @@ template <class T> __device__ __forceinline__ void gq_phys_pair(int role, const 
 }
 
 // ---- the guard: rk4_delta_guarded of gl_model.hpp over the quad (same ladder, same acceptance rules) ---------------------------------
-template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
+template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false, bool HVU = true>
 __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K, const ModelConst<T>& m,
                                                       const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del, bool* failed, int* extra_steps,
                                                       bool verify, int* first_flags, int win_rt = 0)
@@ -709,7 +710,7 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
     for (int attempt = 0; attempt < SC_ATTEMPTS; ++attempt) {
         if (L.done) break;                                 // uniform inside the quad: every decision below is
         ScStat<T> st;
-        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, L.n, del, st, win_rt);
+        rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC, HVU>(role, z0, s, K, m, cr, dt, L.n, del, st, win_rt);
         T chk = (del.p.x + del.p.y) * T(0);
         for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
         for (int j = 0; j < 4; ++j) chk += del.o[j] * T(0);
@@ -740,7 +741,9 @@ __device__ __forceinline__ int rk4_delta_guarded_quad(int role, const QVec<T>& z
 // Round 6 (glgym_step(control = ...) at small batches runs it too): *extra / *extra_steps / *first_flags as rk4_delta_guarded_quad reports
 // them -- extra attempts, sub-steps beyond the nominal count over all attempts run, the GLGYM_SF_* word of the first attempt and of the
 // acceptance (sc_policy.hpp sc_ladder_judge in verified mode, replayed with integer selects).
-template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false>
+// BOOK = false (glgym_evalF, which reports none of it): the bookkeeping is compiled out -- three more values live across the integrator
+// cost the fp32 evalF kernel (380 registers, the hot loop's operands partly in AGPRs) 6 % of its sub-step loop.
+template <class T, int ORDER, int WIN, bool LDSQ, bool PIPE, bool LDSC = false, bool BOOK = false, bool HVU = true>
 __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, const QVec<T>& z0, const StepCoef<T>& s, LaneK<T>& K,
                                                             const ModelConst<T>& m, const CropConst<T>& cr, T dt, int n_sub, QVec<T>& del,
                                                             int* failed, int* mine, int win_rt = 0, int* extra = nullptr,
@@ -767,7 +770,7 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
         const int n = n_sub << att_mine;
         ScStat<T> st;
         st.flags = 0; st.n_steps = 0;
-        if (round == 0 || half == 0) rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
+        if (round == 0 || half == 0) rk_delta_quad<T, ORDER, WIN, LDSQ, PIPE, LDSC, HVU>(role, z0, s, K, m, cr, dt, n, del, st, win_rt);
         const int n_nom = ((n + WINR - 1) / WINR) * WINR;
         T chk = (del.p.x + del.p.y) * T(0);
         for (int i = 0; i < 6; ++i) chk += del.sh[i] * T(0);
@@ -775,7 +778,7 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
         const int nonfinite = gq_or((chk == T(0)) ? 0 : 1);
         // bit 0: complete; bit 1: no flag; bit 2: not heavy; bits 3-6: the attempt's SC_FLAG_* word; bits 8...: its sub-steps
         int code = (((nonfinite == 0) && !(st.flags & (SC_FLAG_CAP | SC_FLAG_NONFINITE))) ? 1 : 0) | ((st.flags == 0) ? 2 : 0) |
-                   ((st.n_steps < SC_HEAVY * n_nom) ? 4 : 0) | ((st.flags & 15) << 3) | (st.n_steps << 8);
+                   ((st.n_steps < SC_HEAVY * n_nom) ? 4 : 0) | (BOOK ? (((st.flags & 15) << 3) | (st.n_steps << 8)) : 0);
         asm volatile("" : "+v"(code));
         QVec<T> now, oth;
         gq_phys_pair<T>(role, del, now.p);
@@ -798,11 +801,12 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
             const int complete = c & 1, last = (att == SC_ATTEMPTS - 1) ? 1 : 0;
             const int agree = complete & have_prev & ((worst <= T(SC_AGREE)) ? 1 : 0);
             const int ok_n = agree | (last & complete & ((c >> 1) & 1));
-            // sc_ladder_judge's bookkeeping (verified mode: no attempt is accepted as merely clean)
-            total = act ? total + (c >> 8) : total;
-            fflags = (act && att == 0) ? (((c >> 3) & 15) | (((c >> 2) & 1) ? 0 : 16)) : fflags;
-            fflags = (act && ok_n) ? (fflags | (agree ? ((((c >> 1) & 1) == 0) ? 32 : 0) : 64)) : fflags;
-            n_extra = (act && !(ok_n | last)) ? n_extra + 1 : n_extra;
+            if constexpr (BOOK) {      // sc_ladder_judge's bookkeeping (verified mode: no attempt is accepted as merely clean)
+                total = act ? total + (c >> 8) : total;
+                fflags = (act && att == 0) ? (((c >> 3) & 15) | (((c >> 2) & 1) ? 0 : 16)) : fflags;
+                fflags = (act && ok_n) ? (fflags | (agree ? ((((c >> 1) & 1) == 0) ? 32 : 0) : 64)) : fflags;
+                n_extra = (act && !(ok_n | last)) ? n_extra + 1 : n_extra;
+            }
             ok = act ? ok_n : ok;
             winner = act ? holder : winner;
             have_prev = act ? complete : have_prev;
@@ -810,7 +814,7 @@ __device__ __forceinline__ void rk4_delta_guarded_quad_pair(int role, int half, 
             for (int i = 0; i < 6; ++i) prev.sh[i] = act ? cur.sh[i] : prev.sh[i];
             done = act ? (ok_n | last) : done;
             asm volatile("" : "+v"(done), "+v"(ok), "+v"(winner), "+v"(have_prev));
-            asm volatile("" : "+v"(n_extra), "+v"(total), "+v"(fflags));
+            if constexpr (BOOK) asm volatile("" : "+v"(n_extra), "+v"(total), "+v"(fflags));
         }
     }
     *failed = ok ^ 1;

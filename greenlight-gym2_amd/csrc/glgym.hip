@@ -422,14 +422,15 @@ __global__ __launch_bounds__(WAVE) void step_kernel_quad(StepArgsT<T> a, ModelCo
     }
     bool bad;
     int extra_steps = 0, first_flags = 0, retries = 0, mine = 1;
+    constexpr bool HVU = sizeof(T) == 8 || DEFAULT_P;         // harvest_flow's wave-uniform exits: not where the parameters live in SGPRs (fp32, handle parameters)
     if (PAIR) {
         int bad_i;
-        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, false>(role, half, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad_i, &mine,
-                                                                                                   a.window, &retries, &extra_steps, &first_flags);
+        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, false, true, HVU>(role, half, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad_i, &mine,
+                                                                                                         a.window, &retries, &extra_steps, &first_flags);
         asm volatile("" : "+v"(bad_i), "+v"(mine));
         bad = bad_i != 0;
     } else {
-        retries = rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad,
+        retries = rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP, HVU>(role, z0, s, K, m, cr, a.dt, a.n_sub, del, &bad,
                                                                                                     &extra_steps, a.verify != 0, &first_flags, a.window);
     }
     // ---- new state: physical increments of what the lane owns.  Nothing but the integrator's own state is kept live across the
@@ -595,15 +596,16 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const
     z0.p = gq_mk<T>(role == 2 ? x0.sh[2] - x0.p.x : role == 3 ? x0.sh[3] - x0.p.x : x0.p.x,
                     role == 2 ? x0.sh[2] - x0.p.y : role == 3 ? x0.p.x - x0.p.y : x0.p.y);
     bool bad;
+    constexpr bool HVU = sizeof(T) == 8;       // fp32 rows carry their parameters in SGPRs: harvest_flow per lane (gl_model.hpp)
     int mine = 1;                        // (an integer on purpose: rk4_delta_guarded_quad_pair)
     if (PAIR) {
         int bad_i;
-        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, half, z0, s, K, m, cr, dt, n_sub, del, &bad_i, &mine, window);
+        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP, false, HVU>(role, half, z0, s, K, m, cr, dt, n_sub, del, &bad_i, &mine, window);
         asm volatile("" : "+v"(bad_i), "+v"(mine));
         bad = bad_i != 0;
     } else {
         int extra_steps, first_flags = 0;
-        rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP>(role, z0, s, K, m, cr, dt, n_sub, del, &bad, &extra_steps, verify != 0,
+        rk4_delta_guarded_quad<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP, HVU>(role, z0, s, K, m, cr, dt, n_sub, del, &bad, &extra_steps, verify != 0,
                                                                                       &first_flags, window);
     }
     // a failed integration (the reference's evalF raises): the row is NaN and the call returns GLGYM_EODE

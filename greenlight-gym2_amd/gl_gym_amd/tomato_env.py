@@ -24,6 +24,7 @@ PyTorch is used for device memory, streams and RNG plumbing only; all arithmetic
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -224,6 +225,9 @@ class TomatoVecEnv:
         L.check(self._lib.glgym_create(L.NX, L.NU, self.nd, L.NP, self.dt, p64.ctypes.data_as(L._DP),
                                        L.F64 if self.f64 else L.F32, self.n_sub, self.device.index or 0,
                                        C.byref(self._h)), "glgym_create")
+        # GLGYM_LAYOUT / GLGYM_OCC / GLGYM_VERIFY are read ONCE, here in glgym_create (handle state since round 5): changing os.environ
+        # afterwards has no effect on this handle -- _launch_step warns once if that is attempted (use set_layout / set_occupancy / set_verify)
+        self._env_at_create = tuple(os.environ.get(k) for k in ("GLGYM_LAYOUT", "GLGYM_OCC", "GLGYM_VERIFY"))
         if model_variant == "ode_pipe":
             L.check(self._lib.glgym_set_model_variant(self._h, L.ODE_PIPE), "glgym_set_model_variant")
         L.check(self._lib.glgym_set_scheme(self._h, L.SCHEMES[scheme]), "glgym_set_scheme")
@@ -338,6 +342,11 @@ class TomatoVecEnv:
         L.check(self._lib.glgym_obs(self._h, C.byref(a), self._stream()), "glgym_obs")
 
     def _launch_step(self, raw_control: bool):
+        if self._env_at_create is not None and tuple(os.environ.get(k) for k in ("GLGYM_LAYOUT", "GLGYM_OCC", "GLGYM_VERIFY")) != self._env_at_create:
+            import warnings
+            warnings.warn("GLGYM_LAYOUT / GLGYM_OCC / GLGYM_VERIFY changed after this TomatoVecEnv was created: they are read once, at glgym_create, "
+                          "and have no effect on an existing handle -- use set_layout() / set_occupancy() / set_verify()", RuntimeWarning, stacklevel=3)
+            self._env_at_create = None                     # once
         if self.crop_T is not None and not getattr(self, "freeze_crop_noise", False):       # noise.py: a fresh draw every step
             L.check(self._lib.glgym_crop_noise(self._h, self.crop_T.data_ptr(), self.B, self.ld,
                                                self.uncertainty_scale, self.seed_value, self._draw, self._stream()),

@@ -67,10 +67,12 @@ def _worker_config4(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(524288, rank, world)
     n_steps = 961
-    # bench.py's 16-entry vector: elapsed, env-steps, sum reward, failed, episodes, kernel ms, retries, refined, rank, seed, four
-    # first-attempt flag counts, max scaled error of the rank's parity leg, failed integrations in it
+    # bench.py's 19-entry vector: elapsed, env-steps, sum reward, failed, episodes, kernel ms, retries, refined, rank, seed, four
+    # first-attempt flag counts, max scaled error of the rank's parity leg, failed integrations in it, and (round 6) the `sustained`
+    # continuation: its elapsed time, env-steps and kernel time
     mine = [10.0 + 0.25 * rank, float((hi - lo) * n_steps), 1.5 * rank, float(rank == 3), float(hi - lo), 0.9 + 0.01 * rank,
-            2.0, 100.0 * rank, float(rank), float(666 + rank), 1.0, 0.0, 0.0, float(rank == 5), 2.0e-5 + 1.0e-6 * rank, 0.0]
+            2.0, 100.0 * rank, float(rank), float(666 + rank), 1.0, 0.0, 0.0, float(rank == 5), 2.0e-5 + 1.0e-6 * rank, 0.0,
+            1.0 + 0.01 * rank, float((hi - lo) * (1500 + rank)), 0.91 + 0.01 * rank]
     rows = gather_metrics(mine)
     dist.barrier()
     dist.destroy_process_group()
@@ -78,7 +80,7 @@ def _worker_config4(rank, world, port, q):
 
 
 def test_config4_bookkeeping_eight_ranks():
-    """BASELINE configs[3] as the driver would launch it (8 ranks, one all_gather of 16 doubles at the end): contiguous 65 536-env
+    """BASELINE configs[3] as the driver would launch it (8 ranks, one all_gather of 19 doubles at the end): contiguous 65 536-env
     shards, whole-job env-steps / slowest rank, the worst rank's max scaled error, per-rank kernel times -- on gloo, no GPU."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -102,3 +104,10 @@ def test_config4_bookkeeping_eight_ranks():
     assert len(a["ranks"]) == 8 and [r["rank"] for r in a["ranks"]] == list(range(8))
     assert [round(r["kernel_ms"], 2) for r in a["ranks"]] == [round(0.9 + 0.01 * r, 2) for r in range(8)] and a["kernel_ms_max"] == 0.97
     assert a["ranks"][7]["seed"] == 673 and abs(a["ranks"][7]["max_scaled_err"] - 2.7e-5) < 1e-12
+    # the `sustained` block: every rank's continuation env-steps / the slowest rank's continuation time
+    su = a["sustained"]
+    assert su["t_max"] == 1.07 and su["env_steps"] == 65536 * sum(1500 + r for r in range(8)) and abs(su["kernel_ms_max"] - 0.98) < 1e-12
+    assert su["value"] == su["env_steps"] / 1.07
+    # a rank that ran no continuation (an older 16-entry vector): the job reports none
+    from gl_gym_amd.dist import aggregate
+    assert aggregate([[1.0, 10.0, 0.0, 0.0, 0.0, 0.5] + [0.0] * 10, [1.0, 10.0, 0.0, 0.0, 0.0, 0.5] + [0.0] * 13])["sustained"] is None

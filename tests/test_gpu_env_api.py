@@ -431,3 +431,34 @@ def test_host_infos_never_report_an_earlier_steps_controls_and_weather_may_be_a_
     np.testing.assert_allclose(got, u_now, rtol=0, atol=1e-7)
     assert np.abs(got - u_first).max() > 1e-3
     env.close()
+
+
+def test_environment_variables_are_handle_state_read_once():
+    """GLGYM_LAYOUT / GLGYM_OCC / GLGYM_VERIFY are initial values read at glgym_create; toggling os.environ afterwards has no
+    effect on an existing handle -- the Python layer says so (once) instead of silently ignoring it."""
+    import os
+    import warnings
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.utils import synthetic_weather
+    env = TomatoVecEnv(64, weather=synthetic_weather(n_rows=400), season_length=1, auto_reset=False)
+    env.reset()
+    a = np.zeros((64, 6), np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        env.step(a)                                         # nothing changed: no warning
+    old = os.environ.get("GLGYM_LAYOUT")
+    os.environ["GLGYM_LAYOUT"] = "one"
+    try:
+        x_before = env.x.clone()
+        with pytest.warns(RuntimeWarning, match="read once"):
+            env.step(a)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            env.step(a)                                     # said once
+        assert not bool((env.x == x_before).all())          # ... and the step ran (on the layout the handle was created with)
+    finally:
+        if old is None:
+            os.environ.pop("GLGYM_LAYOUT", None)
+        else:
+            os.environ["GLGYM_LAYOUT"] = old
+    env.close()
