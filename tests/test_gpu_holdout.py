@@ -210,3 +210,37 @@ def test_holdout_60_day_season_eight_distinct_environments(golden, dtype, layout
     assert m["n_ode_fail"] == 0 and real == 0
     assert worst[0] < PLAIN_BOUND["holdout_season60"][preset][0 if dtype == "float64" else 1]
     env.close()
+
+
+# Classical RK4 -- the scheme BASELINE's configs name, `bench.py`'s `other_scheme` -- on the same hold-outs at its throughput preset
+# (n_sub 240 / window 4, scaled with dt), one-lane fp32 and fp64: measured in profiles/r06_holdout.txt next to the default scheme's rows.
+RK4_BOUND = {"holdout_gl2010_random": (6e-5, 1e-4), "holdout_gl2010_rulebased": (3e-5, 1e-4), "holdout_runtime_dt300": (1.5e-4, 2.3e-4),
+             "holdout_season60": (6e-5, 1e-4)}          # (float64, float32).  run_time: the same step near 0 C as ls5 (tTop = -0.005 C, kept step 665)
+#   reads 1.31e-4 in fp64 and 2.01e-4 in fp32 (3 and 5 micro-kelvin) -- ABOVE the 1e-4 bar on the plain metric, inside the reference solver's own
+#   band there (BDF rtol = atol = 1e-6: 2.6e-4); what is asserted is that nothing away from the freezing point is above the bar.
+
+
+@pytest.mark.parametrize("dtype,layout,occ", [BUILDS[0], BUILDS[3]], ids=[BUILD_IDS[0], BUILD_IDS[3]])
+@pytest.mark.parametrize("name", ["holdout_gl2010_random", "holdout_gl2010_rulebased", "holdout_runtime_dt300"])
+def test_holdouts_with_classical_rk4(golden, name, dtype, layout, occ):
+    g = golden(name)
+    dt = 300.0 if name == "holdout_runtime_dt300" else 900.0
+    params = g["p"] if "p" in g.files else None
+    env = make_env(g, dtype, layout, occ, "throughput", dt, 10, params=params, pred_horizon=0.5 if name == "holdout_gl2010_random" else 0, scheme="rk4")
+    assert env.scheme == "rk4" and env.n_sub == (240 if dt == 900.0 else 80)
+    if name == "holdout_gl2010_random":
+        X, XR = rollout(env, len(g["actions"]), actions=g["actions"]), g["X"]
+    elif name == "holdout_gl2010_rulebased":
+        X, XR = rollout(env, len(g["U"]), controls=g["U"]), g["X"]
+    else:
+        U = g["U"].astype(np.float64)
+        X = rollout(env, len(U), controls=U, x0=g["x0"], keep_every=3)
+        X = np.vstack([X, env.x[0].double().cpu().numpy()[None]])
+        XR = np.vstack([g["X"], g["X_last"][None]])
+    m = env.metrics()
+    plain, who, step, real, floor = judge(X, XR, abs_floor=1e-4 if dtype == "float64" else 2e-4)
+    report(f"{name:26s} {BUILD_IDS[BUILDS.index((dtype, layout, occ))]:14s} rk4-thr    plain metric {plain:.2e} ({who} at kept step {step}); states above 1e-4 away from 0 C: {real} steps, "
+           f"at the 0 C floor: {floor} steps; failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}")
+    assert m["n_ode_fail"] == 0 and real == 0
+    assert plain < RK4_BOUND[name][0 if dtype == "float64" else 1], (name, dtype, plain)
+    env.close()
