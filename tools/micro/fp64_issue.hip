@@ -26,6 +26,17 @@ template <> struct Op_dpp<float> {
     static __device__ float f(float a, float, float) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true)); }
 };
 
+// inline-asm forms: the compiler cannot pair these into packed instructions
+template <typename T> struct Op_fma_asm {};
+template <> struct Op_fma_asm<float> { static __device__ float f(float a, float b, float c) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c)); return a; } };
+template <> struct Op_fma_asm<double> { static __device__ double f(double a, double b, double c) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c)); return a; } };
+template <typename T> struct Op_mul_asm {};
+template <> struct Op_mul_asm<float> { static __device__ float f(float a, float b, float) { asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b)); return a; } };
+template <typename T> struct Op_exp_asm {};
+template <> struct Op_exp_asm<float> { static __device__ float f(float a, float, float) { asm volatile("v_exp_f32 %0, %0" : "+v"(a)); return a; } };
+template <typename T> struct Op_cnd_asm {};
+template <> struct Op_cnd_asm<float> { static __device__ float f(float a, float b, float) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b)); return a; } };
+
 template <typename T, template <typename> class OP, int K>
 __global__ void __launch_bounds__(64) chain(T* out, long long* cyc, T b, T c, int n) {
     T a[K];
@@ -68,12 +79,18 @@ template <typename T, template <typename> class OP, int K> void run(const char* 
 
 int main(int argc, char** argv) {
     int blocks = argc > 1 ? atoi(argv[1]) : 256;
+    printf("== %d workgroups of one wavefront ==\n", blocks);
     ALLK(double, Op_fma, "fma", 0.999999, 1e-7)
     ALLK(double, Op_mul, "mul", 0.999999, 0.0)
     ALLK(double, Op_add, "add", 0.0, 1e-7)
     ALLK(double, Op_max, "max", 0.5, 0.0)
     ALLK(double, Op_rcp, "rcp", 0.0, 0.0)
     ALLK(double, Op_dpp, "dpp-mov", 0.0, 0.0)
+    ALLK(double, Op_fma_asm, "fma-asm", 0.999999, 1e-7)
+    ALLK(float, Op_fma_asm, "fma-asm", 0.999999f, 1e-7f)
+    ALLK(float, Op_mul_asm, "mul-asm", 0.999999f, 0.0f)
+    ALLK(float, Op_exp_asm, "exp-asm", 0.0f, 0.0f)
+    ALLK(float, Op_cnd_asm, "cndmask", 0.5f, 0.0f)
     ALLK(float, Op_fma, "fma", 0.999999f, 1e-7f)
     ALLK(float, Op_mul, "mul", 0.999999f, 0.0f)
     ALLK(float, Op_rcp, "rcp", 0.0f, 0.0f)
