@@ -800,7 +800,50 @@ def g_holdout_season():
                         actions_q=q, X=X, kept_steps=days)
 
 
-ALL = dict(holdout_random=g_holdout_random, holdout_rulebased=g_holdout_rulebased, holdout_runtime=g_holdout_runtime,
+def _noisy_one(args):
+    b, w, p0 = args
+    rng_p = np.random.default_rng(20261008 + b)                     # the parameter draws (reference noise.py through its own function)
+    acts = np.random.default_rng(20261108 + b).uniform(-1, 1, (961, 6)).astype(np.float32)
+    scale = None
+    x = init_state(w[0]); u = np.zeros(6)
+    Xs, Us, Ps = [x.copy()], [], []
+    for k in range(961):
+        u = np.clip(u + acts[k] * np.float32(0.1), np.float32(0), np.float32(1))        # tomato_env.py:113
+        pk = np.asarray(parametric_crop_uncertainty(p0, 0.2, rng_p))                     # tomato_env.py:118: a NEW block at every step
+        x, _ = tight_step(x, u, w[k], pk.astype(np.float64))
+        Xs.append(x.copy()); Us.append(np.array(u, dtype=np.float64)); Ps.append(pk[128:162].copy())
+    X, U, P = np.array(Xs), np.array(Us), np.array(Ps)
+    scale = 1e-3 * np.abs(X).max(axis=0)
+    one = np.zeros(961); free = np.zeros(961); xb = X[0].copy()
+    for k in range(961):                                             # BDF rtol = atol = 1e-6 (the reference's CVODES settings) from the same truth
+        pk = np.array(p0, dtype=np.float64); pk[128:162] = P[k]
+        y, _ = tight_step(X[k], U[k], w[k], pk, tol=1e-6, method="BDF")
+        one[k] = _sc_rows(y[None], X[k + 1][None], scale)[0]
+        xb, _ = tight_step(xb, U[k], w[k], pk, tol=1e-6, method="BDF")
+        free[k] = _sc_rows(xb[None], X[k + 1][None], scale)[0]
+    return acts, X, U, P, one, free
+
+
+def g_holdout_noisy():
+    """(e) BASELINE config 5's regime on held-out weather: 4 environments x 961 steps of GL2010 from day 40, each env-step with a NEW
+    crop-parameter block from the reference's parametric_crop_uncertainty (noise.py:3-23; uncertainty_scale 0.2 as tomato_env.py:118
+    calls it) -- the kernels' PER-ENVIRONMENT crop-parameter path, which none of the other hold-outs takes -- and Delta-u-bounded random
+    actions, new seeds.  Stored per step: the 34 crop entries the step was solved with (float32 as the reference hands them to evalF)."""
+    from concurrent.futures import ProcessPoolExecutor
+    p0 = init_default_params(208)
+    assert p0.dtype == np.float32
+    w = load_weather_data(WEATHER_DIR, "Bleiswijk", "GL", 2010, 40, 10, 1, 900, 10)
+    with ProcessPoolExecutor(4) as ex:
+        out = list(ex.map(_noisy_one, [(b, w, p0) for b in range(4)]))
+    acts, X, U, P, one, free = (np.array([o[i] for o in out]) for i in range(6))
+    assert P.dtype == np.float32 and P.shape == (4, 961, 34)
+    rel = np.abs(P / p0[128:162] - 1)
+    print("holdout_gl2010_noisy: tOut %.1f..%.1f, iGlob max %.0f; crop entries off their defaults by up to %.3f; BDF-1e-6 band: one-step %.2e, "
+          "free-running %.2e" % (w[:961, 1].min(), w[:961, 1].max(), w[:961, 0].max(), np.nanmax(rel), one.max(), free.max()))
+    np.savez_compressed(HERE / "holdout_gl2010_noisy.npz", actions=acts, weather=w[:1012], X=X, U=U, P_crop=P, p=p0, bdf_one_step=one, bdf_free=free)
+
+
+ALL = dict(holdout_noisy=g_holdout_noisy, holdout_random=g_holdout_random, holdout_rulebased=g_holdout_rulebased, holdout_runtime=g_holdout_runtime,
            holdout_season=g_holdout_season, jump=g_jump, refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 
