@@ -5,7 +5,7 @@ out = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in ([] if (len(sys.argv) > 1 and sys.argv[1] == "--constants") else sys.argv[1:]):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
-        m = re.search(r"(step_kernel(?:_quad)?<[^>]*>|obs_kernel<[^>]*>|reset_kernel<[^>]*>)", n)
+        m = re.search(r"(step_kernel(?:_quad)?<[^>]*>|evalf_kernel(?:_quad)?<[^>]*>|obs_kernel<[^>]*>|reset_kernel<[^>]*>)", n)
         if not m: continue
         out[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if not (len(sys.argv) > 1 and sys.argv[1] == "--constants"):
