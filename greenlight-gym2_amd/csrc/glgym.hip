@@ -597,14 +597,10 @@ __global__ __launch_bounds__(WAVE) void evalf_kernel_quad(const double* x, const
                     role == 2 ? x0.sh[2] - x0.p.y : role == 3 ? x0.p.x - x0.p.y : x0.p.y);
     bool bad;
     constexpr bool HVU = sizeof(T) == 8;       // fp32 rows carry their parameters in SGPRs: harvest_flow per lane (gl_model.hpp)
-#ifndef GL_EVALF_PAIR_HVU
-#define GL_EVALF_PAIR_HVU 1
-#endif
-    constexpr bool HVU_PAIR = HVU && (GL_EVALF_PAIR_HVU != 0);
     int mine = 1;                        // (an integer on purpose: rk4_delta_guarded_quad_pair)
     if (PAIR) {
         int bad_i;
-        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP, false, HVU_PAIR>(role, half, z0, s, K, m, cr, dt, n_sub, del, &bad_i, &mine, window);
+        rk4_delta_guarded_quad_pair<T, gl_order(SCH), SchemeWin<T, SCH>::value, LDSQ, PIPE, LDSQ && CROP, false, HVU>(role, half, z0, s, K, m, cr, dt, n_sub, del, &bad_i, &mine, window);
         asm volatile("" : "+v"(bad_i), "+v"(mine));
         bad = bad_i != 0;
     } else {
