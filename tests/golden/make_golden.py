@@ -843,7 +843,37 @@ def g_holdout_noisy():
     np.savez_compressed(HERE / "holdout_gl2010_noisy.npz", actions=acts, weather=w[:1012], X=X, U=U, P_crop=P, p=p0, bdf_one_step=one, bdf_free=free)
 
 
-ALL = dict(holdout_noisy=g_holdout_noisy, holdout_random=g_holdout_random, holdout_rulebased=g_holdout_rulebased, holdout_runtime=g_holdout_runtime,
+def g_refenv_day60():
+    """Hold-out for the env layer (round 6): the reference's own TomatoEnv (shims of _reference_env) with start_train_day = 60 on Bleiswijk
+    GL2009 (the file holds 19 October - 31 December; `start_day` counts rows from ITS start: 18 December) -- a start day other than 0, which
+    none of the earlier env fixtures has: day-of-year clocks, the forecast window, reward and info on frost weather.  The env asks its loader
+    for Np + 1 = 49 DAYS of horizon (tomato_env.py:250-260), which runs past the end of the file: the reference's expandWeatherData appends
+    GL2010 (utils.py:126-150), so the year wrap is in the fixture too.  2 days, step() with random actions from a new seed, the yml's
+    pred_horizon.  Same record as refenv_1day's "ra" leg."""
+    INFO = ["EPI", "revenue", "variable_costs", "fixed_costs", "co2_cost", "heat_cost", "elec_cost", "temp_violation",
+            "co2_violation", "rh_violation", "lamp_violation"]
+    env, base, spec = _reference_env(season_length=2, year=2009, start_day=60)
+    obs0, _ = env.reset(seed=20261009)
+    acts = np.random.default_rng(20261009).uniform(-1, 1, (400, 6)).astype(np.float32)
+    rec = dict(u=[], x=[np.array(env.x, dtype=np.float64)], obs=[np.asarray(obs0, dtype=np.float64)], reward=[], info=[], done=[],
+               doy=[env.day_of_year], hod=[env.hour_of_day])
+    done, k = False, 0
+    while not done and k < 400:
+        obs, r, done, trunc, info = env.step(acts[k])
+        rec["u"].append(np.array(info["controls"], dtype=np.float64)); rec["x"].append(np.array(env.x, dtype=np.float64))
+        rec["obs"].append(np.asarray(obs, dtype=np.float64)); rec["reward"].append(float(r))
+        rec["info"].append([float(info[q]) for q in INFO]); rec["done"].append(bool(done))
+        rec["doy"].append(env.day_of_year); rec["hod"].append(env.hour_of_day)
+        k += 1
+    assert k == env.N + 1 == 193
+    out = {f"ra_{q}": np.array(v) for q, v in rec.items()}
+    print("refenv_day60: %d steps from day %g of 2009, N = %d, Np = %d, day-of-year %.3f -> %.3f, sum reward %.5f" %
+          (k, base["start_train_day"], env.N, env.Np, rec["doy"][0], rec["doy"][-1], out["ra_reward"].sum()))
+    np.savez_compressed(HERE / "refenv_day60.npz", info_keys=np.array(INFO), weather=np.array(env.weather_data), p=np.array(env.p),
+                        ra_actions=acts[:k], N=env.N, Np=env.Np, start_day=float(base["start_train_day"]), **out)
+
+
+ALL = dict(refenv_day60=g_refenv_day60, holdout_noisy=g_holdout_noisy, holdout_random=g_holdout_random, holdout_rulebased=g_holdout_rulebased, holdout_runtime=g_holdout_runtime,
            holdout_season=g_holdout_season, jump=g_jump, refobs=g_refobs, refenv=g_refenv, storm=g_storm, helpers2=g_helpers2, pipe=g_pipe, rollout_summer=g_rollout_summer, params=g_params, weather=g_weather, rhs=g_rhs, step=g_step, reward=g_reward, noise=g_noise,
            controller=g_controller, env=g_env, rollout=g_rollout)
 

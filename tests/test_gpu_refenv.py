@@ -187,3 +187,46 @@ def test_control_limits_against_reference_env(golden, dtype, atol):
     assert lib.glgym_set_control_limits(h, P(lo), P(hi), -0.1) == L.EINVAL
     assert lib.glgym_set_control_limits(h, None, P(hi), 0.1) == L.EINVAL
     env.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_env_layer_holdout_start_day_60_with_year_wrap(golden, dtype):
+    """Hold-out for the env layer (round 6): the reference's TomatoEnv with start_train_day = 60 on GL2009 (18 December; its loader runs past
+    the end of the file and appends GL2010), 2 days of step() with random actions from a new seed -- the first reference-env fixture whose
+    start day is not 0: day-of-year clocks (observations.py TimeObservations through tomato_env.py:126-128), the forecast window, reward and
+    info on frost weather.  Teacher-forced like the one-day fixture: env b replays step b."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd._lib import INFO_KEYS
+    g = golden("refenv_day60")
+    U, X, OBS, R, INFO, DONE = (g[f"ra_{k}"] for k in ("u", "x", "obs", "reward", "info", "done"))
+    B = len(U)
+    assert B == 193 and float(g["start_day"]) == 60.0 and list(g["info_keys"]) == list(INFO_KEYS)
+    env = TomatoVecEnv(B, weather=g["weather"], params=g["p"], dtype=dtype, season_length=2, pred_horizon=0.5,
+                       start_rows=[0], start_days=[60.0], auto_reset=False)
+    obs0 = env.reset()
+    np.testing.assert_allclose(obs0[0], OBS[0], rtol=2e-6, atol=2e-6)
+    assert env.N == int(g["N"]) == 192 and env.Np == int(g["Np"]) == 48
+    dev, T = env.device, env.tdtype
+    env.x.copy_(torch.as_tensor(X[:B], dtype=T, device=dev))
+    env.u.copy_(torch.as_tensor(np.vstack([np.zeros((1, 6)), U[:-1]]), dtype=T, device=dev))
+    env.timestep_t.copy_(torch.arange(B, dtype=torch.int32, device=dev))
+    obs, r, done, infos = env.step(g["ra_actions"][:B])
+    np.testing.assert_allclose(env.u.double().cpu().numpy(), U, rtol=0, atol=1e-7 if dtype == "float32" else 1e-15)
+    e_x = scaled_err(env.x.double().cpu().numpy(), X[1:B + 1])
+    assert e_x < 1e-4, e_x
+    ref = OBS[1:B + 1]
+    np.testing.assert_allclose(obs[:, 7:], ref[:, 7:], rtol=3e-6, atol=3e-6)          # controls, weather, CLOCKS, the 240-entry forecast block
+    assert np.abs(ref[:, 19:23]).max() > 0.5 and np.ptp(ref[:, 19]) > 0.01            # the day-of-year clock really is away from day 0 and moving
+    sc = np.maximum(np.abs(ref[:, :7]), 1e-3 * np.abs(ref[:, :7]).max(axis=0))
+    assert np.max(np.abs(obs[:, :7] - ref[:, :7]) / sc) < 2e-4
+    np.testing.assert_array_equal(done, DONE)
+    assert done[-1] and not done[:-1].any()
+    assert np.max(np.abs(r - R)) < 2e-4
+    info_gpu = np.array([[infos[b][q] for q in INFO_KEYS] for b in range(B)])
+    np.testing.assert_allclose(info_gpu[:, 2:7], INFO[:, 2:7], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(info_gpu[:, 0:2], INFO[:, 0:2], rtol=0, atol=3e-6)
+    viol_sc = np.array([15.0, 2500.0, 15.0, 1.0])
+    assert np.max(np.abs(info_gpu[:, 7:11] - INFO[:, 7:11]) / viol_sc) < 2e-4
+    print(f"refenv day 60 {dtype}: state {e_x:.2e}, reward {np.max(np.abs(r - R)):.2e}, clocks {np.abs(obs[:, 18:23] - ref[:, 18:23]).max():.1e}")
+    env.close()

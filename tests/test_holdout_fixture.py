@@ -90,3 +90,18 @@ def test_product_arithmetic_on_the_noisy_parameter_holdout(golden, hostmath):
         assert plain < (3e-5 if preset == "parity" else 2e-4)       # throughput: 1.6e-4 on THREE steps (grow-pipe temperature -0.05 C, off by 8e-6 K; BDF-1e-6: 1.4e-4); parity 2.1e-5
         if preset == "parity":
             assert plain < band
+
+
+REF_WEATHER = "/root/reference/gl_gym/environments/weather"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_WEATHER), reason="the reference's weather files are only in the build container")
+def test_host_weather_loader_follows_the_reference_past_the_end_of_a_file(golden):
+    """refenv_day60.npz holds the table the REFERENCE's loader produced for start day 60 of GL2009 with the 49 days of horizon its env asks
+    for (tomato_env.py:250-260): it runs past the end of the file and appends GL2010 (utils.py expandWeatherData).  The package's host
+    loader reads the same two files (data, not code) and must reproduce the table bit for bit."""
+    from gl_gym_amd.utils import load_weather_data
+    g = golden("refenv_day60")
+    w = load_weather_data(REF_WEATHER, "Bleiswijk", "GL", 2009, 60, 2, int(g["Np"]) + 1, 900, 10)
+    assert w.shape == g["weather"].shape == (4896, 10)
+    np.testing.assert_array_equal(w, g["weather"])
