@@ -373,6 +373,8 @@ class TomatoVecEnv:
     def _launch_rule_based(self, controller, hour_t=None, doy_t=None):
         """glgym_rule_based: controller.predict for every env, written to the SoA control buffer of step_raw_control."""
         cfg = L.RuleCfg(*[float(getattr(controller, n)) for n in L.RULE_FIELDS])
+        if hour_t is None and (self.dt / 3600) * 8 != round((self.dt / 3600) * 8):    # increments other than multiples of 1/8 h do not sum exactly
+            hour_t = self.hour_of_day()
         a = L.RuleArgs(self.B, self.ld, self.x_T.data_ptr(), self.weather_t.data_ptr(), self.weather_rows,
                        self.w_off_t.data_ptr(), self.timestep_t.data_ptr(), self.start_day_t.data_ptr(),
                        hour_t.data_ptr() if hour_t is not None else None,
@@ -525,8 +527,23 @@ class TomatoVecEnv:
         idx = (self.w_off_t + self.timestep_t).long().clamp_(0, self.weather_rows - 1)
         return self.weather_t[idx]
 
+    def _hod_table(self):
+        """The reference ACCUMULATES its clock, hour_of_day = (hour_of_day + dt / 3600) % 24 once per step (tomato_env.py:127-128).  With
+        dt = 900 s the increment 0.25 is exact and the sum equals timestep * dt / 3600; with dt = 300 s (experiments/run_time.py) the sum
+        drifts by ulps and reads 17.999999999999996 where the product reads 18.0 -- and the rule-based controller compares the clock with
+        whole hours (baseline.py:76-77, 107, 113): 13 of 960 steps of the dt = 300 hold-out switch the lamps one step apart.  The table
+        holds the reference's sum for every timestep of an episode; timestep indexes it."""
+        if getattr(self, "_hod_table_t", None) is None:
+            t = np.empty(self.N + 4, dtype=np.float64)
+            h = 0.0
+            for k in range(len(t)):
+                t[k] = h
+                h = (h + self.dt / 3600) % 24
+            self._hod_table_t = self.torch.as_tensor(t, device=self.device)
+        return self._hod_table_t
+
     def hour_of_day(self):
-        return (self.timestep_t.double() * (self.dt / 3600.0)) % 24.0            # tomato_env.py:127-128
+        return self._hod_table()[self.timestep_t.long().clamp_(0, self.N + 3)]      # tomato_env.py:127-128, accumulated like the reference's
 
     def day_of_year(self):
         return self.start_day_t.double() + self.timestep_t.double() * ((self.dt / self.c) % 365)   # :126
@@ -685,7 +702,7 @@ class TomatoEnv:
     u = property(lambda self: self.vec.u[0].double().cpu().numpy())
     timestep = property(lambda self: int(self.vec.timestep_t[0]))
     day_of_year = property(lambda self: self.start_day + self.timestep * ((self.dt / self.c) % 365))
-    hour_of_day = property(lambda self: (self.timestep * self.dt / 3600) % 24)
+    hour_of_day = property(lambda self: float(self.vec.hour_of_day()[0]))
 
     def reset(self, seed: Optional[int] = None):
         obs = self.vec.reset_tensor(seed)

@@ -316,7 +316,11 @@ typedef struct {
     const int32_t* timestep;   /* [B] */
     const float* start_day;    /* [B] day of year at reset: day_of_year = start_day + timestep*((dt/86400) mod 365),
                                   hour_of_day = (timestep*dt/3600) mod 24   (tomato_env.py:126-128) */
-    const double* hour;        /* optional [B] explicit clocks (known-answer tests); NULL = derive as above */
+    const double* hour;        /* optional [B] explicit clocks; NULL = derive as above.  The reference keeps hour_of_day as a RUNNING SUM
+                                  (hour += dt/3600; hour %= 24 per step): exact for dt = 900 s, but for increments that are not multiples of
+                                  1/8 h (dt = 300 s, experiments/run_time.py) the sum reads 17.999999999999996 where the product reads 18 and
+                                  the rules compare the clock with whole hours -- pass the running sum here to switch the lamps on the
+                                  reference's step (gl_gym_amd.TomatoVecEnv does; tests/test_gpu_holdout.py rule_based_controller_kernel) */
     const double* doy;
     void* control;             /* SoA [6][ld] T out */
 } glgym_rule_args;

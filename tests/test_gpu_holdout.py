@@ -288,3 +288,37 @@ def test_holdout_noisy_crop_parameters_every_step(golden, dtype, layout, occ, pr
     for b in range(B):
         assert judge(X[b], XR[b], abs_floor=1e-4 if dtype == "float64" else 2e-4)[3] == 0
     env.close()
+
+
+@pytest.mark.parametrize("name,dt,start_day", [("holdout_gl2010_rulebased", 900.0, 20.0), ("holdout_runtime_dt300", 300.0, 35.0)])
+def test_holdout_rule_based_controller_kernel_reproduces_the_references_controls(golden, name, dt, start_day):
+    """The rule_based_kernel (baseline.py:68-227 on the device) on the two closed-loop hold-outs: the controls the REFERENCE's
+    RuleBasedController chose at every recorded (state, weather row, time of day) -- 961 steps of GL2010 from day 20, and the first 961 of the
+    run_time fixture (dt = 300 s, MATLAB parameters, from day 35: its states are kept every third step, so is the comparison) --
+    teacher-forced: environment b sits at step b of the recording.  Until round 6 the kernel had seen 128 reference vectors and one autumn day."""
+    import torch
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from gl_gym_amd.baseline import RuleBasedController
+    g = golden(name)
+    stride = 3 if name == "holdout_runtime_dt300" else 1
+    XR, U = g["X"], g["U"]
+    steps = np.arange(0, (len(XR) - 1) * stride, stride)[:961]
+    B = len(steps)
+    env = TomatoVecEnv(B, weather=g["weather"], params=g["p"], dtype="float64", dt=dt, season_length=10, pred_horizon=0, start_rows=[0],
+                       start_days=[start_day], auto_reset=False)
+    env.reset_tensor()
+    x = XR[steps // stride].copy()
+    if "x0" in g.files:
+        x[0] = g["x0"]
+    env.x.copy_(torch.as_tensor(x, dtype=env.tdtype, device=env.device))
+    env.u.copy_(torch.as_tensor(np.vstack([np.zeros((1, 6)), U[steps[1:] - 1]]), dtype=env.tdtype, device=env.device))
+    env.timestep_t.copy_(torch.as_tensor(steps, dtype=torch.int32, device=env.device))
+    u = env.rule_based_controls(RuleBasedController()).double().cpu().numpy()
+    tol = 1e-9 if U.dtype == np.float64 else 1e-7                  # the run_time fixture stores its controls as float32
+    err = np.abs(u - U[steps])
+    report(f"{name:26s} rule_based_kernel vs the reference controller's recorded controls: {B} steps, max |du| {err.max():.1e}, "
+           f"controls that differ by more than {tol:g}: {int((err > tol).sum())} of {err.size}; lamps on in {int((U[steps][:, 4] > 0.5).sum())} steps")
+    # dt = 300 s: the reference's clock is a running sum (tomato_env.py:127-128) that reads 17.999999999999996 at 18:00 -- TomatoVecEnv hands the
+    # kernel that sum (tomato_env.py _hod_table); with the exact product 13 of these 960 steps switch the lamps one step apart
+    assert err.max() < tol
+    env.close()
