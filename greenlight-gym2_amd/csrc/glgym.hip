@@ -1401,6 +1401,19 @@ int glgym_set_params(glgym_handle h, const double* p)
     return refresh(h);
 }
 
+int glgym_set_params_keep_reward_scale(glgym_handle h, const double* p)
+{
+    if (!h || !p) return GLGYM_EINVAL;
+    const float minf = h->rf.minProfit, invf = h->rf.invRange;
+    const double mind = h->rd.minProfit, invd = h->rd.invRange, maxp = h->max_profit, minp = h->min_profit;
+    std::memcpy(h->p, p, sizeof h->p);
+    const int rc = refresh(h);
+    h->rf.minProfit = minf; h->rf.invRange = invf;
+    h->rd.minProfit = mind; h->rd.invRange = invd;
+    h->max_profit = maxp; h->min_profit = minp;
+    return rc;
+}
+
 int glgym_set_model_variant(glgym_handle h, int variant)
 {
     if (!h || (variant != GLGYM_ODE && variant != GLGYM_ODE_PIPE) || (variant == GLGYM_ODE_PIPE && h->nd < 14)) {

@@ -17,7 +17,7 @@ SCHEME_RK4, SCHEME_RK2 = 0, 1
 SCHEME_RK3 = 2
 SCHEME_LS5 = 3
 SCHEMES = {"rk4": SCHEME_RK4, "rk2": SCHEME_RK2, "rk3": SCHEME_RK3, "ls5": SCHEME_LS5}
-ABI_VERSION = 5                                           # include/glgym.h GLGYM_ABI_VERSION
+ABI_VERSION = 6                                           # include/glgym.h GLGYM_ABI_VERSION
 LAYOUTS = {"auto": 0, "one": 1, "quad": 2}                # glgym_layout
 # NOMINAL sub-steps per 900 s env-step.  RK4 (round 4): the conduction between the two faces of the cover glass -- the 0.65 1/s
 # mode that kept every explicit scheme at >= 224 sub-steps -- is integrated exactly (gl_model.hpp rk_delta, COVEXP), so the nominal
@@ -170,6 +170,7 @@ PROTOTYPES = {
                                C.POINTER(C.c_void_p)]),
     "glgym_destroy": (C.c_int, [C.c_void_p]),
     "glgym_set_params": (C.c_int, [C.c_void_p, _DP]),
+    "glgym_set_params_keep_reward_scale": (C.c_int, [C.c_void_p, _DP]),
     "glgym_set_n_sub": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_model_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "glgym_set_scheme": (C.c_int, [C.c_void_p, C.c_int]),

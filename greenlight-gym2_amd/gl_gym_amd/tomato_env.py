@@ -219,7 +219,7 @@ class TomatoVecEnv:
         self.integration_info = bool(integration_info)
         self.seed_value = int(seed)
 
-        self.p = np.asarray(init_default_params(L.NP) if params is None else params, dtype=np.float32)
+        self._p = np.asarray(init_default_params(L.NP) if params is None else params, dtype=np.float32)
         self._h = C.c_void_p()
         p64 = np.ascontiguousarray(self.p, dtype=np.float64)
         L.check(self._lib.glgym_create(L.NX, L.NU, self.nd, L.NP, self.dt, p64.ctypes.data_as(L._DP),
@@ -527,6 +527,23 @@ class TomatoVecEnv:
         idx = (self.w_off_t + self.timestep_t).long().clamp_(0, self.weather_rows - 1)
         return self.weather_t[idx]
 
+    @property
+    def p(self):
+        """The shared parameter block (float32, tomato_env.py:62).  ASSIGNING to it is the reference's `env.p = new_p` on a constructed env
+        (experiments/run_time.py:40-41: `env.p = set_matlab_params(env.p)`): the device model, the crop block and the reward's per-step cost
+        coefficients follow the new block; the reward's scale max_profit / min_profit stays what it was at construction, as in the reference
+        (rewards.py:82-83 computes it once in __init__) -- glgym_set_params_keep_reward_scale.  Construct with `params=` to have both from one block."""
+        return self._p
+
+    @p.setter
+    def p(self, value):
+        value = np.asarray(value, dtype=np.float32)
+        if value.shape != (L.NP,):
+            raise ValueError(f"p: expected {L.NP} parameters, got an array of shape {value.shape}")
+        p64 = np.ascontiguousarray(value, dtype=np.float64)
+        L.check(self._lib.glgym_set_params_keep_reward_scale(self._h, p64.ctypes.data_as(L._DP)), "glgym_set_params_keep_reward_scale")
+        self._p = value
+
     def _hod_table(self):
         """The reference ACCUMULATES its clock, hour_of_day = (hour_of_day + dt / 3600) % 24 once per step (tomato_env.py:127-128).  With
         dt = 900 s the increment 0.25 is exact and the sum equals timestep * dt / 3600; with dt = 300 s (experiments/run_time.py) the sum
@@ -691,7 +708,7 @@ class TomatoEnv:
                                 reward_params=reward_params, constraints=constraints, auto_reset=False)
         v = self.vec
         self.nx, self.nu, self.nd, self.num_params, self.dt, self.c = v.nx, v.nu, v.nd, v.num_params, v.dt, v.c
-        self.N, self.Np, self.p = v.N, v.Np, v.p
+        self.N, self.Np = v.N, v.Np
         self.weather_data = v.weather_data
         self.observation_space, self.action_space = v.observation_space, v.action_space
         self.start_day, self.growth_year, self.location, self.training = start_day, growth_year, location, training
@@ -700,6 +717,7 @@ class TomatoEnv:
 
     x = property(lambda self: self.vec.x[0].double().cpu().numpy())
     u = property(lambda self: self.vec.u[0].double().cpu().numpy())
+    p = property(lambda self: self.vec.p, lambda self, value: setattr(self.vec, "p", value))     # `env.p = set_matlab_params(env.p)` (run_time.py:40)
     timestep = property(lambda self: int(self.vec.timestep_t[0]))
     day_of_year = property(lambda self: self.start_day + self.timestep * ((self.dt / self.c) % 365))
     hour_of_day = property(lambda self: float(self.vec.hour_of_day()[0]))

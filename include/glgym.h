@@ -146,7 +146,7 @@ typedef struct {
 } glgym_reward_cfg;
 
 /* ABI version of this header; glgym_abi_version() returns the library's.  5: glgym_step_args starts with struct_size (round 5) */
-#define GLGYM_ABI_VERSION 5
+#define GLGYM_ABI_VERSION 6
 
 /* Device-pointer arguments of one batched env-step.  Exactly one of `action` / `control` is non-null. */
 typedef struct {
@@ -231,6 +231,11 @@ int glgym_create(int nx, int nu, int nd, int np, double dt, const double* p, int
                  glgym_handle* out);
 int glgym_destroy(glgym_handle h);
 int glgym_set_params(glgym_handle h, const double* p);
+/* The reference's `env.p = new_p` on an env that already exists (experiments/run_time.py:40-41, gl_predefined_controls.py:70-77): the model, the
+ * crop block and the per-step cost coefficients of the reward follow new_p (rewards.py:164-166 read env.p at every step), but the reward's SCALE
+ * -- max_profit / min_profit -- stays what it was at construction (rewards.py:82-83 computes them once, in __init__).  glgym_set_params
+ * recomputes the scale too, i.e. it is "construct the env with new_p".  (ABI 6) */
+int glgym_set_params_keep_reward_scale(glgym_handle h, const double* p);
 int glgym_set_n_sub(glgym_handle h, int n_sub);
 int glgym_set_scheme(glgym_handle h, int scheme);            /* GLGYM_SCHEME_RK4 (default) | GLGYM_SCHEME_RK2 | GLGYM_SCHEME_RK3 | GLGYM_SCHEME_LS5 */
 /* Nominal sub-steps per tier-2b / harvest window.  0 (default) = the scheme's own (RK4 4, RK2 4, RK3 3, LS5 2); 1..8 overrides it at run

@@ -304,8 +304,12 @@ def test_holdout_rule_based_controller_kernel_reproduces_the_references_controls
     XR, U = g["X"], g["U"]
     steps = np.arange(0, (len(XR) - 1) * stride, stride)[:961]
     B = len(steps)
-    env = TomatoVecEnv(B, weather=g["weather"], params=g["p"], dtype="float64", dt=dt, season_length=10, pred_horizon=0, start_rows=[0],
+    # as the harness does it (experiments/run_time.py:36-41): the env is CONSTRUCTED with the default block and `env.p = set_matlab_params(env.p)`
+    # follows -- the reward's scale (max / min profit) then belongs to the default block, its per-step costs to the new one (rewards.py:82-83, 164-166)
+    env = TomatoVecEnv(B, weather=g["weather"], dtype="float64", dt=dt, season_length=10, pred_horizon=0, start_rows=[0],
                        start_days=[start_day], auto_reset=False)
+    env.p = g["p"]
+    assert np.array_equal(env.p, g["p"].astype(np.float32))
     env.reset_tensor()
     x = XR[steps // stride].copy()
     if "x0" in g.files:
@@ -321,4 +325,20 @@ def test_holdout_rule_based_controller_kernel_reproduces_the_references_controls
     # dt = 300 s: the reference's clock is a running sum (tomato_env.py:127-128) that reads 17.999999999999996 at 18:00 -- TomatoVecEnv hands the
     # kernel that sum (tomato_env.py _hod_table); with the exact product 13 of these 960 steps switch the lamps one step apart
     assert err.max() < tol
+    # ... and the REWARD the reference's env returned for that step (rewards.py:156-231 with the fixture's dt: energy and CO2 costs scale with
+    # the step length, the fruit gain carries the one-step error of cFruit), through step_raw_control from the same teacher-forced states
+    obs, rew, done, info = env.step_tensor(controls_t=torch.as_tensor(U[steps].astype(np.float64), dtype=env.tdtype, device=env.device), want_obs=False)
+    d_rew = np.abs(rew.double().cpu().numpy() - g["reward"][steps])
+    first = 1 if "x0" in g.files else 0      # run_time.py sets the crop state AFTER reset(): the reference's first reward books the jump of cFruit as growth
+    report(f"{name:26s} reward of the same {B} steps against the reference env's: max |d reward| {d_rew[first:].max():.1e} "
+           f"(rewards {g['reward'][steps][first:].min():.3f} ... {g['reward'][steps][first:].max():.3f})")
+    assert d_rew[first:].max() < 2e-4
+    if "x0" in g.files:                      # ... and constructing the env WITH the new block scales the reward differently: the distinction is real
+        env2 = TomatoVecEnv(B, weather=g["weather"], params=g["p"], dtype="float64", dt=dt, season_length=10, pred_horizon=0, start_rows=[0],
+                            start_days=[start_day], auto_reset=False)
+        env2.reset_tensor()
+        env2.x.copy_(env.x * 0 + torch.as_tensor(x, dtype=env.tdtype, device=env.device)); env2.timestep_t.copy_(torch.as_tensor(steps, dtype=torch.int32, device=env.device))
+        _, rew2, _, _ = env2.step_tensor(controls_t=torch.as_tensor(U[steps].astype(np.float64), dtype=env.tdtype, device=env.device), want_obs=False)
+        assert np.abs(rew2.double().cpu().numpy() - g["reward"][steps])[first:].max() > 1e-2
+        env2.close()
     env.close()
