@@ -258,9 +258,9 @@ class TomatoVecEnv:
         # ---- weather tensor (shared by all envs) and the admissible episode start rows
         if weather is None:
             weather = synthetic_weather(dt=self.dt)
-        self.weather_data = (weather.detach().double().cpu().numpy() if weather_is_tensor
-                             else np.ascontiguousarray(weather, dtype=np.float64))
-        self.weather_rows = int(self.weather_data.shape[0])
+        self._weather_data = (weather.detach().double().cpu().numpy() if weather_is_tensor
+                              else np.ascontiguousarray(weather, dtype=np.float64))
+        self.weather_rows = int(self._weather_data.shape[0])
         need = self.N + 1 + self.Np + 1
         if self.weather_rows < need:
             raise ValueError(f"weather tensor has {self.weather_rows} rows, an episode needs {need}")
@@ -528,6 +528,33 @@ class TomatoVecEnv:
         return self.weather_t[idx]
 
     @property
+    def weather_data(self):
+        """The resident weather table [rows, nd] (float64 copy on the host).  ASSIGNING to it is the reference's `env.weather_data = table` on a
+        constructed env (experiments/run_time.py:39, gl_predefined_controls.py:114): the reference's step reads `weather_data[timestep]`, so the new
+        table is indexed from its row 0 by every environment, running episodes included (their `timestep` is kept), and later resets start at row
+        0 / the first start day.  The column count is fixed at construction (`nd`: 10, or 14 for the measured-pipe variant); a step graph captured before
+        the assignment holds the old table's address and has to be captured again."""
+        return self._weather_data
+
+    @weather_data.setter
+    def weather_data(self, table):
+        torch = self.torch
+        table = np.ascontiguousarray(table.detach().double().cpu().numpy() if hasattr(table, "detach") else table, dtype=np.float64)
+        if table.ndim != 2 or table.shape[1] != self._weather_data.shape[1]:
+            raise ValueError(f"weather_data: expected [rows, {self._weather_data.shape[1]}] like the table this env was built with, got {table.shape}")
+        need = self.N + 1 + self.Np + 1
+        if table.shape[0] < need:
+            raise ValueError(f"weather_data has {table.shape[0]} rows, an episode needs {need}")
+        self._weather_data = table
+        self.weather_rows = int(table.shape[0])
+        self.weather_t = torch.as_tensor(table, dtype=self.tdtype, device=self.device).contiguous()
+        self.start_rows = np.zeros(1, dtype=np.int64)
+        self.start_days = np.asarray(self.start_days[:1], dtype=np.float32)
+        self._start_rows_t = torch.as_tensor(self.start_rows, dtype=torch.int32, device=self.device)
+        self._start_days_t = torch.as_tensor(self.start_days, dtype=torch.float32, device=self.device)
+        self.w_off_t.zero_()
+
+    @property
     def p(self):
         """The shared parameter block (float32, tomato_env.py:62).  ASSIGNING to it is the reference's `env.p = new_p` on a constructed env
         (experiments/run_time.py:40-41: `env.p = set_matlab_params(env.p)`): the device model, the crop block and the reward's per-step cost
@@ -709,13 +736,17 @@ class TomatoEnv:
         v = self.vec
         self.nx, self.nu, self.nd, self.num_params, self.dt, self.c = v.nx, v.nu, v.nd, v.num_params, v.dt, v.c
         self.N, self.Np = v.N, v.Np
-        self.weather_data = v.weather_data
         self.observation_space, self.action_space = v.observation_space, v.action_space
         self.start_day, self.growth_year, self.location, self.training = start_day, growth_year, location, training
         self.u_min, self.u_max, self.delta_u_max = v.u_min, v.u_max, v.delta_u_max
         self.terminated = False
 
-    x = property(lambda self: self.vec.x[0].double().cpu().numpy())
+    def _set_x(self, value):          # `env.x = init_mat_state(...)` (gl_predefined_controls.py:116)
+        value = np.asarray(value, dtype=np.float64).reshape(L.NX)
+        self.vec.x_T[:, 0] = self.vec.torch.as_tensor(value, dtype=self.vec.tdtype, device=self.vec.device)
+
+    x = property(lambda self: self.vec.x[0].double().cpu().numpy(), _set_x)
+    weather_data = property(lambda self: self.vec.weather_data, lambda self, table: setattr(self.vec, "weather_data", table))   # run_time.py:39
     u = property(lambda self: self.vec.u[0].double().cpu().numpy())
     p = property(lambda self: self.vec.p, lambda self, value: setattr(self.vec, "p", value))     # `env.p = set_matlab_params(env.p)` (run_time.py:40)
     timestep = property(lambda self: int(self.vec.timestep_t[0]))

@@ -75,6 +75,41 @@ def test_single_env_wrapper_follows_reference_unit_tests(golden):
     env.close()
 
 
+def test_scripts_that_edit_a_constructed_env_weather_parameters_state(golden):
+    """experiments/run_time.py:36-48 and gl_predefined_controls.py:110-126 assign `env.weather_data`, `env.p` and `env.x` on an env that already
+    exists.  On the B = 1 wrapper each assignment reaches the device (none is a silent no-op) with the reference's meaning: the new table is read
+    from its row 0 at the current timestep, the new block drives the model, the state is replaced -- the next raw-control step equals, bit for
+    bit, that of an env CONSTRUCTED with that table and block and put into that state."""
+    from gl_gym_amd.tomato_env import TomatoEnv
+    g = golden("holdout_runtime_dt300")
+    w_a, w_b = golden("rollout_10day")["weather"], g["weather"]
+    u = np.array([0.3, 0.1, 0.6, 0.2, 1.0, 0.4])
+    env = TomatoEnv(weather=w_a, dtype="float64", season_length=1, start_day=0.0)
+    env.reset(seed=1)
+    env.weather_data = w_b
+    env.p = g["p"]
+    env.x = g["x0"]
+    assert np.array_equal(env.weather_data, w_b) and np.array_equal(env.p, g["p"].astype(np.float32)) and np.array_equal(env.x, g["x0"])
+    o1, r1, _, _, i1 = env.step_raw_control(u)
+    ref = TomatoEnv(weather=w_b, params=g["p"], dtype="float64", season_length=1, start_day=0.0)
+    ref.reset(seed=1)
+    ref.x = g["x0"]
+    o2, r2, _, _, i2 = ref.step_raw_control(u)
+    assert np.array_equal(env.x, ref.x) and np.array_equal(o1, o2)                     # state and observation: bit for bit
+    assert abs(r1 - r2) > 1e-3                                                         # the reward's SCALE stays the construction-time block's (rewards.py:82-83)
+    assert i1["heat_cost"] == i2["heat_cost"] and i1["co2_cost"] == i2["co2_cost"]     # ... its per-step costs follow the new one (rewards.py:164-166)
+    base = TomatoEnv(weather=w_a, dtype="float64", season_length=1, start_day=0.0)     # and none of it was a no-op: the untouched env goes elsewhere
+    base.reset(seed=1)
+    base.step_raw_control(u)
+    assert np.abs(base.x - env.x).max() > 1.0
+    with pytest.raises(ValueError):
+        env.weather_data = w_b[:, :7]                                                  # the column count is the handle's nd
+    with pytest.raises(ValueError):
+        env.weather_data = w_b[:20]                                                    # shorter than an episode
+    for e in (env, ref, base):
+        e.close()
+
+
 def test_greenlight_drop_in_signature(golden):
     """gl_gym.environments.models.greenlight_model.GreenLight contract (greenlight_model.cpp:130-136)."""
     from gl_gym_amd import GreenLight, GlgymError
