@@ -577,6 +577,40 @@ def test_run_time_configuration_dt300_no_forecast(golden):
     env.close()
 
 
+@pytest.mark.parametrize("pred_horizon,Np", [(1.0, 96), (0.26, 24), (0.0105, 1)])
+def test_other_forecast_horizons_against_the_env_oracle(golden, pred_horizon, Np):
+    """pred_horizon values other than the yml's 0.5 day and the harness's 0: the forecast block is 5 x Np floats (Np = int(pred_horizon
+    x 86400 / dt), base_env.py:89), its rows come from weather[timestep + 1 ...] -- row width, LDS span and gather bounds of obs_kernel all depend
+    on it.  Reset and three steps against the numpy env oracle for a few environments with their own episode starts."""
+    from gl_gym_amd.tomato_env import TomatoVecEnv
+    from oracle.gl_env_oracle import OracleTomatoEnv
+    w = golden("rollout_10day")["weather"]
+    B = 24
+    env = TomatoVecEnv(B, weather=w, dtype="float64", season_length=0.05, pred_horizon=pred_horizon, start_rows=[0, 7, 40],
+                       start_days=[0.0, 7 * 900 / 86400, 40 * 900 / 86400], seed=5, auto_reset=False)
+    assert env.Np == Np and env.obs_dim == 23 + 5 * Np
+    obs0 = env.reset()
+    w_off = env.w_off_t.cpu().numpy(); sd = env.start_day_t.cpu().numpy()
+    assert len(set(w_off.tolist())) == 3
+    rng = np.random.default_rng(4)
+    orcs = []
+    for b in range(0, B, 5):
+        o = OracleTomatoEnv(weather=w[w_off[b]:], p=env.p, season_length=0.05, pred_horizon=pred_horizon, integrator="rk4", n_sub=256,
+                            train_years=[0], train_days=[float(sd[b])], seed=0)
+        ob = o.reset()
+        assert ob.shape == (23 + 5 * Np,) and np.allclose(ob, obs0[b], rtol=2e-6, atol=1e-6)
+        orcs.append((b, o))
+    for k in range(3):
+        ctrl = rng.uniform(0, 1, (B, 6))
+        obs, rew, dones, info = env.step_raw_control(ctrl)
+        for b, o in orcs:
+            ob, r, term, inf = o.step_raw_control(ctrl[b])
+            assert np.allclose(ob[23:], obs[b][23:], rtol=2e-6, atol=2e-5)          # the forecast block: exact up to float32
+            assert np.allclose(ob[7:23], obs[b][7:23], rtol=2e-6, atol=2e-5)        # controls, weather, clocks
+            assert scaled_err(env.x[b].cpu().numpy(), o.x) < 1e-4                   # (two different sub-steppers: the state only loosely)
+    env.close()
+
+
 def test_custom_reward_prices_and_constraints(golden):
     """Prices, dmfm and the constraint box come from configs/envs/TomatoEnv.yml in the reference; non-default values must
     flow through glgym_set_reward into the kernel epilogue exactly like rewards.py uses them."""
