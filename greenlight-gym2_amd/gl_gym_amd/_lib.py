@@ -95,7 +95,7 @@ class RewardCfg(C.Structure):
 
 
 class StepArgs(C.Structure):
-    # struct_size first (ABI 5): glgym_step refuses a struct of another size; make_step_args() fills it
+    # struct_size first (since ABI 5): glgym_step refuses a struct of another size; make_step_args() fills it
     _fields_ = [("struct_size", C.c_int32), ("B", C.c_int32), ("ld", C.c_int32), ("x", C.c_void_p), ("u", C.c_void_p), ("action", C.c_void_p),
                 ("control", C.c_void_p), ("weather", C.c_void_p), ("weather_rows", C.c_int32), ("w_off", C.c_void_p),
                 ("timestep", C.c_void_p), ("crop_p", C.c_void_p), ("N", C.c_int32), ("reward", C.c_void_p),
