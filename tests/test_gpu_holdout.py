@@ -44,7 +44,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from conftest import judge_rollout as judge
+from conftest import judge_rollout as judge, STATE_NAMES
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,8 @@ def report(line):
         pass
 
 
+TEMPS = list(range(2, 15)) + list(range(17, 22))              # tAir ... tSo5, tLamp, tIntLamp, tGroPipe, tBlScr, tCan24
+OTHERS = [0, 1, 15, 16, 22, 23, 24, 25, 26]
 BUILDS = [("float32", "one", 1), ("float32", "one", 2), ("float32", "quad", 0), ("float64", "quad", 0)]
 BUILD_IDS = ["f32-one-lane", "f32-two-waves", "f32-quad", "f64-quad"]
 
@@ -116,12 +118,32 @@ def rollout(env, n_steps, actions=None, controls=None, x0=None, keep_every=1):
     return keep.cpu().numpy()
 
 
+def report_abs(name, tag, preset, pairs):
+    """The same comparison in ABSOLUTE terms for the temperatures (the relative metric divides a Celsius value by itself): the largest
+    temperature error in kelvin, and the relative metric restricted to everything that is not a temperature -> gpurun_out/r06_holdout_abs.txt"""
+    t_err, t_who, o_err = 0.0, "", 0.0
+    for X, XR in pairs:
+        n = min(len(X), len(XR))
+        d = np.abs(X[:n] - XR[:n])
+        sc = np.maximum(np.abs(XR[:n]), 1e-3 * np.abs(XR[:n]).max(axis=0))
+        if d[:, TEMPS].max() > t_err:
+            t_err, t_who = float(d[:, TEMPS].max()), STATE_NAMES[TEMPS[int(d[:, TEMPS].max(axis=0).argmax())]]
+        o_err = max(o_err, float((d / sc)[:, OTHERS].max()))
+    try:
+        with open(REPORT.with_name("r06_holdout_abs.txt"), "a") as f:
+            f.write(f"{name:26s} {tag:14s} {preset:10s} largest temperature error {t_err:.1e} K ({t_who}); "
+                    f"other states (CO2, vapour, crop pools, temperature sum), relative: {o_err:.1e}\n")
+    except OSError:
+        pass
+
+
 def check(name, tag, dtype, preset, X, XR, m, g, extra=""):
     plain, who, step, real, floor = judge(X, XR, abs_floor=1e-4 if dtype == "float64" else 2e-4)
     band = float(g["bdf_free"].max()) if "bdf_free" in g.files else float("nan")
     report(f"{name:26s} {tag:14s} {preset:10s} plain metric {plain:.2e} ({who} at kept step {step}); states above 1e-4 away from 0 C: {real} steps, "
            f"at the 0 C floor: {floor} steps; failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}, refined sub-steps per env-step "
            f"{m['n_refined_substeps'] / max(m['n_env_steps'], 1):.2f}; BDF-1e-6 free-running band {band:.2e}{extra}")
+    report_abs(name, tag, preset, [(X, XR)])
     assert m["n_ode_fail"] == 0
     assert real == 0, (name, tag, preset, plain, who, step)
     bound = PLAIN_BOUND[name][preset][0 if dtype == "float64" else 1]
@@ -216,6 +238,7 @@ def test_holdout_60_day_season_eight_distinct_environments(golden, dtype, layout
     report(f"{'holdout_season60':26s} {tag:14s} {preset:10s} plain metric {worst[0]:.2e} ({worst[1]} at day {worst[2]}; worst of 8 environments); states above 1e-4 "
            f"away from 0 C: {real}, at the 0 C floor: {floor}; failed {m['n_ode_fail']:.0f}, extra attempts {m['n_guard_retries']:.0f}, refined sub-steps per "
            f"env-step {m['n_refined_substeps'] / max(m['n_env_steps'], 1):.2f}")
+    report_abs("holdout_season60", tag, preset, [(X[b], XR[b]) for b in range(8)])
     assert m["n_ode_fail"] == 0 and real == 0
     assert worst[0] < PLAIN_BOUND["holdout_season60"][preset][0 if dtype == "float64" else 1]
     env.close()
