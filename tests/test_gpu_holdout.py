@@ -135,6 +135,10 @@ def report_abs(name, tag, preset, pairs):
                     f"other states (CO2, vapour, crop pools, temperature sum), relative: {o_err:.1e}\n")
     except OSError:
         pass
+    # asserted: temperatures to 1.5e-4 K at the throughput preset (measured <= 9.7e-5: the grow pipes) and 4e-5 K at parity (<= 2.6e-5);
+    # everything that is not a temperature inside the bar proper, 1e-4 relative (<= 4.3e-5)
+    assert t_err < (1.5e-4 if preset != "parity" else 4e-5), (name, tag, preset, t_err, t_who)
+    assert o_err < 1e-4, (name, tag, preset, o_err)
 
 
 def check(name, tag, dtype, preset, X, XR, m, g, extra=""):
