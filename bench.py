@@ -169,7 +169,7 @@ def cpu_baseline(n_sub: int, budget_s: float = 8.0, order: int = 4, window: int 
             "cpu_baseline_same_scheme_all_cores": rk_all}
 
 
-def parity_leg(args, dev, layout, n_sub=None, window=None, occupancy=0):
+def parity_leg(args, dev, layout, n_sub=None, window=None, occupancy=0, fixture="rollout_10day.npz", want_abs=False):
     """-> (max scaled state error over the 10-day fixture rollout, failed integrations, note).  64 identical environments (one
     wavefront of the one-lane kernel / 4 of the quad kernel); the fixture travels with the repository.  occupancy = 2: the timed
     batch ran the two-waves-per-SIMD build of the one-lane kernel (B >= 131 072 or GLGYM_OCC=2) -- the accuracy half is then
@@ -177,7 +177,7 @@ def parity_leg(args, dev, layout, n_sub=None, window=None, occupancy=0):
     import numpy as np
     import torch
     from gl_gym_amd.tomato_env import TomatoVecEnv
-    g = np.load(ROOT / "tests" / "golden" / "rollout_10day.npz")
+    g = np.load(ROOT / "tests" / "golden" / fixture)
     acts, w, XR = g["actions"], g["weather"], g["X"]
     env = TomatoVecEnv(64, weather=w, dtype="float64" if args.dtype == "f64" else "float32", n_sub=args.n_sub if n_sub is None else n_sub,
                        window=args.window if window is None else window, scheme=args.scheme,
@@ -197,7 +197,11 @@ def parity_leg(args, dev, layout, n_sub=None, window=None, occupancy=0):
     X = np.array(X)
     scale = np.maximum(np.abs(XR), 1e-3 * np.abs(XR).max(axis=0, keepdims=True))
     scale[scale == 0] = 1.0
-    return float(np.max(np.abs(X - XR) / scale)), float(failed), "rollout_10day.npz, %d steps" % len(acts)
+    if want_abs:        # + the largest TEMPERATURE error in kelvin and the metric restricted to the states that are not temperatures
+        temps = list(range(2, 15)) + list(range(17, 22)); others = [0, 1, 15, 16, 22, 23, 24, 25, 26]
+        return (float(np.max(np.abs(X - XR) / scale)), float(failed), float(np.abs(X - XR)[:, temps].max()),
+                float((np.abs(X - XR) / scale)[:, others].max()))
+    return float(np.max(np.abs(X - XR) / scale)), float(failed), "%s, %d steps" % (fixture, len(acts))
 
 
 def main():
@@ -400,8 +404,12 @@ def main():
     # two or more wavefronts per SIMD or GLGYM_OCC=2)
     occ_env0 = os.environ.get("GLGYM_OCC", "")
     occ_timed = 2 if (lay == "one" and not args.uncertainty and (occ_env0 == "2" or (occ_env0 != "1" and B >= 131072))) else 0
+    holdout = None
     if not args.no_parity:
         parity = parity_leg(args, dev, lay, occupancy=occ_timed)
+        if rank == 0 and (ROOT / "tests" / "golden" / "holdout_gl2010_random.npz").exists():
+            # the same leg on a fixture generated AFTER the sub-stepper's constants were frozen (round 6; tests/test_gpu_holdout.py)
+            holdout = parity_leg(args, dev, lay, occupancy=occ_timed, fixture="holdout_gl2010_random.npz", want_abs=True)
     # ---- the accuracy-speed trade on record: the same workload at the PARITY configuration (inside the band the reference solver's
     # tolerances keep from the tight solution; include/glgym.h), timed the same way over min(K, 200) steps, and its own 10-day error
     pcfg = None
@@ -577,6 +585,11 @@ def main():
                 "max_scaled_err_10day": agg["max_scaled_err"], "bar": 1e-4, "failed": agg["parity_failed"],
                 "fixture": "tests/golden/rollout_10day.npz: 961 env-steps (10 days, Bleiswijk weather, delta-u-bounded random "
                            "actions), truth = Radau rtol = atol = 1e-11 of the reference-text right-hand side",
+                "holdout": None if holdout is None else {
+                    "max_scaled_err": holdout[0], "failed": holdout[1], "max_temperature_err_K": holdout[2], "max_scaled_err_non_temperature": holdout[3],
+                    "fixture": "tests/golden/holdout_gl2010_random.npz: 961 env-steps of the reference's second weather file (GL2010 from day 20: "
+                               "frost), generated after the sub-stepper's constants were frozen; same truth.  Next to 0 C the metric divides a Celsius "
+                               "temperature by itself: the kelvin figure and the non-temperature figure say the same without that (DESIGN.md 2.8)"},
                 "kernel_build": ("one lane per environment, two-waves-per-SIMD build (as timed)" if occ_timed else
                                  ("one lane per environment, one-wave build (as timed)" if lay == "one" else "four lanes per environment (as timed)")),
                 "note": "the metric's second half (max |delta state| vs the reference solution), run after the timed region with the "
